@@ -1,0 +1,179 @@
+"""CPU tests: the oracle against the reference's fixed self-check inputs, the
+closed-form mu-law values, the committed goldens, and oracle (i) vs oracle (ii)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import wavenet_np as O
+from oracle import wavenet_torch as OT
+
+
+def test_reference_selfcheck_vectors(golden_dir):
+    """ops.py:243-254 fixed inputs; expected outputs by hand from ops.py:6-10."""
+    g = json.load(open(os.path.join(golden_dir, "ops_selfcheck.json")))
+    x = np.array(g["x"], dtype=np.float64).reshape(1, -1, 1)
+    for c in g["causal"]:
+        w = np.array(c["filt"], dtype=np.float64).reshape(c["shape"])
+        y = O.dilated_causal_conv1d(x, w, c["d"])
+        exp = np.array(c["out"], dtype=np.float64).T[None]
+        assert np.array_equal(y, exp), c["ref"]
+        yt = OT.causal_conv(torch.tensor(x).transpose(1, 2), torch.tensor(w), c["d"]).transpose(1, 2).numpy()
+        assert np.array_equal(yt, exp), c["ref"]
+    # ops.py:254: the un-padded VALID conv is the causal one minus its first K-1 steps
+    c = g["valid_nopad"]
+    w = np.array(c["filt"], dtype=np.float64).reshape(c["shape"])
+    y = O.dilated_causal_conv1d(x, w, 1)[:, 1:, :]
+    assert np.array_equal(y, np.array(c["out"], dtype=np.float64).T[None])
+
+
+def test_mu_law_closed_form(golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "mu_law.json")))
+    codes = O.mu_law_encode(np.array(g["audio"], dtype=np.float32), g["Q"])
+    assert codes.dtype == np.int32 and codes.tolist() == g["codes"]
+    dec = O.mu_law_decode(np.arange(256), 256)
+    assert dec.view(np.uint32).tolist() == g["decode_all_bits"]
+    assert O.mu_law_encode(dec, 256).tolist() == g["roundtrip"] == list(range(256))
+    assert dec[0] == -1.0 and dec[255] == 1.0 and abs(dec[128]) < 1e-4
+
+
+def test_mu_law_edges():
+    a = np.array([0.0, -0.0, 1e-9, -1e-9, 2.0, -2.0, np.float32(1) - np.float32(2 ** -24)], dtype=np.float32)
+    c = O.mu_law_encode(a, 256)
+    assert c.tolist() == [128, 128, 128, 127, 255, 0, 255]
+    assert c.min() >= 0 and c.max() <= 255
+    assert O.mu_law_encode(np.zeros((0,), np.float32), 256).shape == (0,)
+
+
+def test_nn_upsample_and_shift():
+    e = np.arange(2 * 3 * 2, dtype=np.float64).reshape(2, 3, 2)
+    up = O.resize_embedding_nearest_neighbor(e, 12)
+    assert np.array_equal(up, np.repeat(e, 4, axis=1))
+    x = np.arange(8.0).reshape(1, 8, 1)
+    assert O.right_shift(x)[0, :, 0].tolist() == [0, 0, 1, 2, 3, 4, 5, 6]
+
+
+def test_goldens_reproduce(golden_dir):
+    g = np.load(os.path.join(golden_dir, "layer_small.npz"))
+    for d in (1, 4, 32):
+        lp = O.LayerParams(g[f"d{d}_wf"], g[f"d{d}_bf"], None, None, g[f"d{d}_wr"], g[f"d{d}_br"],
+                           g[f"d{d}_ws"], g[f"d{d}_bs"])
+        dense, skip, _ = O.residual_dilation_layer(g["x"], lp, d)
+        assert np.allclose(dense, g[f"d{d}_dense"], rtol=0, atol=1e-14)
+        assert np.allclose(skip, g[f"d{d}_skip"], rtol=0, atol=1e-14)
+
+
+def _mk(seed, dil, R, S, C, cond=0):
+    return O.init_stack_params(seed, dil, 2, R, S, C, cond_channels=cond, bias_scale=0.1)
+
+
+@pytest.mark.parametrize("gate_mode", ["reference", "wavenet"])
+@pytest.mark.parametrize("with_cond", [False, True])
+def test_oracle_i_vs_ii_forward_backward(gate_mode, with_cond):
+    """Two independent restatements (hand backward vs autograd) agree to fp64 round-off."""
+    dil = [1, 2, 4, 8, 1, 2]
+    B, T, R, S, C, E, pool = 2, 64, 8, 16, 12, 5, 16
+    sp = _mk(3, dil, R, S, C, cond=E if with_cond else 0)
+    rng = np.random.default_rng(0)
+    audio = rng.uniform(-1, 1, (B, T))
+    codes = rng.integers(0, C, (B, T))
+    cond = rng.standard_normal((B, T // pool, E)) if with_cond else None
+    logits, cache = O.stack_forward(sp, audio, shift_input=True, cond=cond, pool_stride=pool, gate_mode=gate_mode)
+    loss = O.softmax_ce_per_timestep(logits, codes)
+    grads, extra = O.stack_backward(sp, cache, O.dlogits_per_timestep(logits, codes), cond=cond,
+                                    pool_stride=pool, gate_mode=gate_mode)
+
+    st = OT.TorchStack(sp)
+    tc = None if cond is None else torch.tensor(cond, requires_grad=True)
+    lt = st.forward(torch.tensor(audio), shift_input=True, cond=tc, pool_stride=pool, gate_mode=gate_mode)
+    assert np.allclose(lt.detach().numpy(), logits, rtol=1e-10, atol=1e-12)
+    ls = OT.loss_per_timestep(lt, torch.tensor(codes))
+    assert abs(float(ls.detach()) - loss) < 1e-12
+    ls.backward()
+    gn = dict(O.flatten_named(grads, with_cond))
+    for n, t in st.named(with_cond):
+        ref = np.zeros_like(gn[n]) if t.grad is None else t.grad.numpy()
+        assert np.allclose(gn[n], ref, rtol=1e-9, atol=1e-12), n
+    if with_cond:
+        assert np.allclose(extra["dcond"], tc.grad.numpy(), rtol=1e-9, atol=1e-12)
+
+
+def test_oracle_pooled_loss_grads():
+    dil = [1, 2, 4]
+    B, T, R, S, C = 3, 32, 8, 8, 10
+    sp = _mk(9, dil, R, S, C)
+    rng = np.random.default_rng(1)
+    audio = rng.uniform(-1, 1, (B, T))
+    tg = rng.random((B, C)); tg /= tg.sum(-1, keepdims=True)
+    logits, cache = O.stack_forward(sp, audio)
+    loss = O.wavenet_loss_pooled(logits, tg)
+    grads, _ = O.stack_backward(sp, cache, O.dlogits_pooled(logits, tg))
+    st = OT.TorchStack(sp)
+    lt = st.forward(torch.tensor(audio))
+    ls = OT.loss_pooled(lt, torch.tensor(tg))
+    assert abs(float(ls) - loss) < 1e-12
+    ls.backward()
+    gn = dict(O.flatten_named(grads, False))
+    for n, t in st.named(False):
+        ref = np.zeros_like(gn[n]) if t.grad is None else t.grad.numpy()
+        assert np.allclose(gn[n], ref, rtol=1e-9, atol=1e-13), n
+    # predict: softmax over pooled logits sums to one, shape [B,1,C]  (model.py:58-60)
+    pr = O.wavenet_predict(sp, audio)
+    assert pr.shape == (B, 1, C) and np.allclose(pr.sum(-1), 1)
+
+
+def test_stack_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "stack_small.npz"))
+    names = [k[2:] for k in g.files if k.startswith("p.")]
+    dil = g["dilations"].tolist()
+    L = len(dil)
+    layers = [O.LayerParams(g[f"p.l{i}.wf"], g[f"p.l{i}.bf"], None, None, g[f"p.l{i}.wr"], g[f"p.l{i}.br"],
+                            g[f"p.l{i}.ws"], g[f"p.l{i}.bs"]) for i in range(L)]
+    sp = O.StackParams(g["p.init_w"], g["p.init_b"], layers, g["p.head_w1"], g["p.head_b1"],
+                       g["p.head_w2"], g["p.head_b2"], tuple(dil))
+    logits, _ = O.stack_forward(sp, g["audio"], shift_input=True)
+    assert np.allclose(logits, g["logits"], rtol=0, atol=1e-12)
+    assert abs(O.softmax_ce_per_timestep(logits, g["codes"]) - float(g["loss"])) < 1e-12
+    assert len(names) == 2 + 6 * L + 4
+
+
+def test_causality():
+    """logits[:, :i+1] depend only on audio[:, :i+1] (pins incremental generation)."""
+    sp = _mk(2, [1, 2, 4, 8], 8, 8, 8)
+    rng = np.random.default_rng(4)
+    a = rng.uniform(-1, 1, (1, 40))
+    b = a.copy(); b[:, 25:] = rng.uniform(-1, 1, (1, 15))
+    la, _ = O.stack_forward(sp, a); lb, _ = O.stack_forward(sp, b)
+    assert np.array_equal(la[:, :25], lb[:, :25]) and not np.allclose(la[:, 25:], lb[:, 25:])
+    # with the teacher-forcing shift, step i sees only audio[:i]
+    la, _ = O.stack_forward(sp, a, shift_input=True); lb, _ = O.stack_forward(sp, b, shift_input=True)
+    assert np.array_equal(la[:, :26], lb[:, :26])
+
+
+def test_adam_tf_formula():
+    rng = np.random.default_rng(0)
+    th = rng.standard_normal(50); m = np.zeros(50); v = np.zeros(50)
+    p = torch.tensor(th.copy(), requires_grad=True)
+    opt = OT.TFAdam([p], lr=1e-2)
+    for t in range(1, 6):
+        g = rng.standard_normal(50)
+        th, m, v = O.adam_step_tf(th, g, m, v, t, lr=1e-2)
+        p.grad = torch.tensor(g)
+        opt.step()
+        assert np.allclose(p.detach().numpy(), th, rtol=1e-12, atol=1e-14)
+    # first step moves every coordinate by ~lr*sign(g) (epsilon on the uncorrected sqrt(v))
+    th1, _, _ = O.adam_step_tf(np.zeros(3), np.array([1.0, -2.0, 1e-3]), np.zeros(3), np.zeros(3), 1, lr=0.1)
+    assert np.allclose(th1, [-0.1, 0.1, -0.1], rtol=1e-3)
+
+
+def test_tf_variable_names():
+    sp = _mk(0, [1, 2], 8, 8, 8)
+    names = O.tf_variable_names(sp, "WaveNet")
+    for k in ("WaveNet/causal_conv_Kernel", "WaveNet/dilated_conv_1_filter/dilated_conv_1_Kernel",
+              "WaveNet/dilated_conv_0_gate/dilated_conv_0_Bias", "WaveNet/conv1d/kernel",
+              "WaveNet/conv1d_3/kernel", "WaveNet/conv1d_5/bias"):
+        assert k in names, k
+    assert names["WaveNet/conv1d/kernel"].shape == (1, 8, 8)
+    assert names["WaveNet/causal_conv_Bias"].shape == (1, 1, 8)
