@@ -1,0 +1,122 @@
+/* srwn.h -- C-ABI of libsrwn.so: MI355X (gfx950) kernels for the WaveNet residual-stack hot path.
+ *
+ * The reference (tachitachi/SR-WaveNet, TensorFlow 1.x Python) has NO native/FFI interface; its
+ * seam is the Python call surface of ops.py / model.py.  Each entry point below names the
+ * reference function (file:line under /root/reference) whose arithmetic it replaces; the host
+ * mirror of that Python surface lives in sr-wavenet_amd/{ops,model}.py and binds this header
+ * with ctypes.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller; nothing is allocated or freed here;
+ *  - `stream` is a hipStream_t passed as void*; launches are asynchronous on it; no call
+ *    synchronises, so every entry point may be captured into a hipGraph;
+ *  - return value: 0 = ok, >0 = hipError_t of the launch, <0 = argument error (SRWN_E_*);
+ *    srwn_last_error() returns a thread-local message for the last non-zero return;
+ *  - tensors are channels-last [B,T,C] / [rows,C] (ops.py:4); master weights are fp32 in the
+ *    reference's own shapes ([K,Cin,Cout] conv kernels, ops.py:5; [1,Cin,Cout] tf.layers.conv1d);
+ *  - `dtype` selects the activation/compute type: SRWN_F32 (exact fp32 MFMA, parity mode) or
+ *    SRWN_BF16 (bf16 MFMA, fp32 accumulate, throughput mode);
+ *  - "packed" weights are MFMA A-operand fragment images built by srwn_pack_a_index +
+ *    srwn_pack_gather from the fp32 master weights (layout: csrc/srwn_common.h).
+ */
+#ifndef SRWN_H
+#define SRWN_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SRWN_F32 0
+#define SRWN_BF16 1
+
+#define SRWN_E_DTYPE (-1)
+#define SRWN_E_SHAPE (-2)
+#define SRWN_E_NULL (-3)
+#define SRWN_E_UNSUPPORTED (-4)
+
+/* pw_linear prologue / epilogue selectors */
+#define SRWN_PRO_NONE 0
+#define SRWN_PRO_GATE 1 /* x -> x*sigmoid(x): rebuilds c = z*sigmoid(z) from stored z (ops.py:33,36) */
+#define SRWN_EPI_NONE 0
+#define SRWN_EPI_RELU 1
+#define SRWN_EPI_MASK 2 /* y *= (aux > 0): relu backward against the saved activation */
+
+int srwn_version(void);
+const char* srwn_last_error(void);
+
+/* ---- mu-law companding: ops.py:82-93 (encode) and ops.py:96-104 (decode); bit-exact vs the
+ *      oracle (log1p/pow evaluated in f64 and rounded once, every other step an IEEE f32 op). */
+int srwn_mu_law_encode(const float* audio, int32_t* codes, int64_t n, int32_t quantization_channels, void* stream);
+int srwn_mu_law_decode(const int32_t* codes, float* audio, int64_t n, int32_t quantization_channels, void* stream);
+
+/* ---- weight packing (no reference counterpart: TF keeps [K,Cin,Cout] and lets cuDNN/Eigen relayout)
+ * srwn_pack_a_index writes, for an A operand with `mt_count` 32-row tiles and k-steps
+ * [ks_offset, ks_offset+ks_count) of a packed image whose k extent is `ks_total` steps, the int32
+ * source index   src_offset + row*row_stride + k*k_stride   of every fragment element
+ * (row = output channel, k = contraction index local to this call), or -1 where row >= rows_valid
+ * or k >= k_valid (zero padding).  k-steps >= perm_from_ks (local) use the permuted k order.
+ * idx image: [mt_count][ks_total][64 lanes][8] int32, written at dst_idx.
+ * srwn_pack_gather then materialises dst[i] = (dtype) src[idx[i]] (0 where idx<0) in one launch. */
+int srwn_pack_a_index(int32_t* dst_idx, int32_t src_offset, int32_t rows_valid, int32_t k_valid,
+                      int32_t row_stride, int32_t k_stride, int32_t mt_count, int32_t ks_total,
+                      int32_t ks_offset, int32_t ks_count, int32_t perm_from_ks, void* stream);
+int srwn_pack_gather(const float* src, const int32_t* idx, void* dst, int64_t n, int32_t dtype, void* stream);
+
+/* ---- generic dilated causal conv: _DilatedCausalConv1d / DilatedCausalConv1d (ops.py:6-20)
+ * y[b,t,o] = bias[o] + sum_k sum_i x[b, t-(K-1-k)*dilation - shift, i] * w[k,i,o]  (zero for t<0).
+ * `shift` = 1 folds RightShift (ops.py:78-80) into the tap offsets.  x is fp32 (audio side);
+ * y is `dtype_out`.  Plain-VALU kernel: used for the Cin=1 input conv (model.py:40,173) and the
+ * ops-level API; the 64-channel hot conv lives inside srwn_residual_layer_fwd. */
+int srwn_causal_conv1d_fwd(const float* x, const float* w, const float* bias, void* y, int32_t B, int32_t T,
+                           int32_t Cin, int32_t Cout, int32_t K, int32_t dilation, int32_t shift,
+                           int32_t dtype_out, void* stream);
+/* gradient of the Cin=1 input conv wrt its kernel [K,1,R] and bias [R] (autodiff of model.py:40):
+ * gw[k,o] = sum_{b,t} audio[b,t-(K-1-k)-shift] * g[b,t,o]; gb[o] = sum g.  `partials` is a
+ * workspace of srwn_init_conv_wgrad_partials(B,T,R,K) floats; result written (not accumulated). */
+int64_t srwn_init_conv_wgrad_partials(int32_t B, int32_t T, int32_t R, int32_t K);
+int srwn_init_conv_wgrad(const float* audio, const void* g, float* partials, float* gw, float* gb, int32_t B,
+                         int32_t T, int32_t R, int32_t K, int32_t shift, int32_t dtype, void* stream);
+
+/* ---- fused residual layer forward: ResidualDilationLayer (ops.py:23-46) for K=2 taps, with the
+ * decoder's conditioning add (model.py:180-183; NN upsample ops.py:64-74 as t/pool_stride) fused in.
+ *   xin = x + cond[b, t/pool_stride, :]          (cond may be NULL)
+ *   z   = tanh(conv_K(xin) + bias_f)             -> z_out  (saved for skip GEMM and backward)
+ *   c   = z * sigmoid(z)                          (ops.py:33: the gate conv result is discarded)
+ *   h   = (xin + c @ Wr + bias_r) * sqrt(.5)      -> h_out
+ * The skip 1x1 (ops.py:44) is deferred to srwn_pw_linear over the stored z of all layers.
+ * wconv: packed [R/32][K*R/16] (last tap permuted k order), wres: packed [R/32][R/16] (permuted). */
+int srwn_residual_layer_fwd(const void* x, const void* cond, const void* wconv, const void* wres,
+                            const float* bias_f, const float* bias_r, void* h_out, void* z_out, int32_t B,
+                            int32_t T, int32_t R, int32_t K, int32_t dilation, int32_t cond_frames,
+                            int32_t pool_stride, int32_t dtype, void* stream);
+
+/* ---- pointwise linear ("channels GEMM"): tf.layers.conv1d kernel_size=1 (ops.py:39,44;
+ * model.py:53,56,180) and the sum of all skip 1x1s (model.py:50) as one K = L*R contraction:
+ *   y[row, n] = epi( bias[n] + sum_k pro(x[row, k]) * W[k, n] )
+ * Input channel k lives at  x + (k / chunk_len)*x_chunk_stride + row*x_row_stride + k % chunk_len
+ * (chunk = one layer's z tensor for the skip sum; chunk_len = Cin for an ordinary tensor).
+ * wpack: packed [Cout_pad/32][Cin/16] natural k order.  Rows n >= cout_valid are not stored.
+ * EPI_MASK multiplies by (aux[row, n] > 0) (aux row stride = aux_row_stride elements). */
+int srwn_pw_linear(const void* x, int64_t x_row_stride, int64_t x_chunk_stride, int32_t chunk_len, int32_t Cin,
+                   const void* wpack, const float* bias, void* y, int64_t y_row_stride, int32_t cout_pad,
+                   int32_t cout_valid, int64_t rows, const void* aux, int64_t aux_row_stride, int32_t pro,
+                   int32_t epi, int32_t dtype, void* stream);
+
+/* ---- last 1x1 + softmax head: model.py:56 then the mu-law softmax-CE the reference carries at
+ * model.py:100-112 (log-softmax as ops.py:111-115), per time step, fused in registers:
+ *   logits = bias + x @ W;  loss_row = logsumexp(logits) - logits[target]
+ *   dlogits = (softmax(logits) - onehot(target)) * grad_scale   -> dlogits (dtype), may be NULL
+ * logits_out (fp32, [rows, cout_valid]) may be NULL.  Per-tile loss sums go to loss_partials
+ * (srwn_softmax_ce_partials(rows) floats); srwn_reduce_loss sums them in a fixed order. */
+int64_t srwn_softmax_ce_partials(int64_t rows);
+int srwn_head_softmax_ce(const void* x, int64_t x_row_stride, int32_t Cin, const void* wpack, const float* bias,
+                         const int32_t* targets, float* loss_partials, void* dlogits, float* logits_out,
+                         int32_t cout_pad, int32_t cout_valid, int64_t rows, float grad_scale, int32_t dtype,
+                         void* stream);
+int srwn_reduce_loss(const float* loss_partials, int64_t n, float scale, float* loss_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRWN_H */

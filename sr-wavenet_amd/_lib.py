@@ -1,0 +1,68 @@
+"""ctypes binding of libsrwn.so (the C-ABI declared in include/srwn.h).
+
+The product path has NO fallback: if the HIP library is missing or a symbol is absent the import
+fails loudly, and every call raises RuntimeError on a non-zero return code.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsrwn.so")
+
+F32, BF16 = 0, 1
+PRO_NONE, PRO_GATE = 0, 1
+EPI_NONE, EPI_RELU, EPI_MASK = 0, 1, 2
+
+_p, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+# name -> (restype, argtypes); must list every symbol of include/srwn.h (checked by tests/test_abi.py)
+SIGNATURES = {
+    "srwn_version": (C.c_int, []),
+    "srwn_last_error": (C.c_char_p, []),
+    "srwn_mu_law_encode": (C.c_int, [_p, _p, _i64, _i32, _p]),
+    "srwn_mu_law_decode": (C.c_int, [_p, _p, _i64, _i32, _p]),
+    "srwn_pack_a_index": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    "srwn_pack_gather": (C.c_int, [_p, _p, _p, _i64, _i32, _p]),
+    "srwn_causal_conv1d_fwd": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    "srwn_init_conv_wgrad_partials": (_i64, [_i32, _i32, _i32, _i32]),
+    "srwn_init_conv_wgrad": (C.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    "srwn_residual_layer_fwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
+                                          _i32, _p]),
+    "srwn_pw_linear": (C.c_int, [_p, _i64, _i64, _i32, _i32, _p, _p, _p, _i64, _i32, _i32, _i64, _p, _i64, _i32,
+                                 _i32, _i32, _p]),
+    "srwn_softmax_ce_partials": (_i64, [_i64]),
+    "srwn_head_softmax_ce": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _p, _p, _p, _i32, _i32, _i64, _f32, _i32, _p]),
+    "srwn_reduce_loss": (C.c_int, [_p, _i64, _f32, _p, _p]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads libsrwn.so once and binds every symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libsrwn.so not found at %s: build it with `python sr-wavenet_amd/build.py` "
+            "(there is no CPU fallback for the product path)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Calls an int-returning entry point and raises RuntimeError on a non-zero code."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.srwn_last_error()
+        raise RuntimeError("%s failed (code %d): %s" % (name, rc, msg.decode() if msg else ""))
+    return rc

@@ -1,0 +1,146 @@
+// Shared device-side building blocks for the gfx950 (MI355X / CDNA4) WaveNet kernels.
+//
+// Orientation used by every MFMA kernel in this library ("channels on rows, time on lanes"):
+//   D[n][t] = sum_k A[n][k] * B[k][t]      A = weights (W^T), B = activations^T, D = output^T
+// with v_mfma_f32_32x32x16_bf16 (bf16 mode) or 8 x v_mfma_f32_32x32x2_f32 (exact fp32 mode).
+// * B fragments are 8 consecutive channels of one time row of a channels-last [rows][C] tensor:
+//   one 16-byte (bf16) load per lane, no LDS, no transpose.
+// * The accumulator tile (lane = time column, registers = channels) is directly the B operand of
+//   the next product that contracts over channels (gate -> 1x1 residual, dgrad chains), so the
+//   fused residual layer needs no LDS round trip for activations.
+// Lane maps (MI355X guide, "Fragment layout"): lane l: r = l&31, h = l>>5.
+//   A frag element j  = A[row r][k = kord(h,j)],  B frag element j = B[k = kord(h,j)][col r]
+//   C/D register  q   = D[row (q&3) + 8*(q>>2) + 4*h][col r]
+// "natural" k order kord = 8h + j; "permuted" k order kord = 8*(j>>2) + 4h + (j&3), which is the
+// order in which accumulator registers 8s..8s+7 present their rows when reused as a B operand.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace srwn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr float kSqrtHalf = 0.7071067811865476f;  // reference literal, ops.py:40
+
+// ----------------------------------------------------------------------------------------------
+// fragments: 8 elements of T per lane
+// ----------------------------------------------------------------------------------------------
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> {
+  bf16x8 v;
+  __device__ __forceinline__ float get(int j) const { return (float)v[j]; }
+  __device__ __forceinline__ void set(int j, float x) { v[j] = (bf16_t)x; }
+};
+template <> struct Frag<float> {
+  f32x4 lo, hi;
+  __device__ __forceinline__ float get(int j) const { return j < 4 ? lo[j] : hi[j - 4]; }
+  __device__ __forceinline__ void set(int j, float x) {
+    if (j < 4) lo[j] = x; else hi[j - 4] = x;
+  }
+};
+
+template <typename T> __device__ __forceinline__ Frag<T> zero_frag();
+template <> __device__ __forceinline__ Frag<bf16_t> zero_frag<bf16_t>() {
+  Frag<bf16_t> f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f.v[j] = (bf16_t)0.0f;
+  return f;
+}
+template <> __device__ __forceinline__ Frag<float> zero_frag<float>() {
+  Frag<float> f;
+  f.lo = f32x4{0.f, 0.f, 0.f, 0.f};
+  f.hi = f32x4{0.f, 0.f, 0.f, 0.f};
+  return f;
+}
+
+// natural order: p points at the lane's first element (caller adds +8*h)
+__device__ __forceinline__ Frag<bf16_t> load_nat(const bf16_t* p) {
+  Frag<bf16_t> f;
+  f.v = *reinterpret_cast<const bf16x8*>(p);
+  return f;
+}
+__device__ __forceinline__ Frag<float> load_nat(const float* p) {
+  Frag<float> f;
+  f.lo = *reinterpret_cast<const f32x4*>(p);
+  f.hi = *reinterpret_cast<const f32x4*>(p + 4);
+  return f;
+}
+// permuted order: elements 0-3 at p[0..3], 4-7 at p[8..11] (caller adds +4*h)
+__device__ __forceinline__ Frag<bf16_t> load_perm(const bf16_t* p) {
+  bf16x4 a = *reinterpret_cast<const bf16x4*>(p);
+  bf16x4 b = *reinterpret_cast<const bf16x4*>(p + 8);
+  Frag<bf16_t> f;
+  f.v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  return f;
+}
+__device__ __forceinline__ Frag<float> load_perm(const float* p) {
+  Frag<float> f;
+  f.lo = *reinterpret_cast<const f32x4*>(p);
+  f.hi = *reinterpret_cast<const f32x4*>(p + 8);
+  return f;
+}
+
+// one 32x32 output tile, 16-deep contraction
+__device__ __forceinline__ void mma(f32x16& acc, const Frag<bf16_t>& a, const Frag<bf16_t>& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma(f32x16& acc, const Frag<float>& a, const Frag<float>& b) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.lo[j], b.lo[j], acc, 0, 0, 0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi[j], b.hi[j], acc, 0, 0, 0);
+}
+
+// row (channel) held by accumulator register q in lane half h, within its 32-row tile
+__device__ __forceinline__ constexpr int crow(int q, int h) { return (q & 3) + 8 * (q >> 2) + 4 * h; }
+
+// 4 consecutive channels of one time row, from/to accumulator group g (registers 4g..4g+3)
+__device__ __forceinline__ void store4(bf16_t* p, float a, float b, float c, float d) {
+  bf16x4 v;
+  v[0] = (bf16_t)a; v[1] = (bf16_t)b; v[2] = (bf16_t)c; v[3] = (bf16_t)d;
+  *reinterpret_cast<bf16x4*>(p) = v;
+}
+__device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
+  *reinterpret_cast<f32x4*>(p) = f32x4{a, b, c, d};
+}
+__device__ __forceinline__ f32x4 load4(const bf16_t* p) {
+  bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+  return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+__device__ __forceinline__ f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// ----------------------------------------------------------------------------------------------
+// nonlinearities.  fp32 mode = libm-accurate (parity <= 1e-3 vs the oracle); bf16 mode = hardware
+// exp2/rcp (their ~1 ulp error is far below the bf16 storage rounding).
+// ----------------------------------------------------------------------------------------------
+template <typename T> struct Math;
+template <> struct Math<float> {
+  static __device__ __forceinline__ float tanh_(float x) { return tanhf(x); }
+  static __device__ __forceinline__ float sigmoid_(float x) { return 1.0f / (1.0f + expf(-x)); }
+};
+template <> struct Math<bf16_t> {
+  static __device__ __forceinline__ float tanh_(float x) {
+    float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);  // exp(2x)
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+  }
+  static __device__ __forceinline__ float sigmoid_(float x) {
+    float e = __builtin_amdgcn_exp2f(x * -1.4426950408889634f);  // exp(-x)
+    return __builtin_amdgcn_rcpf(1.0f + e);
+  }
+};
+
+// the reference's gate (ops.py:28-36, incl. the discarded-gate-conv behaviour of line 33):
+//   z = tanh(f); c = z * sigmoid(z)
+template <typename T> __device__ __forceinline__ float gate_of_z(float z) { return z * Math<T>::sigmoid_(z); }
+// d c / d f  = (s + z s (1-s)) * (1 - z^2)
+template <typename T> __device__ __forceinline__ float dgate_df(float z) {
+  float s = Math<T>::sigmoid_(z);
+  return (s + z * s * (1.0f - s)) * (1.0f - z * z);
+}
+
+}  // namespace srwn

@@ -1,0 +1,472 @@
+// Forward kernels: fused residual layer, pointwise linear (channels GEMM), softmax-CE head.
+// gfx950 (MI355X) only; see srwn_common.h for the MFMA orientation and lane maps.
+#include "srwn_common.h"
+#include "srwn_host.h"
+#include "../../include/srwn.h"
+
+using namespace srwn;
+
+// ------------------------------------------------------------------------------------------
+// fused residual layer forward (ops.py:23-46 + model.py:180-183)
+//   grid = (ceil(T / (4*32*NT)), B), block = 4 waves; each wave owns NT column tiles of 32 time steps.
+//   LDS holds only the layer's packed weights (A fragments); activations go HBM -> VGPR -> MFMA.
+// ------------------------------------------------------------------------------------------
+template <typename T, int RT, int K, int NT, bool COND>
+__global__ __launch_bounds__(256) void layer_fwd_kernel(const T* __restrict__ x, const T* __restrict__ cond,
+                                                        const T* __restrict__ wconv, const T* __restrict__ wres,
+                                                        const float* __restrict__ bias_f,
+                                                        const float* __restrict__ bias_r, T* __restrict__ h_out,
+                                                        T* __restrict__ z_out, int Tlen, int dilation,
+                                                        int cond_frames, int pool) {
+  constexpr int R = 32 * RT;
+  constexpr int KS = R / 16;  // k-steps per tap
+  constexpr int NCONV = RT * K * KS, NRES = RT * KS;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  Frag<T>* lds_conv = reinterpret_cast<Frag<T>*>(smem);
+  Frag<T>* lds_res = lds_conv + NCONV * 64;
+  {
+    const Frag<T>* gc = reinterpret_cast<const Frag<T>*>(wconv);
+    const Frag<T>* gr = reinterpret_cast<const Frag<T>*>(wres);
+    for (int i = threadIdx.x; i < NCONV * 64; i += 256) lds_conv[i] = gc[i];
+    for (int i = threadIdx.x; i < NRES * 64; i += 256) lds_res[i] = gr[i];
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 31, half = lane >> 5;
+  const int b = blockIdx.y;
+  const int t_wave = (blockIdx.x * 4 + wave) * (32 * NT);
+  if (t_wave >= Tlen) return;
+  const T* xb = x + (size_t)b * Tlen * R;
+  const T* cb = COND ? cond + (size_t)b * cond_frames * R : nullptr;
+
+  // ---- B fragments: taps 0..K-2 natural k order, last tap (shift 0) permuted so that its
+  //      registers are also the residual-add operand in accumulator layout.
+  Frag<T> bx[NT][K][KS];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int tc = t_wave + 32 * nt + col;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int tk = tc - (K - 1 - k) * dilation;
+      const bool valid = (tc < Tlen) && (tk >= 0);
+      const T* row = xb + (size_t)(valid ? tk : 0) * R;
+      const T* crow_ = COND ? cb + (size_t)((valid ? tk : 0) / pool) * R : nullptr;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        Frag<T> f;
+        if (k == K - 1) {
+          f = valid ? load_perm(row + 16 * ks + 4 * half) : zero_frag<T>();
+          if (COND && valid) {
+            Frag<T> c = load_perm(crow_ + 16 * ks + 4 * half);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f.set(j, f.get(j) + c.get(j));
+          }
+        } else {
+          f = valid ? load_nat(row + 16 * ks + 8 * half) : zero_frag<T>();
+          if (COND && valid) {
+            Frag<T> c = load_nat(crow_ + 16 * ks + 8 * half);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f.set(j, f.get(j) + c.get(j));
+          }
+        }
+        bx[nt][k][ks] = f;
+      }
+    }
+  }
+
+  // ---- dilated causal conv as one (K*R)-deep contraction; accumulators start at the bias
+  f32x16 accF[RT][NT];
+#pragma unroll
+  for (int mt = 0; mt < RT; ++mt) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const float bv = bias_f[32 * mt + crow(q, half)];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) accF[mt][nt][q] = bv;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int mt = 0; mt < RT; ++mt) {
+        const Frag<T> a = lds_conv[(mt * (K * KS) + k * KS + ks) * 64 + lane];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) mma(accF[mt][nt], a, bx[nt][k][ks]);
+      }
+    }
+  }
+
+  // ---- epilogue per column tile: tanh, gate, 1x1 residual from registers, scaled residual add
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int tc = t_wave + 32 * nt + col;
+    const bool ok = tc < Tlen;
+    T* zrow = z_out + ((size_t)b * Tlen + (ok ? tc : 0)) * R;
+    T* hrow = h_out + ((size_t)b * Tlen + (ok ? tc : 0)) * R;
+    Frag<T> cf[KS];
+#pragma unroll
+    for (int mt = 0; mt < RT; ++mt) {
+      float zz[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float z = Math<T>::tanh_(accF[mt][nt][q]);
+        zz[q] = z;
+        cf[2 * mt + (q >> 3)].set(q & 7, gate_of_z<T>(z));
+      }
+      if (ok) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          store4(zrow + 32 * mt + 8 * g + 4 * half, zz[4 * g], zz[4 * g + 1], zz[4 * g + 2], zz[4 * g + 3]);
+      }
+    }
+    f32x16 accR[RT];
+#pragma unroll
+    for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) accR[mt][q] = bias_r[32 * mt + crow(q, half)];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int mt = 0; mt < RT; ++mt) {
+        const Frag<T> a = lds_res[(mt * KS + s) * 64 + lane];
+        mma(accR[mt], a, cf[s]);
+      }
+    if (ok) {
+#pragma unroll
+      for (int mt = 0; mt < RT; ++mt) {
+        float hv[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const float xin = bx[nt][K - 1][2 * mt + (q >> 3)].get(q & 7);
+          hv[q] = (xin + accR[mt][q]) * kSqrtHalf;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          store4(hrow + 32 * mt + 8 * g + 4 * half, hv[4 * g], hv[4 * g + 1], hv[4 * g + 2], hv[4 * g + 3]);
+      }
+    }
+  }
+}
+
+template <typename T, int RT, int K, int NT>
+static int launch_layer_fwd(const void* x, const void* cond, const void* wconv, const void* wres,
+                            const float* bias_f, const float* bias_r, void* h_out, void* z_out, int B, int Tlen,
+                            int dilation, int cond_frames, int pool, hipStream_t st) {
+  constexpr int R = 32 * RT, KS = R / 16;
+  const size_t sh = (size_t)(RT * K * KS + RT * KS) * 64 * sizeof(Frag<T>);
+  dim3 grid((unsigned)((Tlen + 4 * 32 * NT - 1) / (4 * 32 * NT)), (unsigned)B), block(256);
+  if (cond) {
+    auto kfn = layer_fwd_kernel<T, RT, K, NT, true>;
+    if (sh > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipLaunchKernelGGL(kfn, grid, block, sh, st, (const T*)x, (const T*)cond, (const T*)wconv, (const T*)wres, bias_f,
+                       bias_r, (T*)h_out, (T*)z_out, Tlen, dilation, cond_frames, pool);
+  } else {
+    auto kfn = layer_fwd_kernel<T, RT, K, NT, false>;
+    if (sh > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipLaunchKernelGGL(kfn, grid, block, sh, st, (const T*)x, (const T*)nullptr, (const T*)wconv, (const T*)wres,
+                       bias_f, bias_r, (T*)h_out, (T*)z_out, Tlen, dilation, 1, 1);
+  }
+  return check_launch("residual_layer_fwd");
+}
+
+extern "C" int srwn_residual_layer_fwd(const void* x, const void* cond, const void* wconv, const void* wres,
+                                       const float* bias_f, const float* bias_r, void* h_out, void* z_out,
+                                       int32_t B, int32_t T, int32_t R, int32_t K, int32_t dilation,
+                                       int32_t cond_frames, int32_t pool_stride, int32_t dtype, void* stream) {
+  if (B == 0 || T == 0) return 0;
+  if (!x || !wconv || !wres || !bias_f || !bias_r || !h_out || !z_out)
+    return set_error(SRWN_E_NULL, "residual_layer_fwd: null pointer");
+  if (B < 0 || T < 0 || dilation < 1) return set_error(SRWN_E_SHAPE, "residual_layer_fwd: B=%d T=%d d=%d", B, T, dilation);
+  if (cond && (pool_stride < 1 || (int64_t)cond_frames * pool_stride < T))
+    return set_error(SRWN_E_SHAPE, "residual_layer_fwd: cond frames %d x pool %d < T %d", cond_frames, pool_stride, T);
+  if (K != 2) return set_error(SRWN_E_UNSUPPORTED, "residual_layer_fwd: filter_width %d (only 2 is built)", K);
+  hipStream_t st = (hipStream_t)stream;
+#define SRWN_LF(TT, RT_, NT_) \
+  return launch_layer_fwd<TT, RT_, 2, NT_>(x, cond, wconv, wres, bias_f, bias_r, h_out, z_out, B, T, dilation, cond_frames, pool_stride, st)
+  if (dtype == SRWN_BF16) {
+    if (R == 32) SRWN_LF(bf16_t, 1, 2);
+    if (R == 64) SRWN_LF(bf16_t, 2, 2);
+  } else if (dtype == SRWN_F32) {
+    if (R == 32) SRWN_LF(float, 1, 1);
+    if (R == 64) SRWN_LF(float, 2, 1);
+  } else {
+    return set_error(SRWN_E_DTYPE, "residual_layer_fwd: dtype %d", dtype);
+  }
+#undef SRWN_LF
+  return set_error(SRWN_E_UNSUPPORTED, "residual_layer_fwd: dilation_channels %d (built: 32, 64)", R);
+}
+
+// ------------------------------------------------------------------------------------------
+// pointwise linear: y^T[n][row] = epi(bias[n] + sum_k W[k][n] * pro(x[row][k]))
+//   grid = (ceil(rows / (4*32*NT)), cout_pad / (32*MT)); wave = NT column tiles x MT row tiles.
+//   A fragments stream from the packed global image (L2-resident; identical for all waves).
+// ------------------------------------------------------------------------------------------
+struct PwArgs {
+  const void* x; int64_t x_row_stride; int64_t x_chunk_stride; int chunk_len; int ks_total;
+  const void* wpack; const float* bias; void* y; int64_t y_row_stride; int cout_valid; int64_t rows;
+  const void* aux; int64_t aux_row_stride;
+};
+
+template <typename T, int PRO>
+__device__ __forceinline__ Frag<T> pw_load_b(const PwArgs& a, int64_t row, bool valid, int ks, int half) {
+  if (!valid) return zero_frag<T>();
+  const int kg = 16 * ks;
+  const int chunk = kg / a.chunk_len, within = kg - chunk * a.chunk_len;
+  const T* p = reinterpret_cast<const T*>(a.x) + (int64_t)chunk * a.x_chunk_stride + row * a.x_row_stride + within +
+               8 * half;
+  Frag<T> f = load_nat(p);
+  if (PRO == SRWN_PRO_GATE) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f.set(j, gate_of_z<T>(f.get(j)));
+  }
+  return f;
+}
+
+template <typename T, int MT, int NT, int PRO, int EPI>
+__global__ __launch_bounds__(256) void pw_linear_kernel(PwArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 31, half = lane >> 5;
+  const int64_t row_wave = ((int64_t)blockIdx.x * 4 + wave) * (32 * NT);
+  if (row_wave >= a.rows) return;
+  const int mb = blockIdx.y;  // block of MT row tiles
+  const Frag<T>* wp = reinterpret_cast<const Frag<T>*>(a.wpack) + (size_t)mb * MT * a.ks_total * 64 + lane;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int n = 32 * (mb * MT + mt) + crow(q, half);
+      const float bv = (a.bias && n < a.cout_valid) ? a.bias[n] : 0.0f;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt][q] = bv;
+    }
+
+  int64_t rowc[NT];
+  bool valid[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    rowc[nt] = row_wave + 32 * nt + col;
+    valid[nt] = rowc[nt] < a.rows;
+  }
+
+  for (int ks = 0; ks < a.ks_total; ++ks) {
+    Frag<T> bf[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bf[nt] = pw_load_b<T, PRO>(a, rowc[nt], valid[nt], ks, half);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const Frag<T> af = wp[((size_t)mt * a.ks_total + ks) * 64];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) mma(acc[mt][nt], af, bf[nt]);
+    }
+  }
+
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    if (!valid[nt]) continue;
+    T* yrow = reinterpret_cast<T*>(a.y) + rowc[nt] * a.y_row_stride;
+    const T* arow = (EPI == SRWN_EPI_MASK) ? reinterpret_cast<const T*>(a.aux) + rowc[nt] * a.aux_row_stride : nullptr;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n0 = 32 * (mb * MT + mt) + 8 * g + 4 * half;
+        if (n0 >= a.cout_valid) continue;  // cout_valid is a multiple of 4 (checked on the host)
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * g + e];
+        if (EPI == SRWN_EPI_RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+        } else if (EPI == SRWN_EPI_MASK) {
+          const f32x4 m = load4(arow + n0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (m[e] > 0.0f) ? v[e] : 0.0f;
+        }
+        store4(yrow + n0, v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+}
+
+template <typename T, int MT, int NT>
+static int launch_pw(const PwArgs& a, int cout_pad, int pro, int epi, hipStream_t st) {
+  dim3 grid((unsigned)((a.rows + 4 * 32 * NT - 1) / (4 * 32 * NT)), (unsigned)(cout_pad / (32 * MT))), block(256);
+#define SRWN_PW(P, E)                                                                                   \
+  if (pro == P && epi == E) {                                                                           \
+    hipLaunchKernelGGL((pw_linear_kernel<T, MT, NT, P, E>), grid, block, 0, st, a);                     \
+    return check_launch("pw_linear");                                                                   \
+  }
+  SRWN_PW(SRWN_PRO_NONE, SRWN_EPI_NONE)
+  SRWN_PW(SRWN_PRO_NONE, SRWN_EPI_RELU)
+  SRWN_PW(SRWN_PRO_NONE, SRWN_EPI_MASK)
+  SRWN_PW(SRWN_PRO_GATE, SRWN_EPI_NONE)
+  SRWN_PW(SRWN_PRO_GATE, SRWN_EPI_RELU)
+#undef SRWN_PW
+  return set_error(SRWN_E_UNSUPPORTED, "pw_linear: pro %d / epi %d combination not built", pro, epi);
+}
+
+extern "C" int srwn_pw_linear(const void* x, int64_t x_row_stride, int64_t x_chunk_stride, int32_t chunk_len,
+                              int32_t Cin, const void* wpack, const float* bias, void* y, int64_t y_row_stride,
+                              int32_t cout_pad, int32_t cout_valid, int64_t rows, const void* aux,
+                              int64_t aux_row_stride, int32_t pro, int32_t epi, int32_t dtype, void* stream) {
+  if (rows == 0) return 0;
+  if (!x || !wpack || !y) return set_error(SRWN_E_NULL, "pw_linear: null pointer");
+  if (epi == SRWN_EPI_MASK && !aux) return set_error(SRWN_E_NULL, "pw_linear: EPI_MASK needs aux");
+  if (rows < 0 || Cin < 16 || Cin % 16 || chunk_len < 16 || chunk_len % 16 || Cin % chunk_len || cout_pad < 32 ||
+      cout_pad % 32 || cout_valid < 4 || cout_valid % 4 || cout_valid > cout_pad)
+    return set_error(SRWN_E_SHAPE, "pw_linear: rows=%lld Cin=%d chunk=%d cout_pad=%d cout_valid=%d", (long long)rows,
+                     Cin, chunk_len, cout_pad, cout_valid);
+  PwArgs a{x, x_row_stride, x_chunk_stride, chunk_len, Cin / 16, wpack, bias, y, y_row_stride, cout_valid, rows, aux,
+           aux_row_stride};
+  hipStream_t st = (hipStream_t)stream;
+  const int tiles = cout_pad / 32;
+  if (dtype == SRWN_BF16) {
+    if (tiles % 4 == 0) return launch_pw<bf16_t, 4, 2>(a, cout_pad, pro, epi, st);
+    if (tiles % 2 == 0) return launch_pw<bf16_t, 2, 2>(a, cout_pad, pro, epi, st);
+    return launch_pw<bf16_t, 1, 2>(a, cout_pad, pro, epi, st);
+  } else if (dtype == SRWN_F32) {
+    if (tiles % 4 == 0) return launch_pw<float, 4, 1>(a, cout_pad, pro, epi, st);
+    if (tiles % 2 == 0) return launch_pw<float, 2, 1>(a, cout_pad, pro, epi, st);
+    return launch_pw<float, 1, 1>(a, cout_pad, pro, epi, st);
+  }
+  return set_error(SRWN_E_DTYPE, "pw_linear: dtype %d", dtype);
+}
+
+// ------------------------------------------------------------------------------------------
+// last 1x1 + per-time-step softmax cross-entropy, fused in registers.
+//   One wave = one column tile of 32 time steps x ALL classes (MT = cout_pad/32 row tiles): a lane
+//   holds half of its time step's logits, lane^32 the other half -> one cross-half exchange.
+// ------------------------------------------------------------------------------------------
+struct HeadArgs {
+  const void* x; int64_t x_row_stride; int ks_total; const void* wpack; const float* bias;
+  const int32_t* targets; float* loss_partials; void* dlogits; float* logits_out;
+  int cout_valid; int64_t rows; float grad_scale;
+};
+
+template <typename T, int MT>
+__global__ __launch_bounds__(256) void head_softmax_ce_kernel(HeadArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 31, half = lane >> 5;
+  const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t row_wave = tile * 32;
+  if (row_wave >= a.rows) return;
+  const int64_t row = row_wave + col;
+  const bool valid = row < a.rows;
+  const Frag<T>* wp = reinterpret_cast<const Frag<T>*>(a.wpack) + lane;
+
+  f32x16 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int n = 32 * mt + crow(q, half);
+      acc[mt][q] = (a.bias && n < a.cout_valid) ? a.bias[n] : 0.0f;
+    }
+  const T* xr = reinterpret_cast<const T*>(a.x) + (valid ? row : 0) * a.x_row_stride + 8 * half;
+
+  for (int ks = 0; ks < a.ks_total; ++ks) {
+    const Frag<T> bf = valid ? load_nat(xr + 16 * ks) : zero_frag<T>();
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const Frag<T> af = wp[((size_t)mt * a.ks_total + ks) * 64];
+      mma(acc[mt], af, bf);
+    }
+  }
+
+  // log-softmax over the class axis (ops.py:111-115): registers x two lane halves
+  const int tgt = valid ? a.targets[row] : -1;
+  float m = -INFINITY, vt = 0.0f;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int n = 32 * mt + crow(q, half);
+      if (n < a.cout_valid) m = fmaxf(m, acc[mt][q]);
+      if (n == tgt) vt = acc[mt][q];
+    }
+  m = fmaxf(m, __shfl_xor(m, 32));
+  vt += __shfl_xor(vt, 32);
+  float s = 0.0f;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int n = 32 * mt + crow(q, half);
+      if (n < a.cout_valid) s += expf(acc[mt][q] - m);
+    }
+  s += __shfl_xor(s, 32);
+  const float lse = m + logf(s);
+  float loss = (valid && half == 0) ? (lse - vt) : 0.0f;
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) loss += __shfl_xor(loss, off);  // sums within each 32-lane half
+  if (lane == 0) a.loss_partials[tile] = loss;
+
+  if (!valid) return;
+  if (a.logits_out) {
+    float* lr = a.logits_out + row * (int64_t)a.cout_valid;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int n = 32 * mt + crow(q, half);
+        if (n < a.cout_valid) lr[n] = acc[mt][q];
+      }
+  }
+  if (a.dlogits) {
+    T* dr = reinterpret_cast<T*>(a.dlogits) + row * (int64_t)(32 * MT);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int n = 32 * mt + 8 * g + 4 * half + e;
+          const float p = (n < a.cout_valid) ? expf(acc[mt][4 * g + e] - lse) : 0.0f;
+          v[e] = (p - (n == tgt ? 1.0f : 0.0f)) * a.grad_scale;
+        }
+        store4(dr + 32 * mt + 8 * g + 4 * half, v[0], v[1], v[2], v[3]);
+      }
+  }
+}
+
+extern "C" int64_t srwn_softmax_ce_partials(int64_t rows) { return (rows + 31) / 32; }
+
+extern "C" int srwn_head_softmax_ce(const void* x, int64_t x_row_stride, int32_t Cin, const void* wpack,
+                                    const float* bias, const int32_t* targets, float* loss_partials, void* dlogits,
+                                    float* logits_out, int32_t cout_pad, int32_t cout_valid, int64_t rows,
+                                    float grad_scale, int32_t dtype, void* stream) {
+  if (rows == 0) return 0;
+  if (!x || !wpack || !targets || !loss_partials) return set_error(SRWN_E_NULL, "head_softmax_ce: null pointer");
+  if (rows < 0 || Cin < 16 || Cin % 16 || cout_pad % 32 || cout_pad < 32 || cout_pad > 256 || cout_valid < 1 ||
+      cout_valid > cout_pad)
+    return set_error(SRWN_E_SHAPE, "head_softmax_ce: rows=%lld Cin=%d cout_pad=%d cout_valid=%d (cout_pad <= 256)",
+                     (long long)rows, Cin, cout_pad, cout_valid);
+  HeadArgs a{x, x_row_stride, Cin / 16, wpack, bias, targets, loss_partials, dlogits, logits_out, cout_valid, rows,
+             grad_scale};
+  const int64_t tiles = (rows + 31) / 32;
+  dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  const int mt = cout_pad / 32;
+#define SRWN_HD(TT, M)                                                                  \
+  if (mt == M) {                                                                        \
+    hipLaunchKernelGGL((head_softmax_ce_kernel<TT, M>), grid, block, 0, st, a);         \
+    return check_launch("head_softmax_ce");                                             \
+  }
+  if (dtype == SRWN_BF16) {
+    SRWN_HD(bf16_t, 1) SRWN_HD(bf16_t, 2) SRWN_HD(bf16_t, 3) SRWN_HD(bf16_t, 4) SRWN_HD(bf16_t, 5) SRWN_HD(bf16_t, 6)
+    SRWN_HD(bf16_t, 7) SRWN_HD(bf16_t, 8)
+  } else if (dtype == SRWN_F32) {
+    SRWN_HD(float, 1) SRWN_HD(float, 2) SRWN_HD(float, 3) SRWN_HD(float, 4) SRWN_HD(float, 5) SRWN_HD(float, 6)
+    SRWN_HD(float, 7) SRWN_HD(float, 8)
+  } else {
+    return set_error(SRWN_E_DTYPE, "head_softmax_ce: dtype %d", dtype);
+  }
+#undef SRWN_HD
+  return set_error(SRWN_E_UNSUPPORTED, "head_softmax_ce: cout_pad %d", cout_pad);
+}

@@ -1,0 +1,297 @@
+// Utility kernels + C-ABI glue: error reporting, mu-law, weight packing, generic causal conv,
+// input-conv weight gradient, loss reduction.  gfx950 only.
+#include "srwn_common.h"
+#include "srwn_host.h"
+#include "../../include/srwn.h"
+
+using namespace srwn;
+
+// ------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+namespace srwn {
+int set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error((int)e, "%s: %s", what, hipGetErrorString(e));
+  return 0;
+}
+}  // namespace srwn
+
+extern "C" int srwn_version(void) { return 100; }
+extern "C" const char* srwn_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------------------------
+// mu-law (ops.py:82-104)
+// ------------------------------------------------------------------------------------------
+__global__ void mu_law_encode_kernel(const float* __restrict__ audio, int32_t* __restrict__ codes, int64_t n,
+                                     float mu, float log1p_mu) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float a = audio[i];
+  float safe = fminf(fabsf(a), 1.0f);                              // ops.py:88
+  float lm = (float)log1p((double)__fmul_rn(mu, safe));             // correctly rounded f32 log1p
+  float magnitude = __fdiv_rn(lm, log1p_mu);                        // ops.py:89
+  float sgn = (a > 0.0f) ? 1.0f : ((a < 0.0f) ? -1.0f : 0.0f);      // tf.sign
+  float signal = __fmul_rn(sgn, magnitude);                         // ops.py:90
+  float q = __fadd_rn(__fmul_rn(__fdiv_rn(__fadd_rn(signal, 1.0f), 2.0f), mu), 0.5f);  // ops.py:92
+  codes[i] = (int32_t)q;                                            // tf.to_int32 truncates
+}
+
+__global__ void mu_law_decode_kernel(const int32_t* __restrict__ codes, float* __restrict__ audio, int64_t n,
+                                     float mu, float inv_mu, double base) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float o = (float)codes[i];
+  float signal = __fadd_rn(__fmul_rn(2.0f, __fdiv_rn(o, mu)), -1.0f);  // ops.py:101
+  float p = (float)pow(base, (double)fabsf(signal));                    // (1+mu)**|signal|
+  float magnitude = __fmul_rn(inv_mu, __fadd_rn(p, -1.0f));             // ops.py:103
+  float sgn = (signal > 0.0f) ? 1.0f : ((signal < 0.0f) ? -1.0f : 0.0f);
+  audio[i] = __fmul_rn(sgn, magnitude);
+}
+
+extern "C" int srwn_mu_law_encode(const float* audio, int32_t* codes, int64_t n, int32_t Q, void* stream) {
+  if (n == 0) return 0;
+  if (!audio || !codes) return set_error(SRWN_E_NULL, "mu_law_encode: null pointer");
+  if (n < 0 || Q < 2) return set_error(SRWN_E_SHAPE, "mu_law_encode: n=%lld Q=%d", (long long)n, Q);
+  float mu = (float)(Q - 1);
+  float l1p = (float)log1p((double)mu);
+  hipLaunchKernelGGL(mu_law_encode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     audio, codes, n, mu, l1p);
+  return check_launch("mu_law_encode");
+}
+
+extern "C" int srwn_mu_law_decode(const int32_t* codes, float* audio, int64_t n, int32_t Q, void* stream) {
+  if (n == 0) return 0;
+  if (!audio || !codes) return set_error(SRWN_E_NULL, "mu_law_decode: null pointer");
+  if (n < 0 || Q < 2) return set_error(SRWN_E_SHAPE, "mu_law_decode: n=%lld Q=%d", (long long)n, Q);
+  int mu = Q - 1;
+  hipLaunchKernelGGL(mu_law_decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     codes, audio, n, (float)mu, (float)(1.0 / (double)mu), (double)(1 + mu));
+  return check_launch("mu_law_decode");
+}
+
+// ------------------------------------------------------------------------------------------
+// weight packing
+// ------------------------------------------------------------------------------------------
+__global__ void pack_a_index_kernel(int32_t* __restrict__ dst, int32_t src_offset, int32_t rows_valid,
+                                    int32_t k_valid, int32_t row_stride, int32_t k_stride, int32_t mt_count,
+                                    int32_t ks_total, int32_t ks_offset, int32_t ks_count, int32_t perm_from_ks) {
+  // one thread per (mt, ks_local, lane, j)
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t total = (int64_t)mt_count * ks_count * 64 * 8;
+  if (i >= total) return;
+  int j = (int)(i & 7);
+  int lane = (int)((i >> 3) & 63);
+  int ksl = (int)((i >> 9) % ks_count);
+  int mt = (int)((i >> 9) / ks_count);
+  int r = lane & 31, h = lane >> 5;
+  int kin = (ksl >= perm_from_ks) ? (8 * (j >> 2) + 4 * h + (j & 3)) : (8 * h + j);
+  int k = 16 * ksl + kin;
+  int row = 32 * mt + r;
+  int32_t v = (row < rows_valid && k < k_valid) ? (src_offset + row * row_stride + k * k_stride) : -1;
+  int64_t o = ((((int64_t)mt * ks_total + (ks_offset + ksl)) * 64) + lane) * 8 + j;
+  dst[o] = v;
+}
+
+extern "C" int srwn_pack_a_index(int32_t* dst_idx, int32_t src_offset, int32_t rows_valid, int32_t k_valid,
+                                 int32_t row_stride, int32_t k_stride, int32_t mt_count, int32_t ks_total,
+                                 int32_t ks_offset, int32_t ks_count, int32_t perm_from_ks, void* stream) {
+  if (!dst_idx) return set_error(SRWN_E_NULL, "pack_a_index: null dst");
+  if (mt_count <= 0 || ks_count <= 0 || ks_offset < 0 || ks_offset + ks_count > ks_total)
+    return set_error(SRWN_E_SHAPE, "pack_a_index: mt=%d ks=[%d,+%d) of %d", mt_count, ks_offset, ks_count, ks_total);
+  int64_t total = (int64_t)mt_count * ks_count * 512;
+  hipLaunchKernelGGL(pack_a_index_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     dst_idx, src_offset, rows_valid, k_valid, row_stride, k_stride, mt_count, ks_total, ks_offset,
+                     ks_count, perm_from_ks);
+  return check_launch("pack_a_index");
+}
+
+template <typename T>
+__global__ void pack_gather_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx,
+                                   T* __restrict__ dst, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int32_t s = idx[i];
+  dst[i] = (T)(s >= 0 ? src[s] : 0.0f);
+}
+
+extern "C" int srwn_pack_gather(const float* src, const int32_t* idx, void* dst, int64_t n, int32_t dtype,
+                                void* stream) {
+  if (n == 0) return 0;
+  if (!src || !idx || !dst) return set_error(SRWN_E_NULL, "pack_gather: null pointer");
+  dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  if (dtype == SRWN_F32)
+    hipLaunchKernelGGL(pack_gather_kernel<float>, grid, block, 0, (hipStream_t)stream, src, idx, (float*)dst, n);
+  else if (dtype == SRWN_BF16)
+    hipLaunchKernelGGL(pack_gather_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, src, idx, (bf16_t*)dst, n);
+  else
+    return set_error(SRWN_E_DTYPE, "pack_gather: dtype %d", dtype);
+  return check_launch("pack_gather");
+}
+
+// ------------------------------------------------------------------------------------------
+// generic causal conv (ops.py:6-20), plain VALU: thread = (b, t, 4 output channels)
+// ------------------------------------------------------------------------------------------
+template <typename TOut>
+__global__ void causal_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                   const float* __restrict__ bias, TOut* __restrict__ y, int B, int T, int Cin,
+                                   int Cout, int K, int dilation, int shift) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int cq = (Cout + 3) / 4;
+  int64_t total = (int64_t)B * T * cq;
+  if (i >= total) return;
+  int o0 = (int)(i % cq) * 4;
+  int64_t bt = i / cq;
+  int t = (int)(bt % T);
+  int b = (int)(bt / T);
+  float acc[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) acc[q] = (bias && o0 + q < Cout) ? bias[o0 + q] : 0.0f;
+  for (int k = 0; k < K; ++k) {
+    int tk = t - (K - 1 - k) * dilation - shift;
+    if (tk < 0) continue;
+    const float* xr = x + ((int64_t)b * T + tk) * Cin;
+    const float* wk = w + (int64_t)k * Cin * Cout;
+    for (int ci = 0; ci < Cin; ++ci) {
+      float xv = xr[ci];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (o0 + q < Cout) acc[q] = fmaf(xv, wk[(int64_t)ci * Cout + o0 + q], acc[q]);
+    }
+  }
+  TOut* yr = y + ((int64_t)b * T + t) * Cout + o0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if (o0 + q < Cout) yr[q] = (TOut)acc[q];
+}
+
+extern "C" int srwn_causal_conv1d_fwd(const float* x, const float* w, const float* bias, void* y, int32_t B,
+                                      int32_t T, int32_t Cin, int32_t Cout, int32_t K, int32_t dilation,
+                                      int32_t shift, int32_t dtype_out, void* stream) {
+  if (B == 0 || T == 0) return 0;
+  if (!x || !w || !y) return set_error(SRWN_E_NULL, "causal_conv1d_fwd: null pointer");
+  if (B < 0 || T < 0 || Cin < 1 || Cout < 1 || K < 1 || dilation < 1 || shift < 0)
+    return set_error(SRWN_E_SHAPE, "causal_conv1d_fwd: B=%d T=%d Cin=%d Cout=%d K=%d d=%d shift=%d", B, T, Cin, Cout,
+                     K, dilation, shift);
+  int64_t total = (int64_t)B * T * ((Cout + 3) / 4);
+  dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  if (dtype_out == SRWN_F32)
+    hipLaunchKernelGGL(causal_conv_kernel<float>, grid, block, 0, (hipStream_t)stream, x, w, bias, (float*)y, B, T,
+                       Cin, Cout, K, dilation, shift);
+  else if (dtype_out == SRWN_BF16)
+    hipLaunchKernelGGL(causal_conv_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, x, w, bias, (bf16_t*)y, B,
+                       T, Cin, Cout, K, dilation, shift);
+  else
+    return set_error(SRWN_E_DTYPE, "causal_conv1d_fwd: dtype %d", dtype_out);
+  return check_launch("causal_conv1d_fwd");
+}
+
+// ------------------------------------------------------------------------------------------
+// input conv (Cin = 1) weight/bias gradient: two-stage deterministic reduction.
+// stage 1: block p sums rows [p*ROWS, (p+1)*ROWS) of the flattened [B*T] axis -> partials[p][(K+1)*R]
+// stage 2: fixed-order sum over p.
+// ------------------------------------------------------------------------------------------
+constexpr int kIcRows = 512;
+
+template <typename T>
+__global__ __launch_bounds__(256) void init_conv_wgrad_stage1(const float* __restrict__ audio,
+                                                              const T* __restrict__ g, float* __restrict__ partials,
+                                                              int B, int Tlen, int R, int K, int shift) {
+  // thread = (channel o = tid % R, row group rg = tid / R); R in {32, 64, 128}
+  extern __shared__ float red[];  // [256 / R][(K+1)*R]
+  const int o = threadIdx.x % R, rg = threadIdx.x / R, ngrp = 256 / R;
+  const int64_t rows = (int64_t)B * Tlen;
+  const int64_t r0 = (int64_t)blockIdx.x * kIcRows;
+  float acc[9];  // K <= 8
+#pragma unroll
+  for (int k = 0; k < 9; ++k) acc[k] = 0.0f;
+  for (int rr = rg; rr < kIcRows; rr += ngrp) {
+    int64_t row = r0 + rr;
+    if (row >= rows) break;
+    int t = (int)(row % Tlen);
+    float gv = (float)g[row * R + o];
+    acc[K] += gv;
+    for (int k = 0; k < K; ++k) {
+      int tk = t - (K - 1 - k) - shift;
+      if (tk >= 0) acc[k] = fmaf(audio[row - t + tk], gv, acc[k]);
+    }
+  }
+  for (int k = 0; k <= K; ++k) red[(rg * (K + 1) + k) * R + o] = acc[k];
+  __syncthreads();
+  for (int i = threadIdx.x; i < (K + 1) * R; i += 256) {
+    float s = 0.0f;
+    for (int q = 0; q < ngrp; ++q) s += red[q * (K + 1) * R + i];
+    partials[(int64_t)blockIdx.x * (K + 1) * R + i] = s;
+  }
+}
+
+__global__ void init_conv_wgrad_stage2(const float* __restrict__ partials, int64_t nparts, float* __restrict__ gw,
+                                       float* __restrict__ gb, int R, int K) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (K + 1) * R) return;
+  double s = 0.0;
+  for (int64_t p = 0; p < nparts; ++p) s += (double)partials[p * (K + 1) * R + i];
+  if (i < K * R) gw[i] = (float)s; else gb[i - K * R] = (float)s;
+}
+
+extern "C" int64_t srwn_init_conv_wgrad_partials(int32_t B, int32_t T, int32_t R, int32_t K) {
+  int64_t rows = (int64_t)B * T;
+  return ((rows + kIcRows - 1) / kIcRows) * (int64_t)(K + 1) * R;
+}
+
+extern "C" int srwn_init_conv_wgrad(const float* audio, const void* g, float* partials, float* gw, float* gb,
+                                    int32_t B, int32_t T, int32_t R, int32_t K, int32_t shift, int32_t dtype,
+                                    void* stream) {
+  if (!audio || !g || !partials || !gw || !gb) return set_error(SRWN_E_NULL, "init_conv_wgrad: null pointer");
+  if (B < 1 || T < 1 || K < 1 || K > 8 || (R != 32 && R != 64 && R != 128))
+    return set_error(SRWN_E_SHAPE, "init_conv_wgrad: B=%d T=%d R=%d K=%d", B, T, R, K);
+  int64_t rows = (int64_t)B * T;
+  int64_t nparts = (rows + kIcRows - 1) / kIcRows;
+  size_t sh = (size_t)(256 / R) * (K + 1) * R * sizeof(float);
+  if (dtype == SRWN_F32)
+    hipLaunchKernelGGL(init_conv_wgrad_stage1<float>, dim3((unsigned)nparts), dim3(256), sh, (hipStream_t)stream,
+                       audio, (const float*)g, partials, B, T, R, K, shift);
+  else if (dtype == SRWN_BF16)
+    hipLaunchKernelGGL(init_conv_wgrad_stage1<bf16_t>, dim3((unsigned)nparts), dim3(256), sh, (hipStream_t)stream,
+                       audio, (const bf16_t*)g, partials, B, T, R, K, shift);
+  else
+    return set_error(SRWN_E_DTYPE, "init_conv_wgrad: dtype %d", dtype);
+  int rc = check_launch("init_conv_wgrad_stage1");
+  if (rc) return rc;
+  int n = (K + 1) * R;
+  hipLaunchKernelGGL(init_conv_wgrad_stage2, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, partials,
+                     nparts, gw, gb, R, K);
+  return check_launch("init_conv_wgrad_stage2");
+}
+
+// ------------------------------------------------------------------------------------------
+// loss partial reduction (fixed order, f64 accumulate)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void reduce_loss_kernel(const float* __restrict__ p, int64_t n, float scale,
+                                                          float* __restrict__ out) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) s += (double)p[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = (float)(red[0] * (double)scale);
+}
+
+extern "C" int srwn_reduce_loss(const float* loss_partials, int64_t n, float scale, float* loss_out, void* stream) {
+  if (!loss_partials || !loss_out) return set_error(SRWN_E_NULL, "reduce_loss: null pointer");
+  hipLaunchKernelGGL(reduce_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_partials, n, scale,
+                     loss_out);
+  return check_launch("reduce_loss");
+}

@@ -1,0 +1,207 @@
+"""Torch-tensor front end of the C-ABI: argument validation + pointer/stream plumbing.
+
+PyTorch here only owns device memory and streams; every computation is a HIP kernel of
+libsrwn.so launched on torch's current stream.  All shape checks that the kernels assume are
+done here on the host *before* a launch, so a wrong shape raises instead of faulting the GPU.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import BF16, EPI_MASK, EPI_NONE, EPI_RELU, F32, PRO_GATE, PRO_NONE, call
+
+_TORCH2ABI = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def abi_dtype(dt: torch.dtype) -> int:
+    try:
+        return _TORCH2ABI[dt]
+    except KeyError:
+        raise TypeError("unsupported activation dtype %s (float32 or bfloat16)" % dt)
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: torch.Tensor, name: str, dtype=None, shape=None):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise ValueError("%s must be a CUDA/HIP tensor" % name)
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError("%s: dtype %s, expected %s" % (name, t.dtype, dtype))
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError("%s: shape %s, expected %s" % (name, tuple(t.shape), tuple(shape)))
+    return t.data_ptr()
+
+
+def _opt(t: Optional[torch.Tensor], name: str, dtype=None, shape=None):
+    return None if t is None else _chk(t, name, dtype, shape)
+
+
+# ----------------------------------------------------------------------------------------------
+# mu-law (ops.py:82-104)
+# ----------------------------------------------------------------------------------------------
+def mu_law_encode(audio: torch.Tensor, quantization_channels: int) -> torch.Tensor:
+    pa = _chk(audio, "audio", torch.float32)
+    codes = torch.empty(audio.shape, dtype=torch.int32, device=audio.device)
+    call("srwn_mu_law_encode", pa, codes.data_ptr(), audio.numel(), int(quantization_channels), _stream())
+    return codes
+
+
+def mu_law_decode(codes: torch.Tensor, quantization_channels: int) -> torch.Tensor:
+    pc = _chk(codes, "codes", torch.int32)
+    out = torch.empty(codes.shape, dtype=torch.float32, device=codes.device)
+    call("srwn_mu_law_decode", pc, out.data_ptr(), codes.numel(), int(quantization_channels), _stream())
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# weight packing
+# ----------------------------------------------------------------------------------------------
+class Packer:
+    """Collects the MFMA A-operand images of a model; one int32 index image, one gather per step."""
+
+    def __init__(self, device):
+        self.device = device
+        self.total = 0
+        self._jobs: List[Tuple] = []
+        self.idx: Optional[torch.Tensor] = None
+
+    def reserve(self, mt_count: int, ks_total: int) -> int:
+        """Reserves an image of mt_count x ks_total fragments; returns its element offset."""
+        off = self.total
+        self.total += mt_count * ks_total * 512
+        return off
+
+    def fill(self, image_off: int, *, src_offset: int, rows_valid: int, k_valid: int, row_stride: int,
+             k_stride: int, mt_count: int, ks_total: int, ks_offset: int = 0, ks_count: Optional[int] = None,
+             perm_from_ks: int = 1 << 30):
+        ks_count = ks_total - ks_offset if ks_count is None else ks_count
+        self._jobs.append((image_off, src_offset, rows_valid, k_valid, row_stride, k_stride, mt_count, ks_total,
+                           ks_offset, ks_count, min(perm_from_ks, 1 << 30)))
+
+    def finalize(self):
+        self.idx = torch.full((max(self.total, 1),), -1, dtype=torch.int32, device=self.device)
+        base = self.idx.data_ptr()
+        for (off, so, rv, kv, rs, ks_, mt, kst, kso, ksc, pf) in self._jobs:
+            call("srwn_pack_a_index", base + 4 * off, so, rv, kv, rs, ks_, mt, kst, kso, ksc, pf, _stream())
+        return self
+
+    def gather(self, params_flat: torch.Tensor, out: torch.Tensor):
+        """out[i] = (out.dtype) params_flat[idx[i]] (0 where idx<0)."""
+        _chk(params_flat, "params", torch.float32)
+        _chk(out, "packed", None, (max(self.total, 1),))
+        call("srwn_pack_gather", params_flat.data_ptr(), self.idx.data_ptr(), out.data_ptr(), self.total,
+             abi_dtype(out.dtype), _stream())
+        return out
+
+
+# ----------------------------------------------------------------------------------------------
+# generic causal conv (ops.py:6-20) and the input conv's weight gradient
+# ----------------------------------------------------------------------------------------------
+def causal_conv1d_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], dilation: int = 1,
+                      shift: int = 0, out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    B, T, Cin = x.shape
+    K, Cin2, Cout = w.shape
+    if Cin != Cin2:
+        raise ValueError("conv: x has %d channels, filters expect %d" % (Cin, Cin2))
+    px = _chk(x, "x", torch.float32)
+    pw = _chk(w, "w", torch.float32)
+    pb = _opt(bias, "bias", torch.float32, (Cout,))
+    y = torch.empty((B, T, Cout), dtype=out_dtype, device=x.device)
+    call("srwn_causal_conv1d_fwd", px, pw, pb, y.data_ptr(), B, T, Cin, Cout, K, int(dilation), int(shift),
+         abi_dtype(out_dtype), _stream())
+    return y
+
+
+def init_conv_wgrad(audio: torch.Tensor, g: torch.Tensor, gw: torch.Tensor, gb: torch.Tensor, K: int, shift: int,
+                    workspace: torch.Tensor):
+    B, T = audio.shape
+    R = g.shape[-1]
+    pa = _chk(audio, "audio", torch.float32)
+    pg = _chk(g, "g", None, (B, T, R))
+    need = _lib.load().srwn_init_conv_wgrad_partials(B, T, R, K)
+    if workspace.numel() < need or workspace.dtype != torch.float32:
+        raise ValueError("init_conv_wgrad: workspace needs %d floats" % need)
+    _chk(gw, "gw", torch.float32)
+    _chk(gb, "gb", torch.float32)
+    if gw.numel() != K * R or gb.numel() != R:
+        raise ValueError("init_conv_wgrad: gw/gb size")
+    call("srwn_init_conv_wgrad", pa, pg, workspace.data_ptr(), gw.data_ptr(), gb.data_ptr(), B, T, R, K, int(shift),
+         abi_dtype(g.dtype), _stream())
+
+
+# ----------------------------------------------------------------------------------------------
+# fused residual layer forward (ops.py:23-46)
+# ----------------------------------------------------------------------------------------------
+def residual_layer_fwd(x: torch.Tensor, cond: Optional[torch.Tensor], wconv_ptr: int, wres_ptr: int,
+                       bias_f: torch.Tensor, bias_r: torch.Tensor, h_out: torch.Tensor, z_out: torch.Tensor, K: int,
+                       dilation: int, pool_stride: int = 1):
+    B, T, R = x.shape
+    px = _chk(x, "x")
+    dt = abi_dtype(x.dtype)
+    frames = 1
+    pc = None
+    if cond is not None:
+        frames = cond.shape[1]
+        pc = _chk(cond, "cond", x.dtype, (B, frames, R))
+        if frames * pool_stride < T:
+            raise ValueError("cond: %d frames x pool %d < T=%d" % (frames, pool_stride, T))
+    pbf = _chk(bias_f, "bias_f", torch.float32, (R,))
+    pbr = _chk(bias_r, "bias_r", torch.float32, (R,))
+    ph = _chk(h_out, "h_out", x.dtype, (B, T, R))
+    pz = _chk(z_out, "z_out", x.dtype, (B, T, R))
+    call("srwn_residual_layer_fwd", px, pc, wconv_ptr, wres_ptr, pbf, pbr, ph, pz, B, T, R, K, int(dilation),
+         frames, int(pool_stride), dt, _stream())
+
+
+# ----------------------------------------------------------------------------------------------
+# pointwise linear and the fused softmax head
+# ----------------------------------------------------------------------------------------------
+def pw_linear(x_ptr: int, x_row_stride: int, x_chunk_stride: int, chunk_len: int, Cin: int, wpack_ptr: int,
+              bias: Optional[torch.Tensor], y: torch.Tensor, cout_pad: int, cout_valid: int, rows: int,
+              aux: Optional[torch.Tensor] = None, pro: int = PRO_NONE, epi: int = EPI_NONE):
+    """Raw-pointer input (the skip sum reads a [L,rows,R] stack through chunk strides); y is [rows, >=cout_valid]."""
+    py = _chk(y, "y")
+    if y.shape[0] != rows or y.shape[-1] < cout_valid:
+        raise ValueError("pw_linear: y shape %s vs rows=%d cout_valid=%d" % (tuple(y.shape), rows, cout_valid))
+    pa, astride = None, 0
+    if aux is not None:
+        pa = _chk(aux, "aux", y.dtype)
+        if aux.shape[0] != rows or aux.shape[-1] < cout_valid:
+            raise ValueError("pw_linear: aux shape %s" % (tuple(aux.shape),))
+        astride = aux.shape[-1]
+    pb = _opt(bias, "bias", torch.float32)
+    if bias is not None and bias.numel() < cout_valid:
+        raise ValueError("pw_linear: bias too short")
+    call("srwn_pw_linear", x_ptr, int(x_row_stride), int(x_chunk_stride), int(chunk_len), int(Cin), wpack_ptr, pb, py,
+         y.shape[-1], int(cout_pad), int(cout_valid), int(rows), pa, astride, pro, epi, abi_dtype(y.dtype), _stream())
+
+
+def head_softmax_ce(x: torch.Tensor, wpack_ptr: int, bias: torch.Tensor, targets: torch.Tensor,
+                    loss_partials: torch.Tensor, dlogits: Optional[torch.Tensor], logits_out: Optional[torch.Tensor],
+                    cout_pad: int, cout_valid: int, grad_scale: float):
+    rows, Cin = x.shape
+    px = _chk(x, "x")
+    pb = _chk(bias, "bias", torch.float32)
+    if bias.numel() < cout_valid:
+        raise ValueError("head: bias too short")
+    pt = _chk(targets, "targets", torch.int32, (rows,))
+    need = (rows + 31) // 32
+    pl = _chk(loss_partials, "loss_partials", torch.float32)
+    if loss_partials.numel() < need:
+        raise ValueError("head: loss_partials needs %d floats" % need)
+    pd = _opt(dlogits, "dlogits", x.dtype, (rows, cout_pad))
+    plo = _opt(logits_out, "logits_out", torch.float32, (rows, cout_valid))
+    call("srwn_head_softmax_ce", px, Cin, Cin, wpack_ptr, pb, pt, pl, pd, plo, int(cout_pad), int(cout_valid), rows,
+         float(grad_scale), abi_dtype(x.dtype), _stream())
+
+
+def reduce_loss(loss_partials: torch.Tensor, n: int, scale: float, out: torch.Tensor):
+    call("srwn_reduce_loss", _chk(loss_partials, "loss_partials", torch.float32), int(n), float(scale),
+         _chk(out, "loss", torch.float32), _stream())
