@@ -116,6 +116,46 @@ int srwn_head_softmax_ce(const void* x, int64_t x_row_stride, int32_t Cin, const
                          void* stream);
 int srwn_reduce_loss(const float* loss_partials, int64_t n, float scale, float* loss_out, void* stream);
 
+/* ---- fused residual layer backward: autodiff of ResidualDilationLayer (ops.py:23-46); TF builds
+ * these gradients in tf.train.AdamOptimizer.minimize (model.py:31).  One call per layer, top down:
+ *   has_up  : G_{l+1}[t] = g_in[t]*sqrt(.5) + sum_k Wf_{l+1}[k] . df_up[t + (K-1-k)*dilation_up]  -> g_out
+ *             (g_in = G_{l+2}, may be NULL = 0; wconvT_up packed [R/32][K*R/16], rows = in channel)
+ *   has_down: dc = Wr_l . (G_{l+1} sqrt(.5)) + Ws_l . dtotal;  df_l = dc * d(z sigmoid z)/df      -> df_out
+ *             (wresT packed permuted [R/32][R/16]; wskipT packed natural [R/32][S/16]; z = z_l)
+ * Layer L-1: has_up=0 (its dense output is unused, model.py:45-50).  Below layer 0: has_down=0. */
+int srwn_residual_layer_bwd(const void* g_in, const void* df_up, const void* wconvT_up, void* g_out,
+                            const void* wresT, const void* wskipT, const void* dtotal, const void* z, void* df_out,
+                            int32_t B, int32_t T, int32_t R, int32_t S, int32_t K, int32_t dilation_up,
+                            int32_t has_up, int32_t has_down, int32_t dtype, void* stream);
+
+/* ---- weight gradients (the tf.gradients of every kernel on the path), batched over `nbatch` layers:
+ *   partials[l][slab][i][o] = sum_{rows of slab} pro(in_l[row - shifts[l], i] + cond_l[b, (t-shift)/pool, i])
+ *                                                 * dout_l[row, o]          (0 where t - shift < 0)
+ *   bias_partials[l][slab][o] = sum_{rows of slab} dout_l[row, o]           (may be NULL)
+ * in_l = in + l*in_batch_stride (elements), dout_l likewise (stride 0 = shared by all layers);
+ * rows = B*T flattened, `T` delimits batch elements for the shift.  pro = SRWN_PRO_GATE rebuilds
+ * c = z*sigmoid(z).  nslabs = srwn_wgrad_slabs(rows); partials need nbatch*nslabs*cin*cout floats.
+ * srwn_reduce_partials then writes out[l*out_batch_stride + i] = scale * sum_slab partials[...]
+ * (fixed order, f64 accumulate); partials_batched=0 re-reads batch entry 0 for every l. */
+int32_t srwn_wgrad_slabs(int64_t rows);
+int srwn_wgrad(const void* in, int64_t in_batch_stride, int32_t cin, const void* dout, int64_t dout_batch_stride,
+               int32_t cout, const void* cond, int64_t cond_batch_stride, int32_t cond_frames, int32_t pool_stride,
+               const int32_t* shifts /* host array [nbatch] or NULL */, int32_t nbatch, float* partials,
+               float* bias_partials, int64_t rows, int32_t T, int32_t nslabs, int32_t pro, int32_t dtype,
+               void* stream);
+int srwn_reduce_partials(const float* partials, int32_t nslabs, int64_t n, int32_t nbatch, int32_t partials_batched,
+                         float scale, float* out, int64_t out_batch_stride, void* stream);
+
+/* ---- adjoint of ResizeEmbeddingNearestNeighbor (ops.py:64-74): out[b,e,c] = sum_{t in frame e} g[b,t,c] */
+int srwn_frame_sum(const void* g, void* out, int32_t B, int32_t T, int32_t C, int32_t frames, int32_t pool_stride,
+                   int32_t dtype, void* stream);
+
+/* ---- tf.train.AdamOptimizer update (model.py:31,117,382) on the flat fp32 parameter buffer:
+ *   t = ++*step (device counter);  lr_t = lr*sqrt(1-b2^t)/(1-b1^t);  g = grads*grad_scale;
+ *   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  params -= lr_t * m / (sqrt(v) + eps) */
+int srwn_adam_step(float* params, const float* grads, float* m, float* v, int64_t n, int64_t* step, float lr,
+                   float beta1, float beta2, float eps, float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

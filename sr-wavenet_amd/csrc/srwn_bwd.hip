@@ -1,0 +1,504 @@
+// Backward kernels: fused residual-layer data gradient, time-contraction weight gradients,
+// deterministic partial reduction.  gfx950 (MI355X) only.
+#include "srwn_common.h"
+#include "srwn_host.h"
+#include "../../include/srwn.h"
+
+using namespace srwn;
+
+// ------------------------------------------------------------------------------------------
+// fused residual layer backward (autodiff of ops.py:23-46), one launch per layer l, top to bottom.
+//   UP   : G_{l+1}[t] = G_{l+2}[t]*sqrt(.5) + sum_k Wf_{l+1}[k] . df_{l+1}[t + (K-1-k) d_{l+1}]   -> g_out
+//          (data gradient of the layer above; anti-causal taps, zero beyond T)
+//   DOWN : dc = Wr_l . (G_{l+1} sqrt(.5)) + Ws_l . dtotal ;  df_l = dc * d(z sigmoid(z))/df        -> df_out
+//   The UP accumulator tile is the B operand of the Wr product (no LDS / HBM round trip).
+//   Flags: layer L-1 runs DOWN only (G_L = 0: the last dense output is unused, model.py:45-50);
+//          the call below layer 0 runs UP only (gradient wrt the input conv output).
+// ------------------------------------------------------------------------------------------
+struct LayerBwdArgs {
+  const void* g_in;      // G_{l+2} [B,T,R] or nullptr (zero)
+  const void* df_up;     // df_{l+1} [B,T,R]
+  const void* wconvT;    // packed [R/32][K*R/16] natural: rows = in channel i, k = tap*R + o
+  void* g_out;           // G_{l+1}
+  const void* wresT;     // packed [R/32][R/16] permuted: rows = n, k = m  (Wr[n][m])
+  const void* wskipT;    // packed [R/32][S/16] natural: rows = n, k = s   (Ws[n][s])
+  const void* dtotal;    // [B*T, S]
+  const void* z;         // z_l [B,T,R]
+  void* df_out;          // df_l
+  int Tlen, dil_up, S;
+};
+
+template <typename T, int RT, int K, int NT, bool UP, bool DOWN>
+__global__ __launch_bounds__(256) void layer_bwd_kernel(LayerBwdArgs a) {
+  constexpr int R = 32 * RT, KS = R / 16;
+  const int KSS = a.S / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  Frag<T>* lds_conv = reinterpret_cast<Frag<T>*>(smem);            // [RT*K*KS][64]   (UP)
+  Frag<T>* lds_res = lds_conv + (UP ? RT * K * KS * 64 : 0);       // [RT*KS][64]     (UP && DOWN)
+  Frag<T>* lds_skip = lds_res + ((UP && DOWN) ? RT * KS * 64 : 0); // [RT*KSS][64]    (DOWN)
+  if (UP) {
+    const Frag<T>* g = reinterpret_cast<const Frag<T>*>(a.wconvT);
+    for (int i = threadIdx.x; i < RT * K * KS * 64; i += 256) lds_conv[i] = g[i];
+  }
+  if (UP && DOWN) {
+    const Frag<T>* g = reinterpret_cast<const Frag<T>*>(a.wresT);
+    for (int i = threadIdx.x; i < RT * KS * 64; i += 256) lds_res[i] = g[i];
+  }
+  if (DOWN) {
+    const Frag<T>* g = reinterpret_cast<const Frag<T>*>(a.wskipT);
+    for (int i = threadIdx.x; i < RT * KSS * 64; i += 256) lds_skip[i] = g[i];
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 31, half = lane >> 5;
+  const int b = blockIdx.y;
+  const int t_wave = (blockIdx.x * 4 + wave) * (32 * NT);
+  if (t_wave >= a.Tlen) return;
+  const size_t boff = (size_t)b * a.Tlen;
+
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int tc = t_wave + 32 * nt + col;
+    const bool ok = tc < a.Tlen;
+    const size_t rowi = boff + (ok ? tc : 0);
+    f32x16 accG[RT];
+    if (UP) {
+      // residual path: G_{l+2} * sqrt(.5) in accumulator layout
+      const T* gin = a.g_in ? reinterpret_cast<const T*>(a.g_in) + rowi * R : nullptr;
+#pragma unroll
+      for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 v = (gin && ok) ? load4(gin + 32 * mt + 8 * g + 4 * half) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) accG[mt][4 * g + e] = v[e] * kSqrtHalf;
+        }
+      // conv data gradient: taps read df_up at t + (K-1-k)*d
+      const T* dfu = reinterpret_cast<const T*>(a.df_up);
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const int tk = tc + (K - 1 - k) * a.dil_up;
+        const bool valid = ok && (tk < a.Tlen);
+        const T* row = dfu + (boff + (valid ? tk : 0)) * R;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const Frag<T> bf = valid ? load_nat(row + 16 * ks + 8 * half) : zero_frag<T>();
+#pragma unroll
+          for (int mt = 0; mt < RT; ++mt) {
+            const Frag<T> af = lds_conv[(mt * (K * KS) + k * KS + ks) * 64 + lane];
+            mma(accG[mt], af, bf);
+          }
+        }
+      }
+      if (ok) {
+        T* go = reinterpret_cast<T*>(a.g_out) + rowi * R;
+#pragma unroll
+        for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            store4(go + 32 * mt + 8 * g + 4 * half, accG[mt][4 * g], accG[mt][4 * g + 1], accG[mt][4 * g + 2],
+                   accG[mt][4 * g + 3]);
+      }
+    }
+    if (DOWN) {
+      f32x16 accC[RT];
+#pragma unroll
+      for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) accC[mt][q] = 0.0f;
+      if (UP) {
+        // dres = G_{l+1} * sqrt(.5): the accumulator tile is the B operand (permuted k order)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          Frag<T> bf;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bf.set(j, accG[s >> 1][8 * (s & 1) + j] * kSqrtHalf);
+#pragma unroll
+          for (int mt = 0; mt < RT; ++mt) {
+            const Frag<T> af = lds_res[(mt * KS + s) * 64 + lane];
+            mma(accC[mt], af, bf);
+          }
+        }
+      }
+      const T* dt = reinterpret_cast<const T*>(a.dtotal) + rowi * a.S + 8 * half;
+      for (int ks = 0; ks < KSS; ++ks) {
+        const Frag<T> bf = ok ? load_nat(dt + 16 * ks) : zero_frag<T>();
+#pragma unroll
+        for (int mt = 0; mt < RT; ++mt) {
+          const Frag<T> af = lds_skip[(mt * KSS + ks) * 64 + lane];
+          mma(accC[mt], af, bf);
+        }
+      }
+      if (ok) {
+        const T* zr = reinterpret_cast<const T*>(a.z) + rowi * R;
+        T* dfo = reinterpret_cast<T*>(a.df_out) + rowi * R;
+#pragma unroll
+        for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 zv = load4(zr + 32 * mt + 8 * g + 4 * half);
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = accC[mt][4 * g + e] * dgate_df<T>(zv[e]);
+            store4(dfo + 32 * mt + 8 * g + 4 * half, v[0], v[1], v[2], v[3]);
+          }
+      }
+    }
+  }
+}
+
+template <typename T, int RT, int NT>
+static int launch_layer_bwd(const LayerBwdArgs& a, int B, bool up, bool down, hipStream_t st) {
+  constexpr int K = 2, R = 32 * RT, KS = R / 16;
+  size_t frags = 0;
+  if (up) frags += RT * K * KS;
+  if (up && down) frags += RT * KS;
+  if (down) frags += (size_t)RT * (a.S / 16);
+  const size_t sh = frags * 64 * sizeof(Frag<T>);
+  dim3 grid((unsigned)((a.Tlen + 4 * 32 * NT - 1) / (4 * 32 * NT)), (unsigned)B), block(256);
+#define SRWN_LB(U, D)                                                                                          \
+  {                                                                                                            \
+    auto kfn = layer_bwd_kernel<T, RT, K, NT, U, D>;                                                           \
+    if (sh > 65536) {                                                                                          \
+      hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+      if (e != hipSuccess) return set_error((int)e, "layer_bwd: LDS %zu: %s", sh, hipGetErrorString(e));       \
+    }                                                                                                          \
+    hipLaunchKernelGGL(kfn, grid, block, sh, st, a);                                                           \
+  }
+  if (up && down) SRWN_LB(true, true)
+  else if (up) SRWN_LB(true, false)
+  else SRWN_LB(false, true)
+#undef SRWN_LB
+  return check_launch("residual_layer_bwd");
+}
+
+extern "C" int srwn_residual_layer_bwd(const void* g_in, const void* df_up, const void* wconvT_up, void* g_out,
+                                       const void* wresT, const void* wskipT, const void* dtotal, const void* z,
+                                       void* df_out, int32_t B, int32_t T, int32_t R, int32_t S, int32_t K,
+                                       int32_t dilation_up, int32_t has_up, int32_t has_down, int32_t dtype,
+                                       void* stream) {
+  if (B == 0 || T == 0) return 0;
+  if (!has_up && !has_down) return set_error(SRWN_E_SHAPE, "residual_layer_bwd: neither UP nor DOWN");
+  if (has_up && (!df_up || !wconvT_up || !g_out)) return set_error(SRWN_E_NULL, "residual_layer_bwd: UP needs df_up, wconvT_up, g_out");
+  if (has_down && (!wskipT || !dtotal || !z || !df_out)) return set_error(SRWN_E_NULL, "residual_layer_bwd: DOWN needs wskipT, dtotal, z, df_out");
+  if (has_up && has_down && !wresT) return set_error(SRWN_E_NULL, "residual_layer_bwd: UP+DOWN needs wresT");
+  if (K != 2) return set_error(SRWN_E_UNSUPPORTED, "residual_layer_bwd: filter_width %d (only 2 is built)", K);
+  if (B < 0 || T < 0 || S < 16 || S % 16 || (has_up && dilation_up < 1))
+    return set_error(SRWN_E_SHAPE, "residual_layer_bwd: B=%d T=%d S=%d d=%d", B, T, S, dilation_up);
+  LayerBwdArgs a{g_in, df_up, wconvT_up, g_out, wresT, wskipT, dtotal, z, df_out, T, dilation_up, S};
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SRWN_BF16) {
+    if (R == 32) return launch_layer_bwd<bf16_t, 1, 2>(a, B, has_up, has_down, st);
+    if (R == 64) return launch_layer_bwd<bf16_t, 2, 2>(a, B, has_up, has_down, st);
+  } else if (dtype == SRWN_F32) {
+    if (R == 32) return launch_layer_bwd<float, 1, 1>(a, B, has_up, has_down, st);
+    if (R == 64) return launch_layer_bwd<float, 2, 1>(a, B, has_up, has_down, st);
+  } else {
+    return set_error(SRWN_E_DTYPE, "residual_layer_bwd: dtype %d", dtype);
+  }
+  return set_error(SRWN_E_UNSUPPORTED, "residual_layer_bwd: dilation_channels %d (built: 32, 64)", R);
+}
+
+// ------------------------------------------------------------------------------------------
+// weight gradient: time-contraction GEMM, batched over layers
+//   out[l][i][o] = scale * sum_{row} pro(In_l[row - shift_l][i] (+ cond)) * Dout_l[row][o]
+//   (rows = flattened [B*T]; a shifted row must stay inside its batch element, else it contributes 0)
+//   Stage 1: block (slab, nblk, l*MB+mblk) accumulates a slab of rows -> partials[l][slab][Cin][Cout] (fp32)
+//            and, if requested, the column sums of Dout (bias gradient) -> bias_partials[l][slab][Cout].
+//   Stage 2: srwn_reduce_partials sums slabs in a fixed order (deterministic, f64 accumulate).
+//   Both operands are contracted over the slow (time) axis of channels-last memory, so the tiles
+//   are staged in LDS as they lie in memory and read back with the transposing LDS read
+//   (ds_read_b64_tr_b16) in bf16 mode, or element-wise in fp32 mode.
+// ------------------------------------------------------------------------------------------
+constexpr int kWgKC = 32;       // rows staged per step (2 k-steps of 16)
+constexpr int kWgMaxBatch = 64;
+
+struct WgradArgs {
+  const void* in;  int64_t in_batch_stride;  int cin;   // In: [rows, cin] per batch entry (elements)
+  const void* dout; int64_t dout_batch_stride; int cout; // Dout: [rows, cout]
+  const void* cond; int64_t cond_batch_stride; int cond_frames; int pool;  // optional add on In
+  float* partials; float* bias_partials;
+  int64_t rows; int Tlen; int rows_per_slab; int nslabs;
+  int shifts[kWgMaxBatch];
+};
+
+template <typename T> struct LdsFrag;
+template <> struct LdsFrag<bf16_t> {
+  // natural-layout tile [row][stride] -> fragment: 8 consecutive rows (16*ks + 8h + j) at column col0 + (lane&31)
+  static __device__ __forceinline__ Frag<bf16_t> load(const bf16_t* tile, int stride, int row0, int col0, int lane) {
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int h = g >> 1;
+    const bf16_t* base = tile + (size_t)(row0 + 8 * h + q) * stride + col0 + 16 * (g & 1) + 4 * p;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 4 * stride));
+    Frag<bf16_t> f;
+    f.v = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    return f;
+  }
+};
+template <> struct LdsFrag<float> {
+  static __device__ __forceinline__ Frag<float> load(const float* tile, int stride, int row0, int col0, int lane) {
+    const int c = col0 + (lane & 31), h = lane >> 5;
+    const float* base = tile + (size_t)(row0 + 8 * h) * stride + c;
+    Frag<float> f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f.set(j, base[(size_t)j * stride]);
+    return f;
+  }
+};
+
+// block tile = (WM*MTW*32) x (WN*NTW*32), WM*WN = 4 waves
+template <typename T, int MTW, int NTW, int WM, int PRO, bool COND>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+  constexpr int WN = 4 / WM;
+  constexpr int BM = WM * MTW * 32, BN = WN * NTW * 32;
+  constexpr int VEC = 16 / sizeof(T);  // elements per 16-byte staging load
+  constexpr int SIN = BM + VEC, SOUT = BN + VEC;  // padded LDS row strides (16-byte multiples)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* lin = reinterpret_cast<T*>(smem);        // [kWgKC][SIN]
+  T* lout = lin + kWgKC * SIN;                // [kWgKC][SOUT]
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int slab = blockIdx.x;
+  const int nblk = blockIdx.y;
+  const int mblocks = (a.cin + BM - 1) / BM;
+  const int layer = blockIdx.z / mblocks, mblk = blockIdx.z % mblocks;
+  const int shift = a.shifts[layer];
+  const T* in = reinterpret_cast<const T*>(a.in) + (int64_t)layer * a.in_batch_stride;
+  const T* dout = reinterpret_cast<const T*>(a.dout) + (int64_t)layer * a.dout_batch_stride;
+  const T* cond = COND ? reinterpret_cast<const T*>(a.cond) + (int64_t)layer * a.cond_batch_stride : nullptr;
+  const int ci0 = mblk * BM, co0 = nblk * BN;
+
+  f32x16 acc[MTW][NTW];
+#pragma unroll
+  for (int m = 0; m < MTW; ++m)
+#pragma unroll
+    for (int n = 0; n < NTW; ++n)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[m][n][q] = 0.0f;
+  float bsum = 0.0f;  // thread j < BN sums column co0 + j of Dout (bias gradient)
+
+  const int64_t r_begin = (int64_t)slab * a.rows_per_slab;
+  const int64_t r_end = (r_begin + a.rows_per_slab < a.rows) ? r_begin + a.rows_per_slab : a.rows;
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += kWgKC) {
+    __syncthreads();  // previous step's fragment reads are done
+    // ---- stage In tile (shifted rows, optional gate / cond add)
+    for (int idx = threadIdx.x; idx < kWgKC * (BM / VEC); idx += 256) {
+      const int rr = idx / (BM / VEC), cv = (idx % (BM / VEC)) * VEC;
+      const int64_t row = r0 + rr;
+      const int t = (int)(row % a.Tlen);
+      const bool valid = (row < r_end) && (t - shift >= 0) && (ci0 + cv < a.cin);
+      float v[VEC];
+      if (valid) {
+        const T* p = in + (row - shift) * a.cin + ci0 + cv;
+        if (sizeof(T) == 2) {
+          Frag<T> f = load_nat(p);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) v[e] = f.get(e);
+        } else {
+          f32x4 f = load4(p);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) v[e] = f[e];
+        }
+        if (COND) {
+          const int64_t bidx = row / a.Tlen;
+          const T* cp = cond + (bidx * a.cond_frames + (t - shift) / a.pool) * a.cin + ci0 + cv;
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) v[e] += (float)cp[e];
+        }
+        if (PRO == SRWN_PRO_GATE) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) v[e] = gate_of_z<T>(v[e]);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[e] = 0.0f;
+      }
+      T* d = lin + rr * SIN + cv;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) d[e] = (T)v[e];
+    }
+    // ---- stage Dout tile
+    for (int idx = threadIdx.x; idx < kWgKC * (BN / VEC); idx += 256) {
+      const int rr = idx / (BN / VEC), cv = (idx % (BN / VEC)) * VEC;
+      const int64_t row = r0 + rr;
+      const bool valid = (row < r_end) && (co0 + cv < a.cout);
+      T* d = lout + rr * SOUT + cv;
+      if (valid) {
+        const T* p = dout + row * a.cout + co0 + cv;
+        if (sizeof(T) == 2) {
+          *reinterpret_cast<bf16x8*>(d) = *reinterpret_cast<const bf16x8*>(p);
+        } else {
+          *reinterpret_cast<f32x4*>(d) = *reinterpret_cast<const f32x4*>(p);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) d[e] = (T)0.0f;
+      }
+    }
+    __syncthreads();
+    if (a.bias_partials && mblk == 0 && (int)threadIdx.x < BN) {
+#pragma unroll 8
+      for (int rr = 0; rr < kWgKC; ++rr) bsum += (float)lout[rr * SOUT + threadIdx.x];
+    }
+#pragma unroll
+    for (int ks = 0; ks < kWgKC / 16; ++ks) {
+      Frag<T> af[MTW], bf[NTW];
+#pragma unroll
+      for (int m = 0; m < MTW; ++m) af[m] = LdsFrag<T>::load(lin, SIN, 16 * ks, (wm * MTW + m) * 32, lane);
+#pragma unroll
+      for (int n = 0; n < NTW; ++n) bf[n] = LdsFrag<T>::load(lout, SOUT, 16 * ks, (wn * NTW + n) * 32, lane);
+#pragma unroll
+      for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) mma(acc[m][n], af[m], bf[n]);
+    }
+  }
+
+  // ---- write the slab's partial tile: partials[layer][slab][cin][cout]
+  float* pbase = a.partials + ((int64_t)layer * a.nslabs + slab) * (int64_t)a.cin * a.cout;
+  const int col = lane & 31, half = lane >> 5;
+#pragma unroll
+  for (int m = 0; m < MTW; ++m)
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) {
+      const int o = co0 + (wn * NTW + n) * 32 + col;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int i = ci0 + (wm * MTW + m) * 32 + crow(q, half);
+        if (i < a.cin && o < a.cout) pbase[(int64_t)i * a.cout + o] = acc[m][n][q];
+      }
+    }
+  if (a.bias_partials && mblk == 0 && (int)threadIdx.x < BN) {
+    const int o = co0 + threadIdx.x;
+    if (o < a.cout) a.bias_partials[((int64_t)layer * a.nslabs + slab) * a.cout + o] = bsum;
+  }
+}
+
+template <typename T, int MTW, int NTW, int WM>
+static int launch_wgrad(const WgradArgs& a, int nbatch, int pro, hipStream_t st) {
+  constexpr int WN = 4 / WM, BM = WM * MTW * 32, BN = WN * NTW * 32, VEC = 16 / sizeof(T);
+  const size_t sh = (size_t)kWgKC * ((BM + VEC) + (BN + VEC)) * sizeof(T);
+  const int mblocks = (a.cin + BM - 1) / BM, nblocks = (a.cout + BN - 1) / BN;
+  dim3 grid((unsigned)a.nslabs, (unsigned)nblocks, (unsigned)(nbatch * mblocks)), block(256);
+  const bool cond = a.cond != nullptr;
+#define SRWN_WG(P, C)                                                              \
+  if (pro == P && cond == C) {                                                     \
+    hipLaunchKernelGGL((wgrad_kernel<T, MTW, NTW, WM, P, C>), grid, block, sh, st, a); \
+    return check_launch("wgrad");                                                  \
+  }
+  SRWN_WG(SRWN_PRO_NONE, false)
+  SRWN_WG(SRWN_PRO_GATE, false)
+  SRWN_WG(SRWN_PRO_NONE, true)
+#undef SRWN_WG
+  return set_error(SRWN_E_UNSUPPORTED, "wgrad: pro %d with cond=%d not built", pro, (int)cond);
+}
+
+extern "C" int32_t srwn_wgrad_slabs(int64_t rows) {
+  // ~2048 rows per slab, at most 256 slabs
+  int64_t n = (rows + 2047) / 2048;
+  if (n < 1) n = 1;
+  if (n > 256) n = 256;
+  return (int32_t)n;
+}
+
+extern "C" int srwn_wgrad(const void* in, int64_t in_batch_stride, int32_t cin, const void* dout,
+                          int64_t dout_batch_stride, int32_t cout, const void* cond, int64_t cond_batch_stride,
+                          int32_t cond_frames, int32_t pool_stride, const int32_t* shifts, int32_t nbatch,
+                          float* partials, float* bias_partials, int64_t rows, int32_t T, int32_t nslabs,
+                          int32_t pro, int32_t dtype, void* stream) {
+  if (rows == 0 || nbatch == 0) return 0;
+  if (!in || !dout || !partials) return set_error(SRWN_E_NULL, "wgrad: null pointer");
+  if (nbatch < 0 || nbatch > kWgMaxBatch) return set_error(SRWN_E_SHAPE, "wgrad: nbatch %d (max %d)", nbatch, kWgMaxBatch);
+  const int vec = (dtype == SRWN_BF16) ? 8 : 4;
+  if (rows < 0 || T < 1 || rows % T || cin < vec || cin % vec || cout < vec || cout % vec || nslabs < 1)
+    return set_error(SRWN_E_SHAPE, "wgrad: rows=%lld T=%d cin=%d cout=%d nslabs=%d", (long long)rows, T, cin, cout, nslabs);
+  if (cond && (pool_stride < 1 || (int64_t)cond_frames * pool_stride < T))
+    return set_error(SRWN_E_SHAPE, "wgrad: cond frames %d x pool %d < T %d", cond_frames, pool_stride, T);
+  WgradArgs a;
+  a.in = in; a.in_batch_stride = in_batch_stride; a.cin = cin;
+  a.dout = dout; a.dout_batch_stride = dout_batch_stride; a.cout = cout;
+  a.cond = cond; a.cond_batch_stride = cond_batch_stride; a.cond_frames = cond_frames; a.pool = pool_stride > 0 ? pool_stride : 1;
+  a.partials = partials; a.bias_partials = bias_partials;
+  a.rows = rows; a.Tlen = T; a.nslabs = nslabs;
+  int64_t rps = (rows + nslabs - 1) / nslabs;
+  rps = (rps + kWgKC - 1) / kWgKC * kWgKC;
+  a.rows_per_slab = (int)rps;
+  for (int i = 0; i < kWgMaxBatch; ++i) a.shifts[i] = (shifts && i < nbatch) ? shifts[i] : 0;
+  for (int i = 0; i < nbatch; ++i)
+    if (a.shifts[i] < 0) return set_error(SRWN_E_SHAPE, "wgrad: negative shift");
+  hipStream_t st = (hipStream_t)stream;
+  const bool big = (cin % 64 == 0) && (cout % 256 == 0);
+  const bool mid = (cin % 64 == 0) && (cout % 64 == 0);
+  if (dtype == SRWN_BF16) {
+    if (big) return launch_wgrad<bf16_t, 2, 2, 1>(a, nbatch, pro, st);
+    if (mid) return launch_wgrad<bf16_t, 1, 1, 2>(a, nbatch, pro, st);
+    return launch_wgrad<bf16_t, 1, 1, 1>(a, nbatch, pro, st);
+  } else if (dtype == SRWN_F32) {
+    if (big) return launch_wgrad<float, 2, 2, 1>(a, nbatch, pro, st);
+    if (mid) return launch_wgrad<float, 1, 1, 2>(a, nbatch, pro, st);
+    return launch_wgrad<float, 1, 1, 1>(a, nbatch, pro, st);
+  }
+  return set_error(SRWN_E_DTYPE, "wgrad: dtype %d", dtype);
+}
+
+// out[l*out_batch_stride + i] = scale * sum_s partials[(l*part_batch_mul*nslabs + s)*n + i]
+__global__ void reduce_partials_kernel(const float* __restrict__ partials, int nslabs, int64_t n, int nbatch,
+                                       int part_batch_mul, float scale, float* __restrict__ out,
+                                       int64_t out_batch_stride) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int l = blockIdx.y;
+  if (i >= n || l >= nbatch) return;
+  const float* p = partials + (int64_t)l * part_batch_mul * nslabs * n + i;
+  double s = 0.0;
+  for (int k = 0; k < nslabs; ++k) s += (double)p[(int64_t)k * n];
+  out[(int64_t)l * out_batch_stride + i] = (float)(s * (double)scale);
+}
+
+extern "C" int srwn_reduce_partials(const float* partials, int32_t nslabs, int64_t n, int32_t nbatch,
+                                    int32_t partials_batched, float scale, float* out, int64_t out_batch_stride,
+                                    void* stream) {
+  if (n == 0 || nbatch == 0) return 0;
+  if (!partials || !out) return set_error(SRWN_E_NULL, "reduce_partials: null pointer");
+  if (nslabs < 1 || n < 0 || nbatch < 0 || nbatch > 65535) return set_error(SRWN_E_SHAPE, "reduce_partials: nslabs=%d n=%lld nbatch=%d", nslabs, (long long)n, nbatch);
+  dim3 grid((unsigned)((n + 255) / 256), (unsigned)nbatch), block(256);
+  hipLaunchKernelGGL(reduce_partials_kernel, grid, block, 0, (hipStream_t)stream, partials, nslabs, n, nbatch,
+                     partials_batched ? 1 : 0, scale, out, out_batch_stride);
+  return check_launch("reduce_partials");
+}
+
+// sum of pool_stride consecutive time rows per frame: adjoint of the nearest-neighbour upsample
+// (ops.py:64-74) for the conditioning gradient: out[b,e,c] = sum_{t in frame e} g[b,t,c]
+template <typename T>
+__global__ void frame_sum_kernel(const T* __restrict__ g, T* __restrict__ out, int B, int Tlen, int C, int frames,
+                                 int pool) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)B * frames * C;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  const int64_t be = i / C;
+  const int e = (int)(be % frames), b = (int)(be / frames);
+  float s = 0.0f;
+  const int t0 = e * pool;
+  for (int t = t0; t < t0 + pool && t < Tlen; ++t) s += (float)g[((int64_t)b * Tlen + t) * C + c];
+  out[i] = (T)s;
+}
+
+extern "C" int srwn_frame_sum(const void* g, void* out, int32_t B, int32_t T, int32_t C, int32_t frames,
+                              int32_t pool_stride, int32_t dtype, void* stream) {
+  if (B == 0 || frames == 0) return 0;
+  if (!g || !out) return set_error(SRWN_E_NULL, "frame_sum: null pointer");
+  if (B < 0 || T < 1 || C < 1 || frames < 1 || pool_stride < 1) return set_error(SRWN_E_SHAPE, "frame_sum: shape");
+  const int64_t total = (int64_t)B * frames * C;
+  dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  if (dtype == SRWN_F32)
+    hipLaunchKernelGGL(frame_sum_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)g, (float*)out, B, T, C, frames, pool_stride);
+  else if (dtype == SRWN_BF16)
+    hipLaunchKernelGGL(frame_sum_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)g, (bf16_t*)out, B, T, C, frames, pool_stride);
+  else
+    return set_error(SRWN_E_DTYPE, "frame_sum: dtype %d", dtype);
+  return check_launch("frame_sum");
+}

@@ -205,3 +205,78 @@ def head_softmax_ce(x: torch.Tensor, wpack_ptr: int, bias: torch.Tensor, targets
 def reduce_loss(loss_partials: torch.Tensor, n: int, scale: float, out: torch.Tensor):
     call("srwn_reduce_loss", _chk(loss_partials, "loss_partials", torch.float32), int(n), float(scale),
          _chk(out, "loss", torch.float32), _stream())
+
+
+# ----------------------------------------------------------------------------------------------
+# backward
+# ----------------------------------------------------------------------------------------------
+def residual_layer_bwd(g_in: Optional[torch.Tensor], df_up: Optional[torch.Tensor], wconvT_up_ptr: Optional[int],
+                       g_out: Optional[torch.Tensor], wresT_ptr: Optional[int], wskipT_ptr: Optional[int],
+                       dtotal: Optional[torch.Tensor], z: Optional[torch.Tensor], df_out: Optional[torch.Tensor],
+                       B: int, T: int, R: int, S: int, K: int, dilation_up: int, has_up: bool, has_down: bool,
+                       dtype: torch.dtype):
+    shp = (B, T, R)
+    pg = _opt(g_in, "g_in", dtype, shp)
+    pdu = _opt(df_up, "df_up", dtype, shp)
+    pgo = _opt(g_out, "g_out", dtype, shp)
+    pz = _opt(z, "z", dtype, shp)
+    pdo = _opt(df_out, "df_out", dtype, shp)
+    pdt = None
+    if dtotal is not None:
+        pdt = _chk(dtotal, "dtotal", dtype)
+        if dtotal.numel() != B * T * S:
+            raise ValueError("dtotal: %d elements, expected %d" % (dtotal.numel(), B * T * S))
+    call("srwn_residual_layer_bwd", pg, pdu, wconvT_up_ptr, pgo, wresT_ptr, wskipT_ptr, pdt, pz, pdo, B, T, R, S, K,
+         int(dilation_up), int(has_up), int(has_down), abi_dtype(dtype), _stream())
+
+
+def wgrad_slabs(rows: int) -> int:
+    return int(_lib.load().srwn_wgrad_slabs(int(rows)))
+
+
+def wgrad(in_ptr: int, in_batch_stride: int, cin: int, dout_ptr: int, dout_batch_stride: int, cout: int,
+          shifts: Optional[List[int]], nbatch: int, partials: torch.Tensor, bias_partials: Optional[torch.Tensor],
+          rows: int, T: int, nslabs: int, dtype: torch.dtype, pro: int = PRO_NONE, cond_ptr: Optional[int] = None,
+          cond_batch_stride: int = 0, cond_frames: int = 1, pool_stride: int = 1):
+    """Raw pointers for in/dout (they index stacks of per-layer tensors); partials are checked for size."""
+    import ctypes as C
+    pp = _chk(partials, "partials", torch.float32)
+    if partials.numel() < nbatch * nslabs * cin * cout:
+        raise ValueError("wgrad: partials needs %d floats" % (nbatch * nslabs * cin * cout))
+    pb = None
+    if bias_partials is not None:
+        pb = _chk(bias_partials, "bias_partials", torch.float32)
+        if bias_partials.numel() < nbatch * nslabs * cout:
+            raise ValueError("wgrad: bias_partials needs %d floats" % (nbatch * nslabs * cout))
+    sh = None
+    if shifts is not None:
+        if len(shifts) != nbatch:
+            raise ValueError("wgrad: len(shifts) != nbatch")
+        sh = (C.c_int32 * nbatch)(*[int(s) for s in shifts])
+    call("srwn_wgrad", in_ptr, int(in_batch_stride), int(cin), dout_ptr, int(dout_batch_stride), int(cout), cond_ptr,
+         int(cond_batch_stride), int(cond_frames), int(pool_stride), sh, int(nbatch), pp, pb, int(rows), int(T),
+         int(nslabs), int(pro), abi_dtype(dtype), _stream())
+
+
+def reduce_partials(partials: torch.Tensor, nslabs: int, n: int, nbatch: int, partials_batched: bool, scale: float,
+                    out_ptr: int, out_batch_stride: int):
+    call("srwn_reduce_partials", _chk(partials, "partials", torch.float32), int(nslabs), int(n), int(nbatch),
+         int(bool(partials_batched)), float(scale), out_ptr, int(out_batch_stride), _stream())
+
+
+def frame_sum(g: torch.Tensor, frames: int, pool_stride: int) -> torch.Tensor:
+    B, T, Cc = g.shape
+    out = torch.empty((B, frames, Cc), dtype=g.dtype, device=g.device)
+    call("srwn_frame_sum", _chk(g, "g"), out.data_ptr(), B, T, Cc, int(frames), int(pool_stride), abi_dtype(g.dtype),
+         _stream())
+    return out
+
+
+def adam_step(params: torch.Tensor, grads: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: torch.Tensor,
+              lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, grad_scale: float = 1.0):
+    n = params.numel()
+    for t, nm in ((params, "params"), (grads, "grads"), (m, "m"), (v, "v")):
+        _chk(t, nm, torch.float32, (n,))
+    _chk(step, "step", torch.int64, (1,))
+    call("srwn_adam_step", params.data_ptr(), grads.data_ptr(), m.data_ptr(), v.data_ptr(), n, step.data_ptr(),
+         float(lr), float(beta1), float(beta2), float(eps), float(grad_scale), _stream())

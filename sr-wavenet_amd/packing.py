@@ -54,3 +54,14 @@ def pack_linear_T(pk, src_offset: int, Cin: int, Cout: int, cin_pad: int, perm: 
     off = pk.reserve(cin_pad // 32, cout_pad // 16)
     fill_linear_T(pk, off, src_offset, Cin, Cout, cin_pad // 32, cout_pad // 16, perm=perm)
     return off
+
+
+def pack_conv_T(pk, src_offset: int, K: int, R: int) -> int:
+    """Data gradient of the dilated conv [K,R,R]: rows = in channel i, k = tap*R + out channel o
+    (A[i][(k,o)] = Wf[k][i][o]); one fill per tap because the source is not affine across taps."""
+    mt, ks_total, ks = R // 32, K * R // 16, R // 16
+    off = pk.reserve(mt, ks_total)
+    for k in range(K):
+        pk.fill(off, src_offset=src_offset + k * R * R, rows_valid=R, k_valid=R, row_stride=R, k_stride=1,
+                mt_count=mt, ks_total=ks_total, ks_offset=k * ks, ks_count=ks)
+    return off

@@ -1,0 +1,154 @@
+"""GPU parity tests of the backward kernels (layer data gradient, weight gradients, Adam) vs the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import wavenet_np as O
+from tests._pkg import sub
+from tests.test_gpu_kernels import DEV, TOL, dev, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _gate_grad(z):
+    s = 1 / (1 + np.exp(-z))
+    return (s + z * s * (1 - s)) * (1 - z * z)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("R,S", [(64, 256), (32, 64)])
+@pytest.mark.parametrize("B,T,d_up", [(2, 64, 1), (1, 100, 8), (2, 300, 64), (1, 50, 128)])
+def test_residual_layer_bwd(dt, R, S, B, T, d_up):
+    K = sub("kernels"); P = sub("packing")
+    rng = np.random.default_rng(R + T + d_up)
+    wf_up = rng.standard_normal((2, R, R)) / np.sqrt(2 * R)
+    wr = rng.standard_normal((R, R)) / np.sqrt(R)
+    ws = rng.standard_normal((R, S)) / np.sqrt(S)
+    flat = torch.cat([dev(wf_up).flatten(), dev(wr).flatten(), dev(ws).flatten()])
+    pk = K.Packer(DEV)
+    oc = P.pack_conv_T(pk, 0, 2, R)
+    orr = P.pack_linear_T(pk, 2 * R * R, R, R, R, perm=True)
+    osk = P.pack_linear_T(pk, 3 * R * R, R, S, R)
+    pk.finalize()
+    buf = torch.empty(pk.total, dtype=dt, device=DEV); pk.gather(flat, buf)
+    es = buf.element_size(); base = buf.data_ptr()
+    g_in = dev(rng.standard_normal((B, T, R)), dt)
+    df_up = dev(rng.standard_normal((B, T, R)), dt)
+    dtotal = dev(rng.standard_normal((B, T, S)), dt)
+    z = dev(np.tanh(rng.standard_normal((B, T, R))), dt)
+    g_out = torch.full((B, T, R), float("nan"), dtype=dt, device=DEV); df_out = torch.full_like(g_out, float("nan"))
+    K.residual_layer_bwd(g_in, df_up, base + oc * es, g_out, base + orr * es, base + osk * es, dtotal, z, df_out,
+                         B, T, R, S, 2, d_up, True, True, dt)
+    # oracle: data gradient of the conv + residual path, then dc/df
+    q = lambda t: t.double().cpu().numpy()
+    wq = lambda w: dev(w, dt).double().cpu().numpy()
+    dxc, _ = O._conv_backward(np.zeros((B, T, R)), wq(wf_up), d_up, q(df_up))
+    G = q(g_in) * O.SQRT_HALF + dxc
+    assert rel_err(q(g_out), G) < TOL[dt]
+    Gq = q(g_out) if dt == torch.bfloat16 else G  # the kernel feeds the rounded tile forward only via registers
+    dc = (G * O.SQRT_HALF) @ wq(wr).T + q(dtotal) @ wq(ws).T
+    df = dc * _gate_grad(q(z))
+    assert rel_err(q(df_out), df) < TOL[dt]
+    # DOWN only (top layer) and UP only (below layer 0)
+    df2 = torch.full_like(df_out, float("nan"))
+    K.residual_layer_bwd(None, None, None, None, None, base + osk * es, dtotal, z, df2, B, T, R, S, 2, 1, False, True, dt)
+    assert rel_err(q(df2), (q(dtotal) @ wq(ws).T) * _gate_grad(q(z))) < TOL[dt]
+    g2 = torch.full_like(g_out, float("nan"))
+    K.residual_layer_bwd(None, df_up, base + oc * es, g2, None, None, None, None, None, B, T, R, S, 2, d_up, True, False, dt)
+    assert rel_err(q(g2), dxc) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cin,cout,B,T,shift,gate", [(64, 64, 2, 300, 4, False), (64, 256, 2, 150, 0, True),
+                                                       (256, 256, 1, 200, 0, False), (32, 32, 3, 70, 1, False),
+                                                       (64, 32, 1, 5000, 512, True), (40, 64, 2, 64, 0, False)])
+def test_wgrad(dt, cin, cout, B, T, shift, gate):
+    K = sub("kernels")
+    rows = B * T
+    rng = np.random.default_rng(cin + cout + T)
+    L = 3
+    x = dev(np.tanh(rng.standard_normal((L, B, T, cin))), dt)
+    dy = dev(rng.standard_normal((2 if cout != 256 else L, B, T, cout)), dt)
+    shared = dy.shape[0] != L
+    shifts = [shift, 0, 2 * shift]
+    ns = K.wgrad_slabs(rows)
+    parts = torch.full((L * ns * cin * cout,), float("nan"), dtype=torch.float32, device=DEV)
+    bparts = torch.full((L * ns * cout,), float("nan"), dtype=torch.float32, device=DEV)
+    es = x.element_size()
+    K.wgrad(x.data_ptr(), rows * cin, cin, dy.data_ptr(), 0 if shared else rows * cout, cout, shifts, L, parts, bparts,
+            rows, T, ns, dt, pro=K.PRO_GATE if gate else K.PRO_NONE)
+    out = torch.empty((L, cin, cout), dtype=torch.float32, device=DEV)
+    K.reduce_partials(parts, ns, cin * cout, L, True, 0.5, out.data_ptr(), cin * cout)
+    bout = torch.empty((L, cout), dtype=torch.float32, device=DEV)
+    K.reduce_partials(bparts, ns, cout, L, True, 1.0, bout.data_ptr(), cout)
+    xs = x.double().cpu().numpy(); ds = dy.double().cpu().numpy()
+    if gate:
+        xs = xs / (1 + np.exp(-xs)) if False else xs * (1 / (1 + np.exp(-xs)))
+        if dt == torch.bfloat16:
+            xs = dev(xs, dt).double().cpu().numpy()
+    for l in range(L):
+        d = ds[0 if shared else l]
+        s = shifts[l]
+        xsh = np.zeros_like(xs[l]); 
+        if s < T:
+            xsh[:, s:, :] = xs[l][:, :T - s, :]
+        ref = 0.5 * np.einsum("bti,bto->io", xsh, d)
+        assert rel_err(out[l].cpu().numpy(), ref) < TOL[dt], l
+        assert rel_err(bout[l].cpu().numpy(), d.sum((0, 1))) < TOL[dt], l
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_wgrad_cond(dt):
+    K = sub("kernels")
+    B, T, cin, cout, pool, shift = 2, 128, 64, 64, 16, 8
+    rows = B * T
+    rng = np.random.default_rng(0)
+    x = dev(rng.standard_normal((1, B, T, cin)), dt); dy = dev(rng.standard_normal((1, B, T, cout)), dt)
+    cb = dev(rng.standard_normal((1, B, T // pool, cin)), dt)
+    ns = K.wgrad_slabs(rows)
+    parts = torch.empty(ns * cin * cout, dtype=torch.float32, device=DEV)
+    K.wgrad(x.data_ptr(), 0, cin, dy.data_ptr(), 0, cout, [shift], 1, parts, None, rows, T, ns, dt,
+            cond_ptr=cb.data_ptr(), cond_frames=T // pool, pool_stride=pool)
+    out = torch.empty((cin, cout), dtype=torch.float32, device=DEV)
+    K.reduce_partials(parts, ns, cin * cout, 1, True, 1.0, out.data_ptr(), 0)
+    xin = x[0].double().cpu().numpy() + np.repeat(cb[0].double().cpu().numpy(), pool, axis=1)
+    if dt == torch.bfloat16:
+        xin = dev(xin, dt).double().cpu().numpy()
+    xsh = np.zeros_like(xin); xsh[:, shift:, :] = xin[:, :T - shift, :]
+    ref = np.einsum("bti,bto->io", xsh, dy[0].double().cpu().numpy())
+    assert rel_err(out.cpu().numpy(), ref) < TOL[dt]
+
+
+def test_frame_sum_and_init_conv_wgrad():
+    K = sub("kernels")
+    rng = np.random.default_rng(1)
+    B, T, R, pool = 2, 96, 64, 16
+    g = dev(rng.standard_normal((B, T, R)))
+    fs = K.frame_sum(g, T // pool, pool).cpu().numpy()
+    assert rel_err(fs, g.cpu().numpy().reshape(B, T // pool, pool, R).sum(2)) < 1e-5
+    audio = dev(rng.uniform(-1, 1, (B, T)))
+    for shift in (0, 1):
+        gw = torch.empty(2 * R, dtype=torch.float32, device=DEV); gb = torch.empty(R, dtype=torch.float32, device=DEV)
+        ws = torch.empty(int(sub("_lib").load().srwn_init_conv_wgrad_partials(B, T, R, 2)), dtype=torch.float32, device=DEV)
+        K.init_conv_wgrad(audio, g, gw, gb, 2, shift, ws)
+        x0 = audio.double().cpu().numpy()[:, :, None]
+        if shift:
+            x0 = O.right_shift(x0)
+        _, dw = O._conv_backward(x0, np.zeros((2, 1, R)), 1, g.double().cpu().numpy())
+        assert rel_err(gw.cpu().numpy().reshape(2, 1, R), dw) < 1e-5
+        assert rel_err(gb.cpu().numpy(), g.double().cpu().numpy().sum((0, 1))) < 1e-5
+
+
+def test_adam_matches_tf_formula():
+    K = sub("kernels")
+    rng = np.random.default_rng(0)
+    n = 1000
+    th = rng.standard_normal(n); m = np.zeros(n); v = np.zeros(n)
+    p = dev(th); pm = torch.zeros(n, device=DEV); pv = torch.zeros(n, device=DEV)
+    step = torch.zeros(1, dtype=torch.int64, device=DEV)
+    for t in range(1, 6):
+        g = rng.standard_normal(n) * 0.1
+        th, m, v = O.adam_step_tf(th, 0.5 * g, m, v, t, lr=1e-2)
+        K.adam_step(p, dev(g), pm, pv, step, 1e-2, grad_scale=0.5)
+    assert int(step.item()) == 5
+    assert rel_err(p.cpu().numpy(), th) < 1e-5
