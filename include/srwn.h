@@ -85,11 +85,12 @@ int srwn_init_conv_wgrad(const float* audio, const void* g, float* partials, flo
  *   c   = z * sigmoid(z)                          (ops.py:33: the gate conv result is discarded)
  *   h   = (xin + c @ Wr + bias_r) * sqrt(.5)      -> h_out
  * The skip 1x1 (ops.py:44) is deferred to srwn_pw_linear over the stored z of all layers.
- * wconv: packed [R/32][K*R/16] (last tap permuted k order), wres: packed [R/32][R/16] (permuted). */
+ * wconv: packed [R/32][K*R/16] (last tap permuted k order), wres: packed [R/32][R/16] (permuted).
+ * cond rows are cond_row_stride elements apart (one [B*frames, L*R] product serves every layer). */
 int srwn_residual_layer_fwd(const void* x, const void* cond, const void* wconv, const void* wres,
                             const float* bias_f, const float* bias_r, void* h_out, void* z_out, int32_t B,
                             int32_t T, int32_t R, int32_t K, int32_t dilation, int32_t cond_frames,
-                            int32_t pool_stride, int32_t dtype, void* stream);
+                            int32_t pool_stride, int32_t cond_row_stride, int32_t dtype, void* stream);
 
 /* ---- pointwise linear ("channels GEMM"): tf.layers.conv1d kernel_size=1 (ops.py:39,44;
  * model.py:53,56,180) and the sum of all skip 1x1s (model.py:50) as one K = L*R contraction:
@@ -140,7 +141,7 @@ int srwn_residual_layer_bwd(const void* g_in, const void* df_up, const void* wco
 int32_t srwn_wgrad_slabs(int64_t rows);
 int srwn_wgrad(const void* in, int64_t in_batch_stride, int32_t cin, const void* dout, int64_t dout_batch_stride,
                int32_t cout, const void* cond, int64_t cond_batch_stride, int32_t cond_frames, int32_t pool_stride,
-               const int32_t* shifts /* host array [nbatch] or NULL */, int32_t nbatch, float* partials,
+               int32_t cond_row_stride, const int32_t* shifts /* host array [nbatch] or NULL */, int32_t nbatch, float* partials,
                float* bias_partials, int64_t rows, int32_t T, int32_t nslabs, int32_t pro, int32_t dtype,
                void* stream);
 int srwn_reduce_partials(const float* partials, int32_t nslabs, int64_t n, int32_t nbatch, int32_t partials_batched,

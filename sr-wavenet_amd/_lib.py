@@ -29,7 +29,7 @@ SIGNATURES = {
     "srwn_init_conv_wgrad_partials": (_i64, [_i32, _i32, _i32, _i32]),
     "srwn_init_conv_wgrad": (C.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "srwn_residual_layer_fwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
-                                          _i32, _p]),
+                                          _i32, _i32, _p]),
     "srwn_pw_linear": (C.c_int, [_p, _i64, _i64, _i32, _i32, _p, _p, _p, _i64, _i32, _i32, _i64, _p, _i64, _i32,
                                  _i32, _i32, _p]),
     "srwn_softmax_ce_partials": (_i64, [_i64]),
@@ -38,8 +38,8 @@ SIGNATURES = {
     "srwn_residual_layer_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32,
                                           _i32, _i32, _i32, _p]),
     "srwn_wgrad_slabs": (_i32, [_i64]),
-    "srwn_wgrad": (C.c_int, [_p, _i64, _i32, _p, _i64, _i32, _p, _i64, _i32, _i32, _p, _i32, _p, _p, _i64, _i32,
-                             _i32, _i32, _i32, _p]),
+    "srwn_wgrad": (C.c_int, [_p, _i64, _i32, _p, _i64, _i32, _p, _i64, _i32, _i32, _i32, _p, _i32, _p, _p, _i64,
+                             _i32, _i32, _i32, _i32, _p]),
     "srwn_reduce_partials": (C.c_int, [_p, _i32, _i64, _i32, _i32, _f32, _p, _i64, _p]),
     "srwn_frame_sum": (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "srwn_adam_step": (C.c_int, [_p, _p, _p, _p, _i64, _p, _f32, _f32, _f32, _f32, _f32, _p]),

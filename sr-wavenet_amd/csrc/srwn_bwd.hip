@@ -217,7 +217,7 @@ constexpr int kWgMaxBatch = 64;
 struct WgradArgs {
   const void* in;  int64_t in_batch_stride;  int cin;   // In: [rows, cin] per batch entry (elements)
   const void* dout; int64_t dout_batch_stride; int cout; // Dout: [rows, cout]
-  const void* cond; int64_t cond_batch_stride; int cond_frames; int pool;  // optional add on In
+  const void* cond; int64_t cond_batch_stride; int cond_frames; int pool; int cond_stride;  // optional add on In
   float* partials; float* bias_partials;
   int64_t rows; int Tlen; int rows_per_slab; int nslabs;
   int shifts[kWgMaxBatch];
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         }
         if (COND) {
           const int64_t bidx = row / a.Tlen;
-          const T* cp = cond + (bidx * a.cond_frames + (t - shift) / a.pool) * a.cin + ci0 + cv;
+          const T* cp = cond + (bidx * a.cond_frames + (t - shift) / a.pool) * a.cond_stride + ci0 + cv;
 #pragma unroll
           for (int e = 0; e < VEC; ++e) v[e] += (float)cp[e];
         }
@@ -407,7 +407,8 @@ extern "C" int32_t srwn_wgrad_slabs(int64_t rows) {
 
 extern "C" int srwn_wgrad(const void* in, int64_t in_batch_stride, int32_t cin, const void* dout,
                           int64_t dout_batch_stride, int32_t cout, const void* cond, int64_t cond_batch_stride,
-                          int32_t cond_frames, int32_t pool_stride, const int32_t* shifts, int32_t nbatch,
+                          int32_t cond_frames, int32_t pool_stride, int32_t cond_row_stride, const int32_t* shifts,
+                          int32_t nbatch,
                           float* partials, float* bias_partials, int64_t rows, int32_t T, int32_t nslabs,
                           int32_t pro, int32_t dtype, void* stream) {
   if (rows == 0 || nbatch == 0) return 0;
@@ -416,12 +417,12 @@ extern "C" int srwn_wgrad(const void* in, int64_t in_batch_stride, int32_t cin, 
   const int vec = (dtype == SRWN_BF16) ? 8 : 4;
   if (rows < 0 || T < 1 || rows % T || cin < vec || cin % vec || cout < vec || cout % vec || nslabs < 1)
     return set_error(SRWN_E_SHAPE, "wgrad: rows=%lld T=%d cin=%d cout=%d nslabs=%d", (long long)rows, T, cin, cout, nslabs);
-  if (cond && (pool_stride < 1 || (int64_t)cond_frames * pool_stride < T))
+  if (cond && (pool_stride < 1 || cond_row_stride < cin || (int64_t)cond_frames * pool_stride < T))
     return set_error(SRWN_E_SHAPE, "wgrad: cond frames %d x pool %d < T %d", cond_frames, pool_stride, T);
   WgradArgs a;
   a.in = in; a.in_batch_stride = in_batch_stride; a.cin = cin;
   a.dout = dout; a.dout_batch_stride = dout_batch_stride; a.cout = cout;
-  a.cond = cond; a.cond_batch_stride = cond_batch_stride; a.cond_frames = cond_frames; a.pool = pool_stride > 0 ? pool_stride : 1;
+  a.cond = cond; a.cond_batch_stride = cond_batch_stride; a.cond_frames = cond_frames; a.pool = pool_stride > 0 ? pool_stride : 1; a.cond_stride = cond_row_stride;
   a.partials = partials; a.bias_partials = bias_partials;
   a.rows = rows; a.Tlen = T; a.nslabs = nslabs;
   int64_t rps = (rows + nslabs - 1) / nslabs;

@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void layer_fwd_kernel(const T* __restrict__ x,
                                                         const float* __restrict__ bias_f,
                                                         const float* __restrict__ bias_r, T* __restrict__ h_out,
                                                         T* __restrict__ z_out, int Tlen, int dilation,
-                                                        int cond_frames, int pool) {
+                                                        int cond_frames, int pool, int cond_stride) {
   constexpr int R = 32 * RT;
   constexpr int KS = R / 16;  // k-steps per tap
   constexpr int NCONV = RT * K * KS, NRES = RT * KS;
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void layer_fwd_kernel(const T* __restrict__ x,
   const int t_wave = (blockIdx.x * 4 + wave) * (32 * NT);
   if (t_wave >= Tlen) return;
   const T* xb = x + (size_t)b * Tlen * R;
-  const T* cb = COND ? cond + (size_t)b * cond_frames * R : nullptr;
+  const T* cb = COND ? cond + (size_t)b * cond_frames * cond_stride : nullptr;
 
   // ---- B fragments: taps 0..K-2 natural k order, last tap (shift 0) permuted so that its
   //      registers are also the residual-add operand in accumulator layout.
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void layer_fwd_kernel(const T* __restrict__ x,
       const int tk = tc - (K - 1 - k) * dilation;
       const bool valid = (tc < Tlen) && (tk >= 0);
       const T* row = xb + (size_t)(valid ? tk : 0) * R;
-      const T* crow_ = COND ? cb + (size_t)((valid ? tk : 0) / pool) * R : nullptr;
+      const T* crow_ = COND ? cb + (size_t)((valid ? tk : 0) / pool) * cond_stride : nullptr;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         Frag<T> f;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void layer_fwd_kernel(const T* __restrict__ x,
 template <typename T, int RT, int K, int NT>
 static int launch_layer_fwd(const void* x, const void* cond, const void* wconv, const void* wres,
                             const float* bias_f, const float* bias_r, void* h_out, void* z_out, int B, int Tlen,
-                            int dilation, int cond_frames, int pool, hipStream_t st) {
+                            int dilation, int cond_frames, int pool, int cond_stride, hipStream_t st) {
   constexpr int R = 32 * RT, KS = R / 16;
   const size_t sh = (size_t)(RT * K * KS + RT * KS) * 64 * sizeof(Frag<T>);
   dim3 grid((unsigned)((Tlen + 4 * 32 * NT - 1) / (4 * 32 * NT)), (unsigned)B), block(256);
@@ -162,12 +162,12 @@ static int launch_layer_fwd(const void* x, const void* cond, const void* wconv, 
     auto kfn = layer_fwd_kernel<T, RT, K, NT, true>;
     if (sh > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     hipLaunchKernelGGL(kfn, grid, block, sh, st, (const T*)x, (const T*)cond, (const T*)wconv, (const T*)wres, bias_f,
-                       bias_r, (T*)h_out, (T*)z_out, Tlen, dilation, cond_frames, pool);
+                       bias_r, (T*)h_out, (T*)z_out, Tlen, dilation, cond_frames, pool, cond_stride);
   } else {
     auto kfn = layer_fwd_kernel<T, RT, K, NT, false>;
     if (sh > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     hipLaunchKernelGGL(kfn, grid, block, sh, st, (const T*)x, (const T*)nullptr, (const T*)wconv, (const T*)wres,
-                       bias_f, bias_r, (T*)h_out, (T*)z_out, Tlen, dilation, 1, 1);
+                       bias_f, bias_r, (T*)h_out, (T*)z_out, Tlen, dilation, 1, 1, R);
   }
   return check_launch("residual_layer_fwd");
 }
@@ -175,17 +175,18 @@ static int launch_layer_fwd(const void* x, const void* cond, const void* wconv, 
 extern "C" int srwn_residual_layer_fwd(const void* x, const void* cond, const void* wconv, const void* wres,
                                        const float* bias_f, const float* bias_r, void* h_out, void* z_out,
                                        int32_t B, int32_t T, int32_t R, int32_t K, int32_t dilation,
-                                       int32_t cond_frames, int32_t pool_stride, int32_t dtype, void* stream) {
+                                       int32_t cond_frames, int32_t pool_stride, int32_t cond_row_stride,
+                                       int32_t dtype, void* stream) {
   if (B == 0 || T == 0) return 0;
   if (!x || !wconv || !wres || !bias_f || !bias_r || !h_out || !z_out)
     return set_error(SRWN_E_NULL, "residual_layer_fwd: null pointer");
   if (B < 0 || T < 0 || dilation < 1) return set_error(SRWN_E_SHAPE, "residual_layer_fwd: B=%d T=%d d=%d", B, T, dilation);
-  if (cond && (pool_stride < 1 || (int64_t)cond_frames * pool_stride < T))
+  if (cond && (pool_stride < 1 || cond_row_stride < R || cond_row_stride % 8 || (int64_t)cond_frames * pool_stride < T))
     return set_error(SRWN_E_SHAPE, "residual_layer_fwd: cond frames %d x pool %d < T %d", cond_frames, pool_stride, T);
   if (K != 2) return set_error(SRWN_E_UNSUPPORTED, "residual_layer_fwd: filter_width %d (only 2 is built)", K);
   hipStream_t st = (hipStream_t)stream;
 #define SRWN_LF(TT, RT_, NT_) \
-  return launch_layer_fwd<TT, RT_, 2, NT_>(x, cond, wconv, wres, bias_f, bias_r, h_out, z_out, B, T, dilation, cond_frames, pool_stride, st)
+  return launch_layer_fwd<TT, RT_, 2, NT_>(x, cond, wconv, wres, bias_f, bias_r, h_out, z_out, B, T, dilation, cond_frames, pool_stride, cond_row_stride, st)
   if (dtype == SRWN_BF16) {
     if (R == 32) SRWN_LF(bf16_t, 1, 2);
     if (R == 64) SRWN_LF(bf16_t, 2, 2);

@@ -1,0 +1,441 @@
+"""Training/inference engine for the WaveNet residual stack on one MI355X (one process per GPU).
+
+Mirrors the graph bodies of the reference's model classes -- ``WaveNet.createNetwork``
+(model.py:33-62) and ``WaveNetAutoEncoder.createDecoder`` (model.py:158-200) -- as a fixed
+sequence of libsrwn.so kernel launches over pre-allocated HBM buffers:
+
+  forward   input conv -> L x fused residual layer (h, z saved) -> skip sum as ONE K = L*R
+            contraction over the saved z -> relu -> 1x1 -> relu -> last 1x1 + softmax-CE (fused)
+  backward  head data gradients -> L x fused layer data gradient (top down) -> batched weight
+            gradients (time-contraction MFMA GEMMs + deterministic slab reduction)
+  update    [RCCL all-reduce of the flat fp32 gradient buffer] -> TF-Adam -> re-pack bf16 weights
+
+HBM layout (channels-last, compute dtype): xs [L+1,B,T,R] layer inputs, zs [L,B,T,R] tanh
+outputs, dfs [L,B,T,R], gs [L+1,B,T,R] residual-stream gradients (gs[L] stays zero), r0/r1/da1/
+dtotal [B*T,S], dlogits [B*T,Cp].  Parameters, gradients and Adam moments are single flat fp32
+buffers laid out struct-of-arrays across layers so every batched kernel sees a constant stride.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import kernels as K
+from . import packing as P
+
+SQRT_HALF = 0.7071067811865476
+
+
+@dataclass
+class StackConfig:
+    dilations: Sequence[int]
+    filter_width: int = 2
+    dilation_channels: int = 32   # R
+    skip_channels: int = 256      # S
+    output_channels: int = 256    # C (softmax classes / head width)
+    cond_channels: int = 0        # channels of encoding_w_condition (model.py:161-167); 0 = no conditioning
+    pool_stride: int = 1
+    shift_input: bool = False     # RightShift(truth) teacher forcing (model.py:172)
+    dtype: torch.dtype = torch.bfloat16
+    learning_rate: float = 1e-3
+
+
+class Section:
+    __slots__ = ("name", "offset", "shape", "numel")
+
+    def __init__(self, name, offset, shape):
+        self.name, self.offset, self.shape = name, offset, tuple(shape)
+        self.numel = int(np.prod(shape))
+
+
+class WaveNetEngine:
+    def __init__(self, cfg: StackConfig, batch: int, length: int, device="cuda", seed: int = 0,
+                 process_group=None):
+        if cfg.filter_width != 2:
+            raise NotImplementedError("filter_width %d: only 2 is built (reference default, model.py:9)" % cfg.filter_width)
+        if cfg.dilation_channels not in (32, 64):
+            raise NotImplementedError("dilation_channels %d: built for 32 and 64" % cfg.dilation_channels)
+        if cfg.skip_channels % 32 or cfg.skip_channels < 32:
+            raise NotImplementedError("skip_channels must be a multiple of 32")
+        if cfg.output_channels < 1 or cfg.output_channels > 256:
+            raise NotImplementedError("output_channels must be in [1, 256]")
+        if cfg.cond_channels and (length % cfg.pool_stride):
+            raise ValueError("length %d is not a multiple of pool_stride %d" % (length, cfg.pool_stride))
+        self.cfg = cfg
+        self.B, self.T = int(batch), int(length)
+        self.N = self.B * self.T
+        self.L = len(cfg.dilations)
+        self.dil = [int(d) for d in cfg.dilations]
+        self.R, self.S, self.C = cfg.dilation_channels, cfg.skip_channels, cfg.output_channels
+        self.Kw = cfg.filter_width
+        self.Cp = (self.C + 31) // 32 * 32
+        self.E = cfg.cond_channels
+        self.Ep = (self.E + 15) // 16 * 16
+        self.frames = self.T // cfg.pool_stride if self.E else 0
+        self.dev = torch.device(device)
+        self.dt = cfg.dtype
+        self.pg = process_group
+        self.world = 1
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self.world = torch.distributed.get_world_size(process_group)
+        self._build_params(seed)
+        self._build_packing()
+        self._alloc_buffers()
+        self.repack()
+
+    # ------------------------------------------------------------------------------------------
+    # parameters
+    # ------------------------------------------------------------------------------------------
+    def _build_params(self, seed):
+        L, R, S, Kw, Cp, E = self.L, self.R, self.S, self.Kw, self.Cp, self.E
+        secs: Dict[str, Section] = {}
+        off = 0
+
+        def add(name, shape):
+            nonlocal off
+            secs[name] = Section(name, off, shape)
+            off += secs[name].numel
+
+        add("init_w", (Kw, 1, R)); add("init_b", (R,))
+        add("WF", (L, Kw, R, R)); add("BF", (L, R))
+        add("WR", (L, R, R)); add("BR", (L, R))
+        add("WS", (L, R, S)); add("BS", (L, S))
+        if E:
+            add("WC", (L, E, R)); add("BC", (L, R))
+        add("head_w1", (S, S)); add("head_b1", (S,))
+        add("head_w2", (S, Cp)); add("head_b2", (Cp,))   # padded to Cp columns (pad stays exactly zero)
+        self.sections = secs
+        self.nparams = off
+        self.params = torch.zeros(off, dtype=torch.float32, device=self.dev)
+        self.grads = torch.zeros(off, dtype=torch.float32, device=self.dev)
+        self.adam_m = torch.zeros(off, dtype=torch.float32, device=self.dev)
+        self.adam_v = torch.zeros(off, dtype=torch.float32, device=self.dev)
+        self.adam_step = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        # the dead gate conv variables of ops.py:31-33 exist in reference checkpoints; they take no
+        # part in the graph (TF reports None gradients) so they live outside the trained buffer.
+        self.dead_gate = {"WG": torch.zeros((L, Kw, R, R), dtype=torch.float32, device=self.dev),
+                          "BG": torch.zeros((L, R), dtype=torch.float32, device=self.dev)}
+        self.init_parameters(seed)
+
+    def view(self, name: str, buf: Optional[torch.Tensor] = None) -> torch.Tensor:
+        s = self.sections[name]
+        buf = self.params if buf is None else buf
+        return buf[s.offset:s.offset + s.numel].view(s.shape)
+
+    def init_parameters(self, seed: int):
+        """Xavier-uniform kernels, zero biases (ops.py:15,18; tf.layers.conv1d defaults)."""
+        rng = np.random.default_rng(seed)
+
+        def xav(shape, fan_in, fan_out):
+            lim = math.sqrt(6.0 / (fan_in + fan_out))
+            return torch.tensor(rng.uniform(-lim, lim, size=shape), dtype=torch.float32)
+
+        L, R, S, Kw, C, E = self.L, self.R, self.S, self.Kw, self.C, self.E
+        host = torch.zeros(self.nparams, dtype=torch.float32)
+
+        def put(name, t):
+            s = self.sections[name]
+            host[s.offset:s.offset + s.numel] = t.reshape(-1)
+
+        put("init_w", xav((Kw, 1, R), Kw * 1, Kw * R))
+        put("WF", xav((L, Kw, R, R), Kw * R, Kw * R))
+        put("WR", xav((L, R, R), R, R))
+        put("WS", xav((L, R, S), R, S))
+        if E:
+            put("WC", xav((L, E, R), E, R))
+        put("head_w1", xav((S, S), S, S))
+        w2 = torch.zeros((S, self.Cp))
+        w2[:, :C] = xav((S, C), S, C)
+        put("head_w2", w2)
+        self.params.copy_(host)
+        self.dead_gate["WG"].copy_(xav((L, Kw, R, R), Kw * R, Kw * R))
+        self.adam_m.zero_(); self.adam_v.zero_(); self.adam_step.zero_()
+
+    def load_oracle_params(self, sp):
+        """Copies an oracle ``StackParams`` (tests) into the flat buffer."""
+        host = torch.zeros(self.nparams, dtype=torch.float32)
+
+        def put(name, arr):
+            s = self.sections[name]
+            host[s.offset:s.offset + s.numel] = torch.tensor(np.asarray(arr), dtype=torch.float32).reshape(-1)
+
+        put("init_w", sp.init_w); put("init_b", sp.init_b)
+        put("WF", np.stack([l.wf for l in sp.layers])); put("BF", np.stack([l.bf for l in sp.layers]))
+        put("WR", np.stack([l.wr for l in sp.layers])); put("BR", np.stack([l.br for l in sp.layers]))
+        put("WS", np.stack([l.ws for l in sp.layers])); put("BS", np.stack([l.bs for l in sp.layers]))
+        if self.E:
+            put("WC", np.stack([l.wc for l in sp.layers])); put("BC", np.stack([l.bc for l in sp.layers]))
+        put("head_w1", sp.head_w1); put("head_b1", sp.head_b1)
+        w2 = np.zeros((self.S, self.Cp)); w2[:, :self.C] = sp.head_w2
+        b2 = np.zeros(self.Cp); b2[:self.C] = sp.head_b2
+        put("head_w2", w2); put("head_b2", b2)
+        self.params.copy_(host)
+        self.adam_m.zero_(); self.adam_v.zero_(); self.adam_step.zero_()
+        self.repack()
+
+    def named_tensors(self, buf: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        """Oracle-style names (l{i}.wf ...) -> views of `buf` (params by default)."""
+        out = {"init_w": self.view("init_w", buf), "init_b": self.view("init_b", buf)}
+        for i in range(self.L):
+            out[f"l{i}.wf"] = self.view("WF", buf)[i]; out[f"l{i}.bf"] = self.view("BF", buf)[i]
+            out[f"l{i}.wr"] = self.view("WR", buf)[i]; out[f"l{i}.br"] = self.view("BR", buf)[i]
+            out[f"l{i}.ws"] = self.view("WS", buf)[i]; out[f"l{i}.bs"] = self.view("BS", buf)[i]
+            if self.E:
+                out[f"l{i}.wc"] = self.view("WC", buf)[i]; out[f"l{i}.bc"] = self.view("BC", buf)[i]
+        out["head_w1"] = self.view("head_w1", buf); out["head_b1"] = self.view("head_b1", buf)
+        out["head_w2"] = self.view("head_w2", buf)[:, :self.C]; out["head_b2"] = self.view("head_b2", buf)[:self.C]
+        return out
+
+    def tf_variables(self, scope: str, decoder: bool) -> Dict[str, torch.Tensor]:
+        """Reference variable names -> tensors in TF shapes, for checkpoint interchange."""
+        per = 3 if decoder else 2
+
+        def cname(j):
+            return "conv1d" if j == 0 else "conv1d_%d" % j
+
+        n = self.named_tensors()
+        out = {f"{scope}/causal_conv_Kernel": n["init_w"], f"{scope}/causal_conv_Bias": n["init_b"].view(1, 1, -1)}
+        for i in range(self.L):
+            nm = f"dilated_conv_{i}"
+            out[f"{scope}/{nm}_filter/{nm}_Kernel"] = n[f"l{i}.wf"]
+            out[f"{scope}/{nm}_filter/{nm}_Bias"] = n[f"l{i}.bf"].view(1, 1, -1)
+            out[f"{scope}/{nm}_gate/{nm}_Kernel"] = self.dead_gate["WG"][i]
+            out[f"{scope}/{nm}_gate/{nm}_Bias"] = self.dead_gate["BG"][i].view(1, 1, -1)
+            j = per * i
+            if decoder:
+                out[f"{scope}/{cname(j)}/kernel"] = n[f"l{i}.wc"].unsqueeze(0)
+                out[f"{scope}/{cname(j)}/bias"] = n[f"l{i}.bc"]
+                j += 1
+            out[f"{scope}/{cname(j)}/kernel"] = n[f"l{i}.wr"].unsqueeze(0)
+            out[f"{scope}/{cname(j)}/bias"] = n[f"l{i}.br"]
+            out[f"{scope}/{cname(j + 1)}/kernel"] = n[f"l{i}.ws"].unsqueeze(0)
+            out[f"{scope}/{cname(j + 1)}/bias"] = n[f"l{i}.bs"]
+        out[f"{scope}/{cname(per * self.L)}/kernel"] = n["head_w1"].unsqueeze(0)
+        out[f"{scope}/{cname(per * self.L)}/bias"] = n["head_b1"]
+        out[f"{scope}/{cname(per * self.L + 1)}/kernel"] = n["head_w2"].unsqueeze(0)
+        out[f"{scope}/{cname(per * self.L + 1)}/bias"] = n["head_b2"]
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    # MFMA weight images
+    # ------------------------------------------------------------------------------------------
+    def _build_packing(self):
+        L, R, S, Kw, Cp, E, Ep = self.L, self.R, self.S, self.Kw, self.Cp, self.E, self.Ep
+        sec = self.sections
+        pk = K.Packer(self.dev)
+        self.o_conv, self.o_res, self.o_convT, self.o_resT, self.o_skipT = [], [], [], [], []
+        for l in range(L):
+            self.o_conv.append(P.pack_conv(pk, sec["WF"].offset + l * Kw * R * R, Kw, R))
+            self.o_res.append(P.pack_res(pk, sec["WR"].offset + l * R * R, R))
+            self.o_convT.append(P.pack_conv_T(pk, sec["WF"].offset + l * Kw * R * R, Kw, R))
+            self.o_resT.append(P.pack_linear_T(pk, sec["WR"].offset + l * R * R, R, R, R, perm=True))
+            self.o_skipT.append(P.pack_linear_T(pk, sec["WS"].offset + l * R * S, R, S, R))
+        # all skip 1x1s as one image: rows = skip channel, k = layer*R + n
+        self.o_skip = pk.reserve(S // 32, L * R // 16)
+        for l in range(L):
+            P.fill_linear(pk, self.o_skip, sec["WS"].offset + l * R * S, R, S, S // 32, L * R // 16,
+                          ks_offset=l * R // 16, ks_count=R // 16)
+        self.o_w1 = P.pack_linear(pk, sec["head_w1"].offset, S, S, S)
+        self.o_w2 = P.pack_linear(pk, sec["head_w2"].offset, S, Cp, Cp)
+        self.o_w1T = P.pack_linear_T(pk, sec["head_w1"].offset, S, S, S)
+        self.o_w2T = P.pack_linear_T(pk, sec["head_w2"].offset, S, Cp, S)
+        if E:
+            # conditioning 1x1 of every layer as one [Ep] -> [L*R] product (model.py:180)
+            self.o_wc = pk.reserve(L * R // 32, Ep // 16)
+            for l in range(L):
+                P.fill_linear(pk, self.o_wc + l * (R // 32) * (Ep // 16) * 512, sec["WC"].offset + l * E * R, E, R,
+                              R // 32, Ep // 16)
+        pk.finalize()
+        self.packer = pk
+        self.packed = torch.zeros(max(pk.total, 1), dtype=self.dt, device=self.dev)
+
+    def wptr(self, off: int) -> int:
+        return self.packed.data_ptr() + off * self.packed.element_size()
+
+    def repack(self):
+        self.packer.gather(self.params, self.packed)
+
+    # ------------------------------------------------------------------------------------------
+    # buffers
+    # ------------------------------------------------------------------------------------------
+    def _alloc_buffers(self):
+        B, T, N, L, R, S, Cp = self.B, self.T, self.N, self.L, self.R, self.S, self.Cp
+        z = lambda *s, dt=self.dt: torch.zeros(s, dtype=dt, device=self.dev)
+        self.audio = z(B, T, dt=torch.float32)
+        self.targets = torch.zeros(N, dtype=torch.int32, device=self.dev)
+        self.xs = z(L + 1, B, T, R)
+        self.zs = z(L, B, T, R)
+        self.dfs = z(L, B, T, R)
+        self.gs = z(L + 1, B, T, R)   # gs[L] is never written: the last dense output is unused
+        self.r0 = z(N, S); self.r1 = z(N, S); self.da1 = z(N, S); self.dtotal = z(N, S)
+        self.dlogits = z(N, Cp)
+        self.bs_sum = z(S, dt=torch.float32)
+        self.loss_parts = z((N + 31) // 32, dt=torch.float32)
+        self.loss = z(1, dt=torch.float32)
+        self.nslabs = K.wgrad_slabs(N)
+        big = max(L * R * S, S * S, S * Cp, L * self.Kw * R * R)
+        self.wg_parts = z(self.nslabs * big, dt=torch.float32)
+        self.wg_bparts = z(self.nslabs * max(L * S, Cp), dt=torch.float32)
+        from . import _lib
+        self.ic_ws = z(int(_lib.load().srwn_init_conv_wgrad_partials(B, T, R, self.Kw)), dt=torch.float32)
+        if self.E:
+            self.cond_in = z(B * self.frames, self.Ep)
+            self.cond_all = z(B * self.frames, L * R)      # cb of every layer, [B*frames, L*R]
+            self.dcb = z(L, B * self.frames, R)
+            self.nslabs_c = K.wgrad_slabs(B * self.frames)
+            self.wgc_parts = z(self.nslabs_c * L * self.Ep * R, dt=torch.float32)
+            self.wgc_bparts = z(self.nslabs_c * L * R, dt=torch.float32)
+            self.wc_grad_pad = z(L, self.Ep, R, dt=torch.float32)
+
+    # ------------------------------------------------------------------------------------------
+    # forward
+    # ------------------------------------------------------------------------------------------
+    def set_inputs(self, audio: torch.Tensor, targets: Optional[torch.Tensor] = None,
+                   cond: Optional[torch.Tensor] = None):
+        self.audio.copy_(audio.reshape(self.B, self.T))
+        if targets is not None:
+            self.targets.copy_(targets.reshape(self.N))
+        if self.E:
+            if cond is None:
+                raise ValueError("this stack was built with conditioning; pass cond [B, frames, cond_channels]")
+            self.cond_in.zero_()
+            self.cond_in[:, :self.E].copy_(cond.reshape(self.B * self.frames, self.E))
+
+    def forward(self, want_logits: bool = False, with_loss: bool = True) -> Optional[torch.Tensor]:
+        """Runs the stack on the staged inputs; leaves loss in self.loss and dlogits for backward.
+        Returns fp32 per-time-step logits [B,T,C] when want_logits."""
+        B, T, N, L, R, S = self.B, self.T, self.N, self.L, self.R, self.S
+        es = self.packed.element_size()
+        v = self.view
+        # input conv (model.py:40 / 172-173); RightShift folded into the tap offset
+        K.causal_conv1d_fwd(self.audio.view(B, T, 1), v("init_w"), v("init_b"), 1,
+                            1 if self.cfg.shift_input else 0, out=self.xs[0])
+        if self.E:
+            K.pw_linear(self.cond_in.data_ptr(), self.Ep, 0, self.Ep, self.Ep, self.wptr(self.o_wc),
+                        v("BC").reshape(-1), self.cond_all, L * R, L * R, B * self.frames)
+        for l in range(L):
+            self._layer_fwd(l, self.cond_all if self.E else None)   # layer l reads columns [l*R, (l+1)*R)
+        K.reduce_partials(v("BS").reshape(-1), L, S, 1, True, 1.0, self.bs_sum.data_ptr(), 0)
+        K.pw_linear(self.zs.data_ptr(), R, N * R, R, L * R, self.wptr(self.o_skip), self.bs_sum, self.r0, S, S, N,
+                    pro=K.PRO_GATE, epi=K.EPI_RELU)                                   # model.py:50-51
+        K.pw_linear(self.r0.data_ptr(), S, 0, S, S, self.wptr(self.o_w1), v("head_b1"), self.r1, S, S, N,
+                    epi=K.EPI_RELU)                                                   # model.py:53-54
+        logits = None
+        if want_logits:
+            logits = torch.empty((N, self.C), dtype=torch.float32, device=self.dev)
+        K.head_softmax_ce(self.r1, self.wptr(self.o_w2), v("head_b2"), self.targets, self.loss_parts, self.dlogits,
+                          logits, self.Cp, self.C, 1.0 / N)                            # model.py:56 + softmax CE
+        if with_loss:
+            K.reduce_loss(self.loss_parts, self.loss_parts.numel(), 1.0 / N, self.loss)
+        return None if logits is None else logits.view(B, T, self.C)
+
+    def _layer_fwd(self, l: int, cond_all: Optional[torch.Tensor]):
+        v = self.view
+        cond3 = None if cond_all is None else cond_all.view(self.B, self.frames, self.L * self.R)
+        K.residual_layer_fwd(self.xs[l], cond3, self.wptr(self.o_conv[l]), self.wptr(self.o_res[l]), v("BF")[l],
+                             v("BR")[l], self.xs[l + 1], self.zs[l], self.Kw, self.dil[l], self.cfg.pool_stride,
+                             cond_channel_offset=l * self.R)
+
+    # ------------------------------------------------------------------------------------------
+    # backward
+    # ------------------------------------------------------------------------------------------
+    def backward(self):
+        B, T, N, L, R, S, Cp, Kw = self.B, self.T, self.N, self.L, self.R, self.S, self.Cp, self.Kw
+        g = self.grads
+        gp = g.data_ptr()
+        sec = self.sections
+        ns = self.nslabs
+        dt = self.dt
+        es = self.xs.element_size()
+        # ---- head data gradients (relu masks against the saved activations)
+        K.pw_linear(self.dlogits.data_ptr(), Cp, 0, Cp, Cp, self.wptr(self.o_w2T), None, self.da1, S, S, N,
+                    aux=self.r1, epi=K.EPI_MASK)
+        K.pw_linear(self.da1.data_ptr(), S, 0, S, S, self.wptr(self.o_w1T), None, self.dtotal, S, S, N,
+                    aux=self.r0, epi=K.EPI_MASK)
+        # ---- residual stack, top down
+        for l in range(L - 1, -1, -1):
+            has_up = l < L - 1
+            g_in = self.gs[l + 2] if (has_up and l + 2 < L) else None
+            K.residual_layer_bwd(g_in, self.dfs[l + 1] if has_up else None,
+                                 self.wptr(self.o_convT[l + 1]) if has_up else None,
+                                 self.gs[l + 1] if has_up else None,
+                                 self.wptr(self.o_resT[l]) if has_up else None, self.wptr(self.o_skipT[l]),
+                                 self.dtotal, self.zs[l], self.dfs[l], B, T, R, S, Kw,
+                                 self.dil[l + 1] if has_up else 1, has_up, True, dt)
+        K.residual_layer_bwd(self.gs[1] if L > 1 else None, self.dfs[0], self.wptr(self.o_convT[0]), self.gs[0],
+                             None, None, None, None, None, B, T, R, S, Kw, self.dil[0], True, False, dt)
+        # ---- weight gradients
+        NR = N * R
+        xs_p, zs_p, dfs_p, gs_p = self.xs.data_ptr(), self.zs.data_ptr(), self.dfs.data_ptr(), self.gs.data_ptr()
+        for k in range(Kw):                                                          # dilated conv taps
+            shifts = [(Kw - 1 - k) * d for d in self.dil]
+            last = k == Kw - 1
+            ckw = {}
+            if self.E:   # the conv input is the conditioned x + cb (model.py:183)
+                ckw = dict(cond_ptr=self.cond_all.data_ptr(), cond_batch_stride=R, cond_frames=self.frames,
+                           pool_stride=self.cfg.pool_stride, cond_row_stride=L * R)
+            K.wgrad(xs_p, NR, R, dfs_p, NR, R, shifts, L, self.wg_parts, self.wg_bparts if last else None, N, T, ns,
+                    dt, **ckw)
+            K.reduce_partials(self.wg_parts, ns, R * R, L, True, 1.0, gp + 4 * (sec["WF"].offset + k * R * R),
+                              Kw * R * R)
+            if last:
+                K.reduce_partials(self.wg_bparts, ns, R, L, True, 1.0, gp + 4 * sec["BF"].offset, R)
+        K.wgrad(zs_p, NR, R, gs_p + NR * es, NR, R, None, L, self.wg_parts, self.wg_bparts, N, T, ns, dt,
+                pro=K.PRO_GATE)                                                       # 1x1 residual
+        K.reduce_partials(self.wg_parts, ns, R * R, L, True, SQRT_HALF, gp + 4 * sec["WR"].offset, R * R)
+        K.reduce_partials(self.wg_bparts, ns, R, L, True, SQRT_HALF, gp + 4 * sec["BR"].offset, R)
+        K.wgrad(zs_p, NR, R, self.dtotal.data_ptr(), 0, S, None, L, self.wg_parts, self.wg_bparts, N, T, ns, dt,
+                pro=K.PRO_GATE)                                                       # 1x1 skip
+        K.reduce_partials(self.wg_parts, ns, R * S, L, True, 1.0, gp + 4 * sec["WS"].offset, R * S)
+        K.reduce_partials(self.wg_bparts, ns, S, L, True, 1.0, gp + 4 * sec["BS"].offset, S)
+        K.wgrad(self.r0.data_ptr(), 0, S, self.da1.data_ptr(), 0, S, None, 1, self.wg_parts, self.wg_bparts, N, T, ns,
+                dt)                                                                   # head 1x1 (S->S)
+        K.reduce_partials(self.wg_parts, ns, S * S, 1, True, 1.0, gp + 4 * sec["head_w1"].offset, 0)
+        K.reduce_partials(self.wg_bparts, ns, S, 1, True, 1.0, gp + 4 * sec["head_b1"].offset, 0)
+        K.wgrad(self.r1.data_ptr(), 0, S, self.dlogits.data_ptr(), 0, Cp, None, 1, self.wg_parts, self.wg_bparts, N, T,
+                ns, dt)                                                               # last 1x1 (S->C)
+        K.reduce_partials(self.wg_parts, ns, S * Cp, 1, True, 1.0, gp + 4 * sec["head_w2"].offset, 0)
+        K.reduce_partials(self.wg_bparts, ns, Cp, 1, True, 1.0, gp + 4 * sec["head_b2"].offset, 0)
+        K.init_conv_wgrad(self.audio, self.gs[0], self.view("init_w", g).reshape(-1), self.view("init_b", g), Kw,
+                          1 if self.cfg.shift_input else 0, self.ic_ws)
+        if self.E:
+            # conditioning 1x1 (model.py:180): dcb_l = adjoint of the NN upsample applied to G_l
+            rows_c, Ep, E = B * self.frames, self.Ep, self.E
+            for l in range(L):
+                from ._lib import call
+                call("srwn_frame_sum", self.gs[l].data_ptr(), self.dcb[l].data_ptr(), B, T, R, self.frames,
+                     self.cfg.pool_stride, K.abi_dtype(dt), torch.cuda.current_stream().cuda_stream)
+            K.wgrad(self.cond_in.data_ptr(), 0, Ep, self.dcb.data_ptr(), rows_c * R, R, None, L, self.wgc_parts,
+                    self.wgc_bparts, rows_c, self.frames, self.nslabs_c, dt)
+            if Ep == E:
+                K.reduce_partials(self.wgc_parts, self.nslabs_c, Ep * R, L, True, 1.0, gp + 4 * sec["WC"].offset, E * R)
+            else:
+                K.reduce_partials(self.wgc_parts, self.nslabs_c, Ep * R, L, True, 1.0, self.wc_grad_pad.data_ptr(),
+                                  Ep * R)
+                self.view("WC", g).copy_(self.wc_grad_pad[:, :E, :])
+            K.reduce_partials(self.wgc_bparts, self.nslabs_c, R, L, True, 1.0, gp + 4 * sec["BC"].offset, R)
+
+    # ------------------------------------------------------------------------------------------
+    # update
+    # ------------------------------------------------------------------------------------------
+    def allreduce_grads(self):
+        """Data parallel: sum the flat gradient over ranks (RCCL over xGMI); Adam divides by world."""
+        if self.world > 1:
+            torch.distributed.all_reduce(self.grads, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+
+    def optimizer_step(self):
+        K.adam_step(self.params, self.grads, self.adam_m, self.adam_v, self.adam_step, self.cfg.learning_rate,
+                    grad_scale=1.0 / self.world)
+        self.repack()
+
+    def train_step(self) -> torch.Tensor:
+        """fwd + bwd + (all-reduce) + Adam on the staged inputs; returns the device loss scalar."""
+        self.forward()
+        self.backward()
+        self.allreduce_grads()
+        self.optimizer_step()
+        return self.loss

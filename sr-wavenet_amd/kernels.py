@@ -105,7 +105,8 @@ class Packer:
 # generic causal conv (ops.py:6-20) and the input conv's weight gradient
 # ----------------------------------------------------------------------------------------------
 def causal_conv1d_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], dilation: int = 1,
-                      shift: int = 0, out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+                      shift: int = 0, out_dtype: torch.dtype = torch.float32,
+                      out: Optional[torch.Tensor] = None) -> torch.Tensor:
     B, T, Cin = x.shape
     K, Cin2, Cout = w.shape
     if Cin != Cin2:
@@ -113,9 +114,13 @@ def causal_conv1d_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Ten
     px = _chk(x, "x", torch.float32)
     pw = _chk(w, "w", torch.float32)
     pb = _opt(bias, "bias", torch.float32, (Cout,))
-    y = torch.empty((B, T, Cout), dtype=out_dtype, device=x.device)
+    if out is None:
+        y = torch.empty((B, T, Cout), dtype=out_dtype, device=x.device)
+    else:
+        y = out
+        _chk(y, "out", None, (B, T, Cout))
     call("srwn_causal_conv1d_fwd", px, pw, pb, y.data_ptr(), B, T, Cin, Cout, K, int(dilation), int(shift),
-         abi_dtype(out_dtype), _stream())
+         abi_dtype(y.dtype), _stream())
     return y
 
 
@@ -141,23 +146,27 @@ def init_conv_wgrad(audio: torch.Tensor, g: torch.Tensor, gw: torch.Tensor, gb: 
 # ----------------------------------------------------------------------------------------------
 def residual_layer_fwd(x: torch.Tensor, cond: Optional[torch.Tensor], wconv_ptr: int, wres_ptr: int,
                        bias_f: torch.Tensor, bias_r: torch.Tensor, h_out: torch.Tensor, z_out: torch.Tensor, K: int,
-                       dilation: int, pool_stride: int = 1):
+                       dilation: int, pool_stride: int = 1, cond_channel_offset: int = 0):
+    """cond: [B, frames, >=R] tensor; the layer reads channels [cond_channel_offset, +R) of every frame row."""
     B, T, R = x.shape
     px = _chk(x, "x")
     dt = abi_dtype(x.dtype)
-    frames = 1
+    frames, cstride = 1, R
     pc = None
     if cond is not None:
-        frames = cond.shape[1]
-        pc = _chk(cond, "cond", x.dtype, (B, frames, R))
+        _chk(cond, "cond", x.dtype)
+        if cond.dim() != 3 or cond.shape[0] != B or cond.shape[2] < cond_channel_offset + R:
+            raise ValueError("cond: shape %s for B=%d R=%d offset=%d" % (tuple(cond.shape), B, R, cond_channel_offset))
+        frames, cstride = cond.shape[1], cond.shape[2]
         if frames * pool_stride < T:
             raise ValueError("cond: %d frames x pool %d < T=%d" % (frames, pool_stride, T))
+        pc = cond.data_ptr() + cond_channel_offset * cond.element_size()
     pbf = _chk(bias_f, "bias_f", torch.float32, (R,))
     pbr = _chk(bias_r, "bias_r", torch.float32, (R,))
     ph = _chk(h_out, "h_out", x.dtype, (B, T, R))
     pz = _chk(z_out, "z_out", x.dtype, (B, T, R))
     call("srwn_residual_layer_fwd", px, pc, wconv_ptr, wres_ptr, pbf, pbr, ph, pz, B, T, R, K, int(dilation),
-         frames, int(pool_stride), dt, _stream())
+         frames, int(pool_stride), int(cstride), dt, _stream())
 
 
 # ----------------------------------------------------------------------------------------------
@@ -237,7 +246,7 @@ def wgrad_slabs(rows: int) -> int:
 def wgrad(in_ptr: int, in_batch_stride: int, cin: int, dout_ptr: int, dout_batch_stride: int, cout: int,
           shifts: Optional[List[int]], nbatch: int, partials: torch.Tensor, bias_partials: Optional[torch.Tensor],
           rows: int, T: int, nslabs: int, dtype: torch.dtype, pro: int = PRO_NONE, cond_ptr: Optional[int] = None,
-          cond_batch_stride: int = 0, cond_frames: int = 1, pool_stride: int = 1):
+          cond_batch_stride: int = 0, cond_frames: int = 1, pool_stride: int = 1, cond_row_stride: int = 0):
     """Raw pointers for in/dout (they index stacks of per-layer tensors); partials are checked for size."""
     import ctypes as C
     pp = _chk(partials, "partials", torch.float32)
@@ -254,7 +263,8 @@ def wgrad(in_ptr: int, in_batch_stride: int, cin: int, dout_ptr: int, dout_batch
             raise ValueError("wgrad: len(shifts) != nbatch")
         sh = (C.c_int32 * nbatch)(*[int(s) for s in shifts])
     call("srwn_wgrad", in_ptr, int(in_batch_stride), int(cin), dout_ptr, int(dout_batch_stride), int(cout), cond_ptr,
-         int(cond_batch_stride), int(cond_frames), int(pool_stride), sh, int(nbatch), pp, pb, int(rows), int(T),
+         int(cond_batch_stride), int(cond_frames), int(pool_stride), int(cond_row_stride or cin), sh, int(nbatch), pp,
+         pb, int(rows), int(T),
          int(nslabs), int(pro), abi_dtype(dtype), _stream())
 
 

@@ -1,0 +1,169 @@
+"""GPU parity of the whole stack (forward logits, loss, every gradient, one Adam step) vs the oracle.
+
+fp32 mode must meet the north-star tolerance (1e-3 relative); bf16 mode is checked loosely (it
+rounds every stored activation to 8 significant bits)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import wavenet_np as O
+from tests._pkg import sub
+from tests.test_gpu_kernels import DEV, dev, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(sp, B, T, R, S, C, dt, shift=True, E=0, pool=1, lr=1e-3):
+    EG = sub("engine")
+    cfg = EG.StackConfig(dilations=list(sp.dilations), dilation_channels=R, skip_channels=S, output_channels=C,
+                         cond_channels=E, pool_stride=pool, shift_input=shift, dtype=dt, learning_rate=lr)
+    eng = EG.WaveNetEngine(cfg, B, T, DEV)
+    eng.load_oracle_params(sp)
+    return eng
+
+
+def _bwd_oracle_on_engine_forward(eng, sp, cond=None, pool=1):
+    """bf16 mode: relu masks flip where an activation is within rounding of zero, which changes single
+    gradient entries by O(1) and says nothing about the backward kernels.  So the backward is judged
+    given the forward: the oracle's backward runs on the engine's own saved activations."""
+    f = lambda t: t.double().cpu().numpy()
+    B, T, L = eng.B, eng.T, eng.L
+    layers = []
+    for l in range(L):
+        x = f(eng.xs[l])
+        if cond is not None:
+            cb = f(eng.cond_all).reshape(B, eng.frames, L, eng.R)[:, :, l, :]
+            x = x + np.repeat(cb, pool, axis=1)
+        z = f(eng.zs[l]); sg = 1 / (1 + np.exp(-z))
+        layers.append(dict(x=x, z=z, s=sg, c=z * sg, g=None))
+    x0 = f(eng.audio)[:, :, None]
+    if eng.cfg.shift_input:
+        x0 = O.right_shift(x0)
+    r0 = f(eng.r0).reshape(B, T, -1); r1 = f(eng.r1).reshape(B, T, -1)
+    cache = dict(x0=x0, layers=layers, total=r0, r0=r0, a1=r1, r1=r1)
+    dlog = f(eng.dlogits).reshape(B, T, -1)[:, :, :eng.C]
+    grads, _ = O.stack_backward(sp, cache, dlog, cond=cond, pool_stride=pool)
+    return grads
+
+
+def _check_grads(eng, grads, tol, with_cond=False):
+    gn = dict(O.flatten_named(grads, with_cond))
+    got = eng.named_tensors(eng.grads)
+    worst = 0.0
+    for n, ref in gn.items():
+        g = got[n].float().cpu().numpy()
+        scale = np.abs(ref).max()
+        if scale < 1e-12:
+            assert np.abs(g).max() < 1e-6, n
+            continue
+        if tol > 1e-2:   # bf16: relu-mask flips make single entries noisy; judge the tensor in L2
+            e = np.linalg.norm(g - ref) / np.linalg.norm(ref)
+        else:
+            e = np.abs(g - ref).max() / scale
+        worst = max(worst, e)
+        assert e < tol, (n, e)
+    return worst
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-3), (torch.bfloat16, 5e-2)])
+def test_stack_small_golden(golden_dir, dt, tol):
+    g = np.load(os.path.join(golden_dir, "stack_small.npz"))
+    dil = g["dilations"].tolist(); L = len(dil)
+    layers = [O.LayerParams(g[f"p.l{i}.wf"], g[f"p.l{i}.bf"], None, None, g[f"p.l{i}.wr"], g[f"p.l{i}.br"],
+                            g[f"p.l{i}.ws"], g[f"p.l{i}.bs"]) for i in range(L)]
+    sp = O.StackParams(g["p.init_w"], g["p.init_b"], layers, g["p.head_w1"], g["p.head_b1"], g["p.head_w2"],
+                       g["p.head_b2"], tuple(dil))
+    B, T = g["audio"].shape
+    eng = _engine(sp, B, T, 32, 32, 32, dt)
+    eng.set_inputs(dev(g["audio"]), dev(g["codes"], torch.int32))
+    logits = eng.forward(want_logits=True)
+    assert rel_err(logits.cpu().numpy(), g["logits"]) < tol
+    assert abs(float(eng.loss.item()) - float(g["loss"])) < tol * float(g["loss"])
+    eng.backward()
+    got = eng.named_tensors(eng.grads)
+    for k in g.files:
+        if k.startswith("g."):
+            ref = g[k]; scale = np.abs(ref).max()
+            d = got[k[2:]].cpu().numpy() - ref
+            e = (np.linalg.norm(d) / max(np.linalg.norm(ref), 1e-30)) if tol > 1e-2 else np.abs(d).max() / max(scale, 1e-12)
+            assert e < tol or scale < 1e-12, (k, e)
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-3), (torch.bfloat16, 5e-2)])
+@pytest.mark.parametrize("R,S,C,B,T", [(64, 256, 256, 2, 300), (32, 128, 30, 1, 515), (64, 64, 100, 3, 64)])
+def test_stack_forward_backward_adam(dt, tol, R, S, C, B, T):
+    dil = [1, 2, 4, 8, 16, 32, 64, 1, 2]
+    sp = O.init_stack_params(21, dil, 2, R, S, C, bias_scale=0.05)
+    rng = np.random.default_rng(T)
+    audio = O.synthetic_audio(B, T, seed=2).astype(np.float64)
+    codes = rng.integers(0, C, (B, T))
+    logits, cache = O.stack_forward(sp, audio, shift_input=True)
+    loss = O.softmax_ce_per_timestep(logits, codes)
+    grads, _ = O.stack_backward(sp, cache, O.dlogits_per_timestep(logits, codes))
+    eng = _engine(sp, B, T, R, S, C, dt, lr=1e-2)
+    eng.set_inputs(dev(audio), dev(codes, torch.int32))
+    lg = eng.forward(want_logits=True)
+    assert rel_err(lg.cpu().numpy(), logits) < tol
+    assert abs(float(eng.loss.item()) - loss) < tol * loss
+    eng.backward()
+    if dt == torch.bfloat16:
+        grads = _bwd_oracle_on_engine_forward(eng, sp)
+    _check_grads(eng, grads, tol)
+    # one TF-Adam step on the oracle's gradients vs the engine's update
+    before = {k: v.clone() for k, v in eng.named_tensors().items()}
+    eng.optimizer_step()
+    gn = dict(O.flatten_named(grads, False)); pn = dict(O.flatten_named(sp, False))
+    after = eng.named_tensors()
+    for n in gn:
+        th, _, _ = O.adam_step_tf(pn[n], gn[n], np.zeros_like(gn[n]), np.zeros_like(gn[n]), 1, lr=1e-2)
+        if dt == torch.float32:
+            # first Adam step moves by ~lr*sign(g): compare only where the gradient is not ~0
+            mask = np.abs(gn[n]) > 1e-6 * max(np.abs(gn[n]).max(), 1e-30)
+            d = np.abs(after[n].cpu().numpy() - th)[mask]
+            assert d.size == 0 or d.max() < 2e-4, (n, d.max())
+    # training loop sanity: the loss goes down
+    l0 = float(eng.loss.item())
+    for _ in range(5):
+        eng.train_step()
+    assert float(eng.loss.item()) < l0
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-3), (torch.bfloat16, 5e-2)])
+@pytest.mark.parametrize("E", [16, 20])
+def test_stack_conditioned_decoder(dt, tol, E):
+    """createDecoder variant (model.py:158-196): RightShift + per-layer conditioning add."""
+    dil = [1, 2, 4, 8, 16, 1, 2, 4]
+    R, S, C, B, T, pool = 64, 128, 64, 2, 256, 32
+    sp = O.init_stack_params(5, dil, 2, R, S, C, cond_channels=E, bias_scale=0.05)
+    rng = np.random.default_rng(0)
+    audio = O.synthetic_audio(B, T, seed=4).astype(np.float64)
+    codes = rng.integers(0, C, (B, T))
+    cond = rng.standard_normal((B, T // pool, E))
+    logits, cache = O.stack_forward(sp, audio, shift_input=True, cond=cond, pool_stride=pool)
+    loss = O.softmax_ce_per_timestep(logits, codes)
+    grads, _ = O.stack_backward(sp, cache, O.dlogits_per_timestep(logits, codes), cond=cond, pool_stride=pool)
+    eng = _engine(sp, B, T, R, S, C, dt, E=E, pool=pool)
+    eng.set_inputs(dev(audio), dev(codes, torch.int32), dev(cond))
+    lg = eng.forward(want_logits=True)
+    assert rel_err(lg.cpu().numpy(), logits) < tol
+    assert abs(float(eng.loss.item()) - loss) < tol * loss
+    eng.backward()
+    if dt == torch.bfloat16:
+        grads = _bwd_oracle_on_engine_forward(eng, sp, cond=cond, pool=pool)
+    _check_grads(eng, grads, tol, with_cond=True)
+
+
+def test_deterministic_and_tf_names():
+    dil = [1, 2, 4]
+    sp = O.init_stack_params(1, dil, 2, 64, 64, 32)
+    eng = _engine(sp, 2, 128, 64, 64, 32, torch.bfloat16)
+    a = dev(O.synthetic_audio(2, 128)); c = dev(np.zeros((2, 128)), torch.int32)
+    eng.set_inputs(a, c); eng.forward(); eng.backward(); g1 = eng.grads.clone(); l1 = eng.loss.clone()
+    eng.set_inputs(a, c); eng.forward(); eng.backward()
+    assert torch.equal(g1, eng.grads) and torch.equal(l1, eng.loss)   # slab reductions are order-fixed
+    names = eng.tf_variables("WaveNet", decoder=False)
+    assert names["WaveNet/conv1d_3/kernel"].shape == (1, 64, 64)
+    assert names["WaveNet/dilated_conv_2_gate/dilated_conv_2_Kernel"].shape == (2, 64, 64)
+    assert names["WaveNet/conv1d_7/kernel"].shape == (1, 64, 32)
