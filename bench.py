@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Headline benchmark: audio samples/s (fwd+bwd+Adam) of the 30-layer teacher WaveNet on MI355X.
+
+Contract: ``python bench.py --gpus N --steps K --warmup W`` (N>1 under torch.distributed.run, one
+rank per GPU over RCCL).  W untimed warm-up steps, then exactly K steps timed between
+barrier + torch.cuda.synchronize() on both sides; MAX over ranks; rank 0 prints ONE JSON line.
+
+Workload = BASELINE.json configs[1]: 3x[1..512] dilations, 64 residual / 256 skip channels,
+256-way mu-law softmax, batch 8 x 16000 samples per GPU, bf16 MFMA with fp32 accumulation,
+synthetic 16 kHz input, random-init weights.  Data parallel = weak scaling.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_HBM_GBS = 8000.0
+
+
+def algorithmic_flops(N, L, R, S, C, Kw):
+    """forward flop/sample of the reference-faithful graph; x3 for fwd+bwd."""
+    per_layer = 2 * Kw * R * R + 2 * R * R + 2 * R * S
+    fwd = 2 * Kw * R + L * per_layer + 2 * S * S + 2 * S * C
+    return dict(per_sample_fwd=fwd, per_sample_fwd_bwd=3 * fwd, per_step=3 * fwd * N)
+
+
+def cpu_baseline(dil, R, S, C, threads, seconds_budget=20.0):
+    """Times the CPU restatement (oracle ii) on a bounded sample of the same workload."""
+    from oracle import wavenet_np as O
+    from oracle import wavenet_torch as OT
+    B, T = 2, 4000
+    sp = O.init_stack_params(0, dil, 2, R, S, C)
+    audio = O.synthetic_audio(B, T, seed=0)
+    codes = O.mu_law_encode(audio, C).astype(np.int64)
+    r = OT.cpu_train_steps(sp, audio, codes, steps=1, threads=threads)
+    steps = int(max(1, min(20, seconds_budget / max(r["seconds"], 1e-3))))
+    if steps > 1:
+        r = OT.cpu_train_steps(sp, audio, codes, steps=steps, threads=threads)
+    return {"value": r["samples_per_s"], "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": "CPU restatement of the reference graph (oracle/wavenet_torch.py; TensorFlow unavailable), "
+                      "fp32 fwd+bwd+Adam, %d steps of batch %dx%d samples (same 30-layer stack)" % (r["steps"], B, T)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--length", type=int, default=16000)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("SRWN_GRAPH", "1")))
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    EG = importlib.import_module("sr-wavenet_amd.engine")
+    KN = importlib.import_module("sr-wavenet_amd.kernels")
+    from oracle import wavenet_np as O   # only for the synthetic input generator + cpu_baseline
+
+    dil = [1, 2, 4, 8, 16, 32, 64, 128, 256, 512] * 3
+    R, S, C, Kw = 64, 256, 256, 2
+    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    cfg = EG.StackConfig(dilations=dil, dilation_channels=R, skip_channels=S, output_channels=C, shift_input=True,
+                         dtype=dt, learning_rate=1e-3)
+    eng = EG.WaveNetEngine(cfg, args.batch, args.length, "cuda", seed=0)   # same init on every rank
+    B, T, N, L = eng.B, eng.T, eng.N, eng.L
+    audio = torch.tensor(O.synthetic_audio(B, T, seed=rank), device="cuda")
+    codes = KN.mu_law_encode(audio, C)
+    eng.set_inputs(audio, codes)
+
+    use_graph = bool(args.graph) and world == 1
+    step_fn = eng.train_step
+    graph = None
+    for _ in range(max(args.warmup, 1 if use_graph else 0)):
+        eng.train_step()
+    if use_graph:
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                eng.train_step()
+            step_fn = graph.replay
+        except Exception as e:   # fall back to eager launches, and say so
+            print("hipGraph capture failed (%s); running eager" % e, file=sys.stderr)
+            graph, use_graph, step_fn = None, False, eng.train_step
+        torch.cuda.synchronize()
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step_fn()
+    sync()
+    dt_s = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt_s], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt_s = float(tt.item())
+    loss = float(eng.loss.item())
+
+    # ---- roofline of the dominant kernel: HIP events on the launch stream, eager launches
+    eng.timing = True
+    eng.spans.clear()
+    for _ in range(min(args.steps, 5)):
+        eng.train_step()
+    torch.cuda.synchronize()
+    eng.timing = False
+    spans = {k: float(np.mean([s.elapsed_time(e) for s, e in v])) for k, v in eng.spans.items()}   # ms
+    fl = algorithmic_flops(N, L, R, S, C, Kw)
+    kflops = {"skip_sum": 2.0 * N * L * R * S, "wgrad_skip": 2.0 * N * L * R * S,
+              "fwd_layers": 2.0 * N * L * (Kw * R * R + R * R), "bwd_layers": 2.0 * N * L * (Kw * R * R + R * R + R * S),
+              "head_1x1": 2.0 * N * S * S, "head_softmax_ce": 2.0 * N * S * C, "bwd_head": 2.0 * N * (S * C + S * S)}
+    dom = max((k for k in spans if k in ("skip_sum", "wgrad_skip")), key=lambda k: spans[k])
+    achieved = kflops[dom] / (spans[dom] * 1e-3) / 1e12
+    roofline = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                "whole_step_frac": fl["per_step"] / (dt_s / args.steps) / 1e12 / PEAK_BF16_TFLOPS,
+                "spans_ms": spans}
+
+    if rank == 0:
+        out = {
+            "metric": "audio samples/sec (fwd+bwd) 30-layer teacher WaveNet",
+            "value": world * N * args.steps / dt_s, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt_s / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "30-layer teacher WaveNet (3x[1..512] dilations, 64 res / 256 skip ch, 256-way "
+                                   "mu-law softmax), fwd+bwd+Adam, batch %dx%d samples per GPU" % (B, T),
+                       "global_batch": world * B, "seq_len": T, "parallelism": "dp%d" % world,
+                       "launch": "hipGraph" if use_graph else "eager", "final_loss": loss},
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(dil, R, S, C, threads=min(os.cpu_count() or 1, 16))
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -52,6 +52,26 @@ class Section:
         self.numel = int(np.prod(shape))
 
 
+class _Span:
+    """Optional HIP-event bracket around a group of launches on the current stream (bench.py roofline)."""
+
+    def __init__(self, eng, name):
+        self.eng, self.name = eng, name
+
+    def __enter__(self):
+        if self.eng.timing:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.eng.timing:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.eng.spans.setdefault(self.name, []).append((self.s, e))
+        return False
+
+
 class WaveNetEngine:
     def __init__(self, cfg: StackConfig, batch: int, length: int, device="cuda", seed: int = 0,
                  process_group=None):
@@ -66,6 +86,8 @@ class WaveNetEngine:
         if cfg.cond_channels and (length % cfg.pool_stride):
             raise ValueError("length %d is not a multiple of pool_stride %d" % (length, cfg.pool_stride))
         self.cfg = cfg
+        self.timing = False
+        self.spans: Dict[str, list] = {}
         self.B, self.T = int(batch), int(length)
         self.N = self.B * self.T
         self.L = len(cfg.dilations)
@@ -317,18 +339,22 @@ class WaveNetEngine:
         if self.E:
             K.pw_linear(self.cond_in.data_ptr(), self.Ep, 0, self.Ep, self.Ep, self.wptr(self.o_wc),
                         v("BC").reshape(-1), self.cond_all, L * R, L * R, B * self.frames)
-        for l in range(L):
-            self._layer_fwd(l, self.cond_all if self.E else None)   # layer l reads columns [l*R, (l+1)*R)
+        with _Span(self, "fwd_layers"):
+            for l in range(L):
+                self._layer_fwd(l, self.cond_all if self.E else None)   # layer l reads columns [l*R, (l+1)*R)
         K.reduce_partials(v("BS").reshape(-1), L, S, 1, True, 1.0, self.bs_sum.data_ptr(), 0)
-        K.pw_linear(self.zs.data_ptr(), R, N * R, R, L * R, self.wptr(self.o_skip), self.bs_sum, self.r0, S, S, N,
-                    pro=K.PRO_GATE, epi=K.EPI_RELU)                                   # model.py:50-51
-        K.pw_linear(self.r0.data_ptr(), S, 0, S, S, self.wptr(self.o_w1), v("head_b1"), self.r1, S, S, N,
-                    epi=K.EPI_RELU)                                                   # model.py:53-54
+        with _Span(self, "skip_sum"):
+            K.pw_linear(self.zs.data_ptr(), R, N * R, R, L * R, self.wptr(self.o_skip), self.bs_sum, self.r0, S, S,
+                        N, pro=K.PRO_GATE, epi=K.EPI_RELU)                            # model.py:50-51
+        with _Span(self, "head_1x1"):
+            K.pw_linear(self.r0.data_ptr(), S, 0, S, S, self.wptr(self.o_w1), v("head_b1"), self.r1, S, S, N,
+                        epi=K.EPI_RELU)                                               # model.py:53-54
         logits = None
         if want_logits:
             logits = torch.empty((N, self.C), dtype=torch.float32, device=self.dev)
-        K.head_softmax_ce(self.r1, self.wptr(self.o_w2), v("head_b2"), self.targets, self.loss_parts, self.dlogits,
-                          logits, self.Cp, self.C, 1.0 / N)                            # model.py:56 + softmax CE
+        with _Span(self, "head_softmax_ce"):
+            K.head_softmax_ce(self.r1, self.wptr(self.o_w2), v("head_b2"), self.targets, self.loss_parts,
+                              self.dlogits, logits, self.Cp, self.C, 1.0 / N)          # model.py:56 + softmax CE
         if with_loss:
             K.reduce_loss(self.loss_parts, self.loss_parts.numel(), 1.0 / N, self.loss)
         return None if logits is None else logits.view(B, T, self.C)
@@ -352,11 +378,13 @@ class WaveNetEngine:
         dt = self.dt
         es = self.xs.element_size()
         # ---- head data gradients (relu masks against the saved activations)
-        K.pw_linear(self.dlogits.data_ptr(), Cp, 0, Cp, Cp, self.wptr(self.o_w2T), None, self.da1, S, S, N,
-                    aux=self.r1, epi=K.EPI_MASK)
-        K.pw_linear(self.da1.data_ptr(), S, 0, S, S, self.wptr(self.o_w1T), None, self.dtotal, S, S, N,
-                    aux=self.r0, epi=K.EPI_MASK)
+        with _Span(self, "bwd_head"):
+            K.pw_linear(self.dlogits.data_ptr(), Cp, 0, Cp, Cp, self.wptr(self.o_w2T), None, self.da1, S, S, N,
+                        aux=self.r1, epi=K.EPI_MASK)
+            K.pw_linear(self.da1.data_ptr(), S, 0, S, S, self.wptr(self.o_w1T), None, self.dtotal, S, S, N,
+                        aux=self.r0, epi=K.EPI_MASK)
         # ---- residual stack, top down
+        span = _Span(self, "bwd_layers").__enter__()
         for l in range(L - 1, -1, -1):
             has_up = l < L - 1
             g_in = self.gs[l + 2] if (has_up and l + 2 < L) else None
@@ -368,6 +396,7 @@ class WaveNetEngine:
                                  self.dil[l + 1] if has_up else 1, has_up, True, dt)
         K.residual_layer_bwd(self.gs[1] if L > 1 else None, self.dfs[0], self.wptr(self.o_convT[0]), self.gs[0],
                              None, None, None, None, None, B, T, R, S, Kw, self.dil[0], True, False, dt)
+        span.__exit__()
         # ---- weight gradients
         NR = N * R
         xs_p, zs_p, dfs_p, gs_p = self.xs.data_ptr(), self.zs.data_ptr(), self.dfs.data_ptr(), self.gs.data_ptr()
@@ -388,8 +417,9 @@ class WaveNetEngine:
                 pro=K.PRO_GATE)                                                       # 1x1 residual
         K.reduce_partials(self.wg_parts, ns, R * R, L, True, SQRT_HALF, gp + 4 * sec["WR"].offset, R * R)
         K.reduce_partials(self.wg_bparts, ns, R, L, True, SQRT_HALF, gp + 4 * sec["BR"].offset, R)
-        K.wgrad(zs_p, NR, R, self.dtotal.data_ptr(), 0, S, None, L, self.wg_parts, self.wg_bparts, N, T, ns, dt,
-                pro=K.PRO_GATE)                                                       # 1x1 skip
+        with _Span(self, "wgrad_skip"):
+            K.wgrad(zs_p, NR, R, self.dtotal.data_ptr(), 0, S, None, L, self.wg_parts, self.wg_bparts, N, T, ns, dt,
+                    pro=K.PRO_GATE)                                                   # 1x1 skip
         K.reduce_partials(self.wg_parts, ns, R * S, L, True, 1.0, gp + 4 * sec["WS"].offset, R * S)
         K.reduce_partials(self.wg_bparts, ns, S, L, True, 1.0, gp + 4 * sec["BS"].offset, S)
         K.wgrad(self.r0.data_ptr(), 0, S, self.da1.data_ptr(), 0, S, None, 1, self.wg_parts, self.wg_bparts, N, T, ns,
