@@ -157,6 +157,22 @@ int srwn_frame_sum(const void* g, void* out, int32_t B, int32_t T, int32_t C, in
 int srwn_adam_step(float* params, const float* grads, float* m, float* v, int64_t n, int64_t* step, float lr,
                    float beta1, float beta2, float eps, float grad_scale, void* stream);
 
+/* ---- time-pooled classifier head of class WaveNet (model.py:56-60; loss model.py:24-29).
+ * tf.nn.pool AVG over the whole clip commutes with the last 1x1, so:
+ *   srwn_time_mean   : out[b,c] = mean_t x[b,t,c]   (partials: B*srwn_time_mean_slabs(T)*C floats)
+ *   srwn_pooled_head : logits = mean @ w2 + b2; probs = softmax (model.py:60); with labels also
+ *                      loss = mean_b softmax_cross_entropy_with_logits_v2 (soft labels, model.py:29),
+ *                      gw2/gb2 (written, [S,ldw]/[ldw]) and dmean = d loss / d mean  [B,S]
+ *   srwn_bcast_mask  : da1[b,t,s] = (r1[b,t,s] > 0) ? dmean[b,s]*scale : 0  (scale = 1/T) */
+int32_t srwn_time_mean_slabs(int32_t T);
+int srwn_time_mean(const void* x, float* partials, float* out, int32_t B, int32_t T, int32_t C, int32_t dtype,
+                   void* stream);
+int srwn_pooled_head(const float* mean, const float* w2, const float* b2, const float* labels, float* probs,
+                     float* loss, float* gw2, float* gb2, float* dmean, int32_t B, int32_t S, int32_t C,
+                     int32_t ldw, void* stream);
+int srwn_bcast_mask(const float* dmean, const void* r1, void* out, int32_t B, int32_t T, int32_t S, float scale,
+                    int32_t dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

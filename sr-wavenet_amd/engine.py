@@ -40,6 +40,8 @@ class StackConfig:
     cond_channels: int = 0        # channels of encoding_w_condition (model.py:161-167); 0 = no conditioning
     pool_stride: int = 1
     shift_input: bool = False     # RightShift(truth) teacher forcing (model.py:172)
+    head_mode: str = "per_timestep"  # "per_timestep": mu-law softmax CE per sample (model.py:100-112);
+    #                                  "pooled": class WaveNet's clip-level softmax (model.py:56-60, 24-29)
     dtype: torch.dtype = torch.bfloat16
     learning_rate: float = 1e-3
 
@@ -83,6 +85,8 @@ class WaveNetEngine:
             raise NotImplementedError("skip_channels must be a multiple of 32")
         if cfg.output_channels < 1 or cfg.output_channels > 256:
             raise NotImplementedError("output_channels must be in [1, 256]")
+        if cfg.head_mode not in ("per_timestep", "pooled"):
+            raise ValueError("head_mode %r" % cfg.head_mode)
         if cfg.cond_channels and (length % cfg.pool_stride):
             raise ValueError("length %d is not a multiple of pool_stride %d" % (length, cfg.pool_stride))
         self.cfg = cfg
@@ -298,6 +302,14 @@ class WaveNetEngine:
         self.bs_sum = z(S, dt=torch.float32)
         self.loss_parts = z((N + 31) // 32, dt=torch.float32)
         self.loss = z(1, dt=torch.float32)
+        self.pooled = self.cfg.head_mode == "pooled"
+        if self.pooled:
+            from . import _lib as _l
+            self.labels = z(B, self.C, dt=torch.float32)
+            self.probs = z(B, self.C, dt=torch.float32)
+            self.mean_r1 = z(B, S, dt=torch.float32)
+            self.dmean = z(B, S, dt=torch.float32)
+            self.tm_parts = z(B * int(_l.load().srwn_time_mean_slabs(T)) * S, dt=torch.float32)
         self.nslabs = K.wgrad_slabs(N)
         big = max(L * R * S, S * S, S * Cp, L * self.Kw * R * R)
         self.wg_parts = z(self.nslabs * big, dt=torch.float32)
@@ -320,7 +332,10 @@ class WaveNetEngine:
                    cond: Optional[torch.Tensor] = None):
         self.audio.copy_(audio.reshape(self.B, self.T))
         if targets is not None:
-            self.targets.copy_(targets.reshape(self.N))
+            if self.pooled:
+                self.labels.copy_(targets.reshape(self.B, self.C))
+            else:
+                self.targets.copy_(targets.reshape(self.N))
         if self.E:
             if cond is None:
                 raise ValueError("this stack was built with conditioning; pass cond [B, frames, cond_channels]")
@@ -349,6 +364,8 @@ class WaveNetEngine:
         with _Span(self, "head_1x1"):
             K.pw_linear(self.r0.data_ptr(), S, 0, S, S, self.wptr(self.o_w1), v("head_b1"), self.r1, S, S, N,
                         epi=K.EPI_RELU)                                               # model.py:53-54
+        if self.pooled:
+            return self._forward_pooled_head(with_loss)
         logits = None
         if want_logits:
             logits = torch.empty((N, self.C), dtype=torch.float32, device=self.dev)
@@ -358,6 +375,21 @@ class WaveNetEngine:
         if with_loss:
             K.reduce_loss(self.loss_parts, self.loss_parts.numel(), 1.0 / N, self.loss)
         return None if logits is None else logits.view(B, T, self.C)
+
+    def _forward_pooled_head(self, with_labels: bool):
+        """model.py:56-60: last 1x1, average pool over the clip, softmax -- computed as the 1x1 of the
+        time-mean (the pool commutes with it); leaves probs [B,C], loss, and dmean for backward."""
+        from ._lib import call
+        st = torch.cuda.current_stream().cuda_stream
+        B, T, S, C, Cp = self.B, self.T, self.S, self.C, self.Cp
+        g = self.grads
+        call("srwn_time_mean", self.r1.data_ptr(), self.tm_parts.data_ptr(), self.mean_r1.data_ptr(), B, T, S,
+             K.abi_dtype(self.dt), st)
+        call("srwn_pooled_head", self.mean_r1.data_ptr(), self.view("head_w2").data_ptr(),
+             self.view("head_b2").data_ptr(), self.labels.data_ptr() if with_labels else None, self.probs.data_ptr(),
+             self.loss.data_ptr(), self.view("head_w2", g).data_ptr(), self.view("head_b2", g).data_ptr(),
+             self.dmean.data_ptr(), B, S, C, Cp, st)
+        return None
 
     def _layer_fwd(self, l: int, cond_all: Optional[torch.Tensor]):
         v = self.view
@@ -379,8 +411,13 @@ class WaveNetEngine:
         es = self.xs.element_size()
         # ---- head data gradients (relu masks against the saved activations)
         with _Span(self, "bwd_head"):
-            K.pw_linear(self.dlogits.data_ptr(), Cp, 0, Cp, Cp, self.wptr(self.o_w2T), None, self.da1, S, S, N,
-                        aux=self.r1, epi=K.EPI_MASK)
+            if self.pooled:
+                from ._lib import call
+                call("srwn_bcast_mask", self.dmean.data_ptr(), self.r1.data_ptr(), self.da1.data_ptr(), B, T, S,
+                     1.0 / T, K.abi_dtype(dt), torch.cuda.current_stream().cuda_stream)
+            else:
+                K.pw_linear(self.dlogits.data_ptr(), Cp, 0, Cp, Cp, self.wptr(self.o_w2T), None, self.da1, S, S, N,
+                            aux=self.r1, epi=K.EPI_MASK)
             K.pw_linear(self.da1.data_ptr(), S, 0, S, S, self.wptr(self.o_w1T), None, self.dtotal, S, S, N,
                         aux=self.r0, epi=K.EPI_MASK)
         # ---- residual stack, top down
@@ -426,10 +463,11 @@ class WaveNetEngine:
                 dt)                                                                   # head 1x1 (S->S)
         K.reduce_partials(self.wg_parts, ns, S * S, 1, True, 1.0, gp + 4 * sec["head_w1"].offset, 0)
         K.reduce_partials(self.wg_bparts, ns, S, 1, True, 1.0, gp + 4 * sec["head_b1"].offset, 0)
-        K.wgrad(self.r1.data_ptr(), 0, S, self.dlogits.data_ptr(), 0, Cp, None, 1, self.wg_parts, self.wg_bparts, N, T,
-                ns, dt)                                                               # last 1x1 (S->C)
-        K.reduce_partials(self.wg_parts, ns, S * Cp, 1, True, 1.0, gp + 4 * sec["head_w2"].offset, 0)
-        K.reduce_partials(self.wg_bparts, ns, Cp, 1, True, 1.0, gp + 4 * sec["head_b2"].offset, 0)
+        if not self.pooled:   # (the pooled head wrote its own kernel/bias gradients in forward)
+            K.wgrad(self.r1.data_ptr(), 0, S, self.dlogits.data_ptr(), 0, Cp, None, 1, self.wg_parts, self.wg_bparts,
+                    N, T, ns, dt)                                                     # last 1x1 (S->C)
+            K.reduce_partials(self.wg_parts, ns, S * Cp, 1, True, 1.0, gp + 4 * sec["head_w2"].offset, 0)
+            K.reduce_partials(self.wg_bparts, ns, Cp, 1, True, 1.0, gp + 4 * sec["head_b2"].offset, 0)
         K.init_conv_wgrad(self.audio, self.gs[0], self.view("init_w", g).reshape(-1), self.view("init_b", g), Kw,
                           1 if self.cfg.shift_input else 0, self.ic_ws)
         if self.E:

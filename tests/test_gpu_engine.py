@@ -155,6 +155,36 @@ def test_stack_conditioned_decoder(dt, tol, E):
     _check_grads(eng, grads, tol, with_cond=True)
 
 
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-3), (torch.bfloat16, 5e-2)])
+@pytest.mark.parametrize("C", [30, 256])
+def test_pooled_classifier_head(dt, tol, C):
+    """class WaveNet (model.py:8-72): clip-level softmax, soft labels, mean CE."""
+    EG = sub("engine")
+    dil = [1, 2, 4, 8, 16, 32]
+    R, S, B, T = 32, 128, 3, 200
+    sp = O.init_stack_params(8, dil, 2, R, S, C, bias_scale=0.05)
+    rng = np.random.default_rng(C)
+    audio = O.synthetic_audio(B, T, seed=6).astype(np.float64)
+    tg = rng.random((B, C)); tg /= tg.sum(-1, keepdims=True)
+    logits, cache = O.stack_forward(sp, audio)
+    loss = O.wavenet_loss_pooled(logits, tg)
+    grads, _ = O.stack_backward(sp, cache, O.dlogits_pooled(logits, tg))
+    cfg = EG.StackConfig(dilations=dil, dilation_channels=R, skip_channels=S, output_channels=C, dtype=dt,
+                         head_mode="pooled")
+    eng = EG.WaveNetEngine(cfg, B, T, DEV); eng.load_oracle_params(sp)
+    eng.set_inputs(dev(audio), dev(tg))
+    eng.forward()
+    assert rel_err(eng.probs.cpu().numpy(), O.wavenet_predict(sp, audio)[:, 0, :]) < tol
+    assert abs(float(eng.loss.item()) - loss) < tol * loss
+    eng.backward()
+    if dt == torch.float32:
+        _check_grads(eng, grads, tol)
+    l0 = float(eng.loss.item())
+    for _ in range(5):
+        eng.train_step()
+    assert float(eng.loss.item()) < l0
+
+
 def test_deterministic_and_tf_names():
     dil = [1, 2, 4]
     sp = O.init_stack_params(1, dil, 2, 64, 64, 32)
