@@ -76,7 +76,7 @@ class _Span:
 
 class WaveNetEngine:
     def __init__(self, cfg: StackConfig, batch: int, length: int, device="cuda", seed: int = 0,
-                 process_group=None):
+                 process_group=None, share_from: Optional["WaveNetEngine"] = None):
         if cfg.filter_width != 2:
             raise NotImplementedError("filter_width %d: only 2 is built (reference default, model.py:9)" % cfg.filter_width)
         if cfg.dilation_channels not in (32, 64):
@@ -108,8 +108,16 @@ class WaveNetEngine:
         self.world = 1
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
-        self._build_params(seed)
-        self._build_packing()
+        if share_from is None:
+            self._build_params(seed)
+            self._build_packing()
+        else:   # another (batch, length) view of the same model: parameters, moments, images are shared
+            for a in ("sections", "nparams", "params", "grads", "adam_m", "adam_v", "adam_step", "dead_gate",
+                      "packer", "packed", "o_conv", "o_res", "o_convT", "o_resT", "o_skipT", "o_skip", "o_w1", "o_w2",
+                      "o_w1T", "o_w2T"):
+                setattr(self, a, getattr(share_from, a))
+            if self.E:
+                self.o_wc = share_from.o_wc
         self._alloc_buffers()
         self.repack()
 

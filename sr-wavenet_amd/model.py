@@ -1,0 +1,240 @@
+"""Host-side mirror of the reference's model classes (``/root/reference/model.py``) on the MI355X engine.
+
+Same constructor and method signatures, NumPy in / NumPy out like the reference's ``sess.run``
+wrappers, but no TensorFlow: the graph body is the fixed kernel sequence of ``engine.WaveNetEngine``.
+
+* ``WaveNet``            -- model.py:8-72 (clip-level softmax classifier), complete.
+* ``WaveNetTeacher``     -- the 30-layer mu-law softmax teacher BASELINE.json names (decoder stack of
+                            model.py:158-196 with the 256-way softmax head the reference carries at
+                            model.py:100-112); this is the benchmark path.
+* ``WaveNetAutoEncoder`` / ``ParallelWaveNet`` -- signatures kept; their mixture-of-logistics head,
+                            encoder and IAF flows are SURVEY §8(f) "next" rows and raise until built.
+"""
+from __future__ import annotations
+
+import os
+import time
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import kernels as K
+from .engine import StackConfig, WaveNetEngine
+
+
+def _default_dtype():
+    return torch.float32 if os.environ.get("SRWN_DTYPE", "bf16").lower() in ("f32", "fp32", "float32") else torch.bfloat16
+
+
+class _EngineOwner:
+    """Builds one engine per (batch, length) seen, all sharing the same parameters."""
+
+    def _setup(self, cfg: StackConfig, seed: int):
+        if not torch.cuda.is_available():
+            raise RuntimeError("sr-wavenet_amd needs an MI355X (HIP) device; there is no CPU fallback")
+        self._cfg = cfg
+        self._seed = seed
+        self._engines: Dict[tuple, WaveNetEngine] = {}
+        self._primary: Optional[WaveNetEngine] = None
+        self.last_checkpoint_time = time.time()
+
+    def _engine(self, B: int, T: int) -> WaveNetEngine:
+        key = (int(B), int(T))
+        eng = self._engines.get(key)
+        if eng is None:
+            eng = WaveNetEngine(self._cfg, B, T, "cuda", seed=self._seed, share_from=self._primary)
+            if self._primary is None:
+                self._primary = eng
+            self._engines[key] = eng
+        return eng
+
+    @property
+    def network_params(self):
+        """Reference name -> tensor (the analogue of tf.get_collection(TRAINABLE_VARIABLES, scope))."""
+        if self._primary is None:
+            self._engine(1, self._default_length)
+        return self._primary.tf_variables(self._scope, decoder=self._decoder_names)
+
+    # --- checkpointing with the reference's cadence semantics (model.py:217-239) -------------------
+    def save(self, logdir, global_step, force=False):
+        if force or time.time() - self.last_checkpoint_time > 60:
+            os.makedirs(logdir, exist_ok=True)
+            state = {k: v.detach().cpu().clone() for k, v in self.network_params.items()}
+            torch.save(state, os.path.join(logdir, "model.ckpt-%d.pt" % int(global_step)))
+            with open(os.path.join(logdir, "checkpoint"), "w") as f:
+                f.write('model_checkpoint_path: "model.ckpt-%d.pt"\n' % int(global_step))
+            self.last_checkpoint_time = time.time()
+            return True
+        return False
+
+    def load(self, logdir):
+        if logdir is None or not os.path.exists(os.path.join(logdir, "checkpoint")):
+            return None
+        line = open(os.path.join(logdir, "checkpoint")).readline()
+        path = os.path.join(logdir, line.split('"')[1])
+        if not os.path.exists(path):
+            print("Could not find checkpoint at %s" % path)
+            return False
+        state = torch.load(path, weights_only=True)
+        for k, dst in self.network_params.items():
+            dst.copy_(state[k].to(dst.device).reshape(dst.shape))
+        self._primary.repack()
+        print("Restoring previous session")
+        return True
+
+
+class WaveNet(_EngineOwner):
+    """model.py:8-72.  ``train(inputs[B,T], targets[B,output_size]) -> loss``; ``predict -> [B,1,C]``."""
+
+    def __init__(self, input_size, output_size, dilations, filter_width=2, dilation_channels=32, skip_channels=256,
+                 output_channels=256, name="WaveNet", learning_rate=0.001, dtype=None, seed=0):
+        self.input_size = input_size
+        self.output_size = output_size
+        self.dilations = dilations
+        self.filter_width = filter_width
+        self.dilation_channels = dilation_channels
+        self.skip_channels = skip_channels
+        self.output_channels = output_channels
+        if output_size != output_channels:
+            # the reference's softmax CE (model.py:29) needs logits and labels of equal width
+            raise ValueError("output_size (%d) must equal output_channels (%d)" % (output_size, output_channels))
+        self._scope, self._decoder_names, self._default_length = name, False, int(input_size)
+        self._setup(StackConfig(dilations=list(dilations), filter_width=filter_width,
+                                dilation_channels=dilation_channels, skip_channels=skip_channels,
+                                output_channels=output_channels, shift_input=False, head_mode="pooled",
+                                dtype=dtype or _default_dtype(), learning_rate=learning_rate), seed)
+
+    def _stage(self, inputs, targets=None):
+        x = np.asarray(inputs, dtype=np.float32)
+        if x.ndim != 2:
+            raise ValueError("inputs must be [batch, samples]")
+        if x.shape[1] != self.input_size:
+            # tf.nn.pool window = input_size, VALID (model.py:58): other lengths would pool differently
+            raise ValueError("inputs have %d samples, the model was built for input_size=%d" % (x.shape[1], self.input_size))
+        eng = self._engine(x.shape[0], x.shape[1])
+        t = None
+        if targets is not None:
+            t = torch.as_tensor(np.asarray(targets, dtype=np.float32), device="cuda")
+            if tuple(t.shape) != (x.shape[0], self.output_size):
+                raise ValueError("targets must be [batch, %d]" % self.output_size)
+        eng.set_inputs(torch.as_tensor(x, device="cuda"), t)
+        return eng
+
+    def train(self, inputs, targets):
+        eng = self._stage(inputs, targets)
+        eng.train_step()
+        return np.float32(eng.loss.item())
+
+    def predict(self, inputs):
+        eng = self._stage(inputs)
+        eng.forward(with_loss=False)
+        return eng.probs.cpu().numpy()[:, None, :]
+
+
+class WaveNetTeacher(_EngineOwner):
+    """The mu-law softmax teacher of BASELINE.json configs[1-2]: ``createDecoder``'s stack
+    (model.py:158-196: RightShift teacher forcing, per-layer conditioning add) with a
+    ``quantization_channels``-way softmax over mu-law codes per sample (model.py:100-112).
+
+    ``train(inputs[B,T], encoding=None, conditions=None) -> loss`` (mean CE over B*T);
+    ``get_logits`` / ``predict_codes`` for evaluation.  ``encoding`` is [B, T/pool_stride, latent];
+    ``conditions`` [B, condition_size] is tiled over frames and concatenated (model.py:161-167).
+    """
+
+    def __init__(self, input_size, condition_size, dilations, filter_width=2, dilation_channels=32,
+                 skip_channels=256, quantization_channels=256, latent_channels=16, pool_stride=512,
+                 name="WaveNetTeacher", learning_rate=0.001, use_encoding=False, dtype=None, seed=0):
+        self.input_size = input_size
+        self.condition_size = condition_size
+        self.dilations = dilations
+        self.quantization_channels = quantization_channels
+        self.latent_channels = latent_channels
+        self.pool_stride = pool_stride
+        self.use_encoding = bool(use_encoding)
+        cond_ch = (latent_channels + condition_size) if self.use_encoding else 0
+        self._scope, self._decoder_names, self._default_length = name, bool(cond_ch), int(input_size)
+        self._setup(StackConfig(dilations=list(dilations), filter_width=filter_width,
+                                dilation_channels=dilation_channels, skip_channels=skip_channels,
+                                output_channels=quantization_channels, cond_channels=cond_ch,
+                                pool_stride=pool_stride if cond_ch else 1, shift_input=True,
+                                head_mode="per_timestep", dtype=dtype or _default_dtype(),
+                                learning_rate=learning_rate), seed)
+
+    def _stage(self, inputs, encoding=None, conditions=None):
+        x = torch.as_tensor(np.asarray(inputs, dtype=np.float32), device="cuda")
+        B, T = x.shape
+        eng = self._engine(B, T)
+        cond = None
+        if self.use_encoding:
+            if encoding is None:
+                raise ValueError("this teacher was built with use_encoding=True; pass encoding [B, T/pool, latent]")
+            e = torch.as_tensor(np.asarray(encoding, dtype=np.float32), device="cuda")
+            if self.condition_size > 0:
+                c = torch.as_tensor(np.asarray(conditions, dtype=np.float32), device="cuda")
+                e = torch.cat([e, c[:, None, :].expand(-1, e.shape[1], -1)], dim=2)   # model.py:162-165
+            cond = e.contiguous()
+        codes = K.mu_law_encode(x.contiguous(), self.quantization_channels)            # ops.py:82-93
+        eng.set_inputs(x, codes, cond)
+        return eng
+
+    def train(self, inputs, encoding=None, conditions=None):
+        eng = self._stage(inputs, encoding, conditions)
+        eng.train_step()
+        return np.float32(eng.loss.item())
+
+    def get_logits(self, inputs, encoding=None, conditions=None):
+        eng = self._stage(inputs, encoding, conditions)
+        return eng.forward(want_logits=True).cpu().numpy()
+
+    def loss(self, inputs, encoding=None, conditions=None):
+        eng = self._stage(inputs, encoding, conditions)
+        eng.forward()
+        return np.float32(eng.loss.item())
+
+
+class WaveNetAutoEncoder(object):
+    """model.py:75-285.  Constructor signature kept; the encoder (ResidualDilationLayerNC), the
+    mixture-of-logistics head and its sampler are SURVEY §8(f) rank-1 "next" rows, not built yet."""
+
+    def __init__(self, input_size, condition_size, num_mixtures, dilations, filter_width=2, encoder_channels=128,
+                 dilation_channels=32, skip_channels=256, latent_channels=16, pool_stride=512,
+                 name="WaveNetAutoEncoder", learning_rate=0.001):
+        raise NotImplementedError(
+            "WaveNetAutoEncoder (mixture-of-logistics teacher + encoder) is not built yet (SURVEY §8f rank 1); "
+            "use WaveNetTeacher for the mu-law softmax teacher on the same decoder stack")
+
+
+class ParallelWaveNet(object):
+    """model.py:290-656.  Constructor signature kept; IAF flows + distillation losses are SURVEY §8(f)
+    rank 1 ("next"), not built yet."""
+
+    def __init__(self, input_size, condition_size, dilations, teacher, num_flows=2, filter_width=2,
+                 dilation_channels=32, skip_channels=256, latent_channels=16, pool_stride=512,
+                 name="ParallelWaveNet", alpha=1.0, beta=1.0, gamma=1.0, learning_rate=0.001):
+        raise NotImplementedError("ParallelWaveNet (student flows) is not built yet (SURVEY §8f rank 1)")
+
+
+def smoke_check():
+    """One tiny fwd+bwd+Adam of the teacher on cuda:0, checked against the CPU oracle (graft smoke)."""
+    from oracle import wavenet_np as O   # checker only
+    dil = [1, 2, 4, 8]
+    B, T, R, S, C = 2, 256, 64, 64, 256
+    sp = O.init_stack_params(3, dil, 2, R, S, C, bias_scale=0.05)
+    audio = O.synthetic_audio(B, T, seed=1)
+    codes = O.mu_law_encode(audio, C)
+    logits, cache = O.stack_forward(sp, audio.astype(np.float64), shift_input=True)
+    ref_loss = O.softmax_ce_per_timestep(logits, codes)
+    m = WaveNetTeacher(T, 0, dil, dilation_channels=R, skip_channels=S, quantization_channels=C,
+                       dtype=torch.float32, learning_rate=1e-3)
+    eng = m._engine(B, T)
+    eng.load_oracle_params(sp)
+    got = m.get_logits(audio)
+    err = float(np.abs(got - logits).max() / np.abs(logits).max())
+    assert err < 1e-3, "forward parity %g" % err
+    l0 = float(m.loss(audio))
+    assert abs(l0 - ref_loss) < 1e-3 * ref_loss, (l0, ref_loss)
+    for _ in range(3):
+        l1 = float(m.train(audio))
+    assert l1 < l0 + 1e-3, (l0, l1)
+    print("smoke: forward rel err %.2e, loss %.4f (oracle %.4f) -> %.4f after 3 steps" % (err, l0, ref_loss, l1))

@@ -1,0 +1,124 @@
+"""GPU tests of the reference-shaped Python surface (model.py classes, ops.py functions)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import wavenet_np as O
+from tests._pkg import sub
+from tests.test_gpu_kernels import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def test_wavenet_class_train_predict():
+    """train.py:39,60,63 usage: WaveNet(num_samples, num_classes, dilations, ...); train; predict."""
+    M = sub("model")
+    T, C = 400, 30
+    dil = [1, 2, 4, 8, 16, 32]
+    net = M.WaveNet(T, C, dil, dilation_channels=32, skip_channels=128, output_channels=C, learning_rate=0.01,
+                    dtype=torch.float32)
+    rng = np.random.default_rng(0)
+    x = O.synthetic_audio(4, T, seed=0)
+    y = np.eye(C, dtype=np.float32)[rng.integers(0, C, 4)]
+    p0 = net.predict(x)
+    assert p0.shape == (4, 1, C) and np.allclose(p0.sum(-1), 1, atol=1e-4)
+    losses = [float(net.train(x, y)) for _ in range(15)]
+    assert losses[-1] < losses[0]
+    p1 = net.predict(x[:1])              # another batch size shares the same weights
+    assert p1.shape == (1, 1, C)
+    assert np.allclose(p1[0], net.predict(x)[0], atol=1e-4)
+    names = net.network_params
+    assert "WaveNet/causal_conv_Kernel" in names and "WaveNet/conv1d_%d/kernel" % (2 * len(dil) + 1) in names
+    with pytest.raises(ValueError):
+        net.predict(x[:, :100])
+
+
+def test_teacher_matches_oracle_and_checkpoint(tmp_path):
+    M = sub("model")
+    dil = [1, 2, 4, 8]
+    B, T, R, S, C = 2, 192, 64, 64, 256
+    sp = O.init_stack_params(3, dil, 2, R, S, C, bias_scale=0.05)
+    audio = O.synthetic_audio(B, T, seed=1)
+    m = M.WaveNetTeacher(T, 0, dil, dilation_channels=R, skip_channels=S, quantization_channels=C,
+                         dtype=torch.float32)
+    m._engine(B, T).load_oracle_params(sp)
+    logits, _ = O.stack_forward(sp, audio.astype(np.float64), shift_input=True)
+    assert rel_err(m.get_logits(audio), logits) < 1e-3
+    codes = O.mu_law_encode(audio, C)
+    assert abs(float(m.loss(audio)) - O.softmax_ce_per_timestep(logits, codes)) < 1e-3
+    assert m.save(str(tmp_path), 7, force=True) is True
+    assert m.save(str(tmp_path), 8) is False          # < 60 s since the last one (model.py:232)
+    l_before = float(m.loss(audio))
+    for _ in range(3):
+        m.train(audio)
+    assert float(m.loss(audio)) != l_before
+    assert m.load(str(tmp_path)) is True
+    assert abs(float(m.loss(audio)) - l_before) < 1e-5
+
+
+def test_teacher_with_encoding_and_conditions():
+    M = sub("model")
+    dil = [1, 2, 4, 8, 16]
+    B, T, pool, lat, cs = 2, 256, 64, 16, 16
+    m = M.WaveNetTeacher(T, cs, dil, dilation_channels=64, skip_channels=128, latent_channels=lat, pool_stride=pool,
+                         use_encoding=True, learning_rate=0.01)
+    rng = np.random.default_rng(0)
+    audio = O.synthetic_audio(B, T, seed=2)
+    enc = rng.standard_normal((B, T // pool, lat)).astype(np.float32)
+    cond = np.eye(cs, dtype=np.float32)[[1, 5]]
+    ls = [float(m.train(audio, enc, cond)) for _ in range(10)]
+    assert ls[-1] < ls[0]
+    assert "WaveNetTeacher/conv1d_%d/kernel" % (3 * len(dil) + 1) in m.network_params
+    with pytest.raises(ValueError):
+        m.train(audio)
+
+
+def test_unbuilt_classes_say_so():
+    M = sub("model")
+    with pytest.raises(NotImplementedError):
+        M.ParallelWaveNet(4096, 0, [1, 2], "teachers/x")
+    with pytest.raises(NotImplementedError):
+        M.WaveNetAutoEncoder(4096, 0, 5, [1, 2])
+
+
+def test_ops_surface(golden_dir):
+    ops = sub("ops")
+    g = json.load(open(os.path.join(golden_dir, "ops_selfcheck.json")))
+    x = np.array(g["x"], np.float32).reshape(1, -1, 1)
+    for c in g["causal"]:     # the reference's own __main__ calls, ops.py:243-252
+        y = ops._DilatedCausalConv1d(x, np.array(c["filt"], np.float32).reshape(c["shape"]), dilation_rate=c["d"])
+        assert np.array_equal(y.cpu().numpy()[0].T, np.array(c["out"], np.float32)), c["ref"]
+    assert ops.RightShift(x).cpu().numpy()[0, :, 0].tolist() == [0, 1, 2, 3, 4, 5, 6, 7]
+    e = np.arange(12, dtype=np.float32).reshape(1, 3, 4)
+    assert np.array_equal(ops.ResizeEmbeddingNearestNeighbor(e, 12).cpu().numpy(), np.repeat(e, 4, axis=1))
+    a = np.array(json.load(open(os.path.join(golden_dir, "mu_law.json")))["audio"], np.float32)
+    assert ops.mu_law_encode(a, 256).cpu().tolist() == [0, 0, 16, 98, 128, 157, 239, 255, 255]
+    rng = np.random.default_rng(0)
+    xin = rng.standard_normal((2, 50, 64)).astype(np.float32)
+    dense, skip = ops.ResidualDilationLayer(xin, 2, 64, 128, dilation_rate=4, name="t_layer")
+    V = ops.VARIABLES
+    lp = O.LayerParams(V["t_layer_filter/t_layer_Kernel"].cpu().numpy().astype(np.float64),
+                       V["t_layer_filter/t_layer_Bias"].cpu().numpy().reshape(-1).astype(np.float64), None, None,
+                       V["t_layer/residual/kernel"].cpu().numpy()[0].astype(np.float64),
+                       V["t_layer/residual/bias"].cpu().numpy().astype(np.float64),
+                       V["t_layer/skip/kernel"].cpu().numpy()[0].astype(np.float64),
+                       V["t_layer/skip/bias"].cpu().numpy().astype(np.float64))
+    d_ref, s_ref, _ = O.residual_dilation_layer(xin.astype(np.float64), lp, 4)
+    assert rel_err(dense.cpu().numpy(), d_ref) < 1e-3 and rel_err(skip.cpu().numpy(), s_ref) < 1e-3
+    assert "t_layer_gate/t_layer_Kernel" in V
+
+
+def test_dropin_shims_import():
+    d = os.path.join(os.path.dirname(sub("model").__file__), "dropin")
+    sys.path.insert(0, d)
+    try:
+        import importlib
+        m = importlib.import_module("model"); o = importlib.import_module("ops")
+        assert hasattr(m, "WaveNet") and hasattr(m, "ParallelWaveNet") and hasattr(o, "ResidualDilationLayer")
+    finally:
+        sys.path.remove(d)
+        sys.modules.pop("model", None); sys.modules.pop("ops", None)
