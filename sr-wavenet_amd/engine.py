@@ -24,6 +24,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
+from . import dp
 from . import kernels as K
 from . import packing as P
 
@@ -105,9 +106,7 @@ class WaveNetEngine:
         self.dev = torch.device(device)
         self.dt = cfg.dtype
         self.pg = process_group
-        self.world = 1
-        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
-            self.world = torch.distributed.get_world_size(process_group)
+        self.world = dp.world_size(process_group)
         if share_from is None:
             self._build_params(seed)
             self._build_packing()
@@ -500,8 +499,7 @@ class WaveNetEngine:
     # ------------------------------------------------------------------------------------------
     def allreduce_grads(self):
         """Data parallel: sum the flat gradient over ranks (RCCL over xGMI); Adam divides by world."""
-        if self.world > 1:
-            torch.distributed.all_reduce(self.grads, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+        dp.allreduce_sum_(self.grads, self.pg)
 
     def optimizer_step(self):
         K.adam_step(self.params, self.grads, self.adam_m, self.adam_v, self.adam_step, self.cfg.learning_rate,

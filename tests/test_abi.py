@@ -1,0 +1,68 @@
+"""CPU tests: the C-ABI library builds, loads and exports every symbol include/srwn.h declares;
+argument errors are reported without touching a GPU; the product has no CPU fallback."""
+import os
+import re
+
+import pytest
+
+from tests._pkg import ROOT, sub
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "srwn.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(srwn_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = sub("_lib")
+    if not os.path.exists(L.LIB_PATH):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("b", os.path.join(ROOT, "sr-wavenet_amd", "build.py"))
+        m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m); m.build()
+    lib = L.load()
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), "declared in srwn.h but not exported: " + n
+        assert n in L.SIGNATURES, "no ctypes signature for " + n
+    assert sorted(L.SIGNATURES) == names, "signature table and header differ"
+    assert lib.srwn_version() >= 100
+
+
+def test_argument_errors_do_not_need_a_gpu():
+    L = sub("_lib")
+    lib = L.load()
+    # empty work returns 0 before any launch
+    assert lib.srwn_mu_law_encode(None, None, 0, 256, None) == 0
+    assert lib.srwn_pw_linear(None, 0, 0, 16, 16, None, None, None, 0, 32, 32, 0, None, 0, 0, 0, 1, None) == 0
+    # null pointers / bad shapes / bad dtype -> negative codes + message, no launch
+    assert lib.srwn_mu_law_encode(None, None, 10, 256, None) == -3
+    assert b"null" in lib.srwn_last_error()
+    assert lib.srwn_residual_layer_fwd(1, None, 1, 1, 1, 1, 1, 1, 2, 64, 64, 3, 1, 1, 1, 64, 1, None) == -4   # K=3
+    assert lib.srwn_residual_layer_fwd(1, None, 1, 1, 1, 1, 1, 1, 2, 64, 48, 2, 1, 1, 1, 48, 1, None) == -4   # R=48
+    assert lib.srwn_residual_layer_fwd(1, None, 1, 1, 1, 1, 1, 1, 2, 64, 64, 2, 1, 1, 1, 64, 7, None) == -1   # dtype
+    assert lib.srwn_pw_linear(1, 8, 0, 8, 8, 1, None, 1, 32, 32, 32, 5, None, 0, 0, 0, 1, None) == -2          # Cin % 16
+    assert lib.srwn_wgrad(1, 0, 64, 1, 0, 64, None, 0, 1, 1, 64, None, 99, 1, None, 64, 64, 1, 0, 1, None) == -2
+    with pytest.raises(RuntimeError):
+        L.call("srwn_mu_law_decode", None, None, 5, 256, None)
+    assert lib.srwn_wgrad_slabs(128000) == 63 and lib.srwn_softmax_ce_partials(100) == 4
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    M = sub("model")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        M.WaveNet(64, 8, [1, 2], output_channels=8)
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "sr-wavenet_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            for line in src.splitlines():
+                if "oracle" in line and ("import" in line) and "smoke_check" not in src[:src.find(line)].split("def ")[-1]:
+                    raise AssertionError("%s imports the oracle outside smoke_check: %s" % (fn, line))
