@@ -322,9 +322,16 @@ extern "C" int srwn_pw_linear(const void* x, int64_t x_row_stride, int64_t x_chu
       cout_pad % 32 || cout_valid < 4 || cout_valid % 4 || cout_valid > cout_pad)
     return set_error(SRWN_E_SHAPE, "pw_linear: rows=%lld Cin=%d chunk=%d cout_pad=%d cout_valid=%d", (long long)rows,
                      Cin, chunk_len, cout_pad, cout_valid);
+  hipStream_t st = (hipStream_t)stream;
+  {
+    int rc = 0;
+    if (rowgemm_dispatch(x, x_row_stride, x_chunk_stride, chunk_len, Cin, wpack, bias, y, y_row_stride, cout_pad,
+                         cout_valid, rows, aux, aux_row_stride, nullptr, nullptr, nullptr, 0.0f, pro, epi, dtype, st,
+                         &rc))
+      return rc;
+  }
   PwArgs a{x, x_row_stride, x_chunk_stride, chunk_len, Cin / 16, wpack, bias, y, y_row_stride, cout_valid, rows, aux,
            aux_row_stride};
-  hipStream_t st = (hipStream_t)stream;
   const int tiles = cout_pad / 32;
   if (dtype == SRWN_BF16) {
     if (tiles % 4 == 0) return launch_pw<bf16_t, 4, 2>(a, cout_pad, pro, epi, st);
@@ -448,6 +455,13 @@ extern "C" int srwn_head_softmax_ce(const void* x, int64_t x_row_stride, int32_t
       cout_valid > cout_pad)
     return set_error(SRWN_E_SHAPE, "head_softmax_ce: rows=%lld Cin=%d cout_pad=%d cout_valid=%d (cout_pad <= 256)",
                      (long long)rows, Cin, cout_pad, cout_valid);
+  {
+    int rc = 0;
+    if (rowgemm_dispatch(x, x_row_stride, 0, Cin, Cin, wpack, bias, dlogits, cout_pad, cout_pad, cout_valid, rows,
+                         nullptr, 0, targets, loss_partials, logits_out, grad_scale, SRWN_PRO_NONE, 3, dtype,
+                         (hipStream_t)stream, &rc))
+      return rc;
+  }
   HeadArgs a{x, x_row_stride, Cin / 16, wpack, bias, targets, loss_partials, dlogits, logits_out, cout_valid, rows,
              grad_scale};
   const int64_t tiles = (rows + 31) / 32;

@@ -2,8 +2,16 @@
 #pragma once
 #include <cstdarg>
 #include <cstdio>
+#include <cstdint>
+#include <hip/hip_runtime.h>
 
 namespace srwn {
 int set_error(int code, const char* fmt, ...);  // records a thread-local message, returns code
 int check_launch(const char* what);             // hipGetLastError -> 0 or the hipError_t (message recorded)
+// srwn_gemm.hip: row-streaming GEMM for cout_pad == 256; returns 1 if it took the call (*rc = result)
+int rowgemm_dispatch(const void* x, int64_t x_row_stride, int64_t x_chunk_stride, int chunk_len, int Cin,
+                     const void* wpack, const float* bias, void* y, int64_t y_row_stride, int cout_pad,
+                     int cout_valid, int64_t rows, const void* aux, int64_t aux_row_stride, const int32_t* targets,
+                     float* loss_partials, float* logits_out, float grad_scale, int pro, int epi, int dtype,
+                     hipStream_t st, int* rc);
 }  // namespace srwn
