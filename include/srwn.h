@@ -173,6 +173,17 @@ int srwn_pooled_head(const float* mean, const float* w2, const float* b2, const 
 int srwn_bcast_mask(const float* dmean, const void* r1, void* out, int32_t B, int32_t T, int32_t S, float scale,
                     int32_t dtype, void* stream);
 
+/* ---- weight gradient of 256-wide products as ONE time-contraction GEMM (tf.gradients of ops.py:44,
+ * model.py:53,56 kernels):  partials[slab][m][n] = sum_{rows of slab} pro(A[row][m]) * D[row][n], n < 256.
+ * A is addressed in chunks of 64 channels: a + (m/64)*a_chunk_stride + row*a_row_stride + m%64
+ * (the [L,rows,64] stack of z for all skip 1x1s at once, or a [rows,256] tensor with chunk stride 64).
+ * bias_partials[slab][n] = column sums of D (may be NULL).  nslabs = srwn_wgrad256_slabs(rows, m_chunks);
+ * finish with srwn_reduce_partials. */
+int32_t srwn_wgrad256_slabs(int64_t rows, int32_t m_chunks);
+int srwn_wgrad256(const void* a, int64_t a_chunk_stride, int64_t a_row_stride, int32_t m_chunks, const void* d,
+                  int64_t d_row_stride, float* partials, float* bias_partials, int64_t rows, int32_t nslabs,
+                  int32_t pro, int32_t dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

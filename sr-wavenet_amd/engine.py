@@ -319,8 +319,13 @@ class WaveNetEngine:
             self.tm_parts = z(B * int(_l.load().srwn_time_mean_slabs(T)) * S, dt=torch.float32)
         self.nslabs = K.wgrad_slabs(N)
         big = max(L * R * S, S * S, S * Cp, L * self.Kw * R * R)
+        self.use_w256 = (S == 256 and R == 64)
+        if self.use_w256:
+            self.ns_skip = K.wgrad256_slabs(N, L)
+            self.ns_head = K.wgrad256_slabs(N, S // 64)
+            big = max(big, -(-max(self.ns_skip * L * R * S, self.ns_head * S * 256) // self.nslabs))
         self.wg_parts = z(self.nslabs * big, dt=torch.float32)
-        self.wg_bparts = z(self.nslabs * max(L * S, Cp), dt=torch.float32)
+        self.wg_bparts = z(max(self.nslabs * max(L * S, Cp), 256 * 256), dt=torch.float32)
         from . import _lib
         self.ic_ws = z(int(_lib.load().srwn_init_conv_wgrad_partials(B, T, R, self.Kw)), dt=torch.float32)
         if self.E:
@@ -461,16 +466,32 @@ class WaveNetEngine:
                 pro=K.PRO_GATE)                                                       # 1x1 residual
         K.reduce_partials(self.wg_parts, ns, R * R, L, True, SQRT_HALF, gp + 4 * sec["WR"].offset, R * R)
         K.reduce_partials(self.wg_bparts, ns, R, L, True, SQRT_HALF, gp + 4 * sec["BR"].offset, R)
-        with _Span(self, "wgrad_skip"):
-            K.wgrad(zs_p, NR, R, self.dtotal.data_ptr(), 0, S, None, L, self.wg_parts, self.wg_bparts, N, T, ns, dt,
-                    pro=K.PRO_GATE)                                                   # 1x1 skip
-        K.reduce_partials(self.wg_parts, ns, R * S, L, True, 1.0, gp + 4 * sec["WS"].offset, R * S)
-        K.reduce_partials(self.wg_bparts, ns, S, L, True, 1.0, gp + 4 * sec["BS"].offset, S)
-        K.wgrad(self.r0.data_ptr(), 0, S, self.da1.data_ptr(), 0, S, None, 1, self.wg_parts, self.wg_bparts, N, T, ns,
-                dt)                                                                   # head 1x1 (S->S)
-        K.reduce_partials(self.wg_parts, ns, S * S, 1, True, 1.0, gp + 4 * sec["head_w1"].offset, 0)
-        K.reduce_partials(self.wg_bparts, ns, S, 1, True, 1.0, gp + 4 * sec["head_b1"].offset, 0)
-        if not self.pooled:   # (the pooled head wrote its own kernel/bias gradients in forward)
+        if self.use_w256:
+            # every skip 1x1 at once: out[L*R, S] = c_all^T . dtotal (dtotal re-read once per 4 layers)
+            with _Span(self, "wgrad_skip"):
+                K.wgrad256(zs_p, NR, R, L, self.dtotal, self.wg_parts, self.wg_bparts, N, self.ns_skip,
+                           pro=K.PRO_GATE)
+            K.reduce_partials(self.wg_parts, self.ns_skip, L * R * S, 1, True, 1.0, gp + 4 * sec["WS"].offset, 0)
+            K.reduce_partials(self.wg_bparts, self.ns_skip, S, L, False, 1.0, gp + 4 * sec["BS"].offset, S)
+            K.wgrad256(self.r0.data_ptr(), 64, S, S // 64, self.da1, self.wg_parts, self.wg_bparts, N, self.ns_head)
+            K.reduce_partials(self.wg_parts, self.ns_head, S * S, 1, True, 1.0, gp + 4 * sec["head_w1"].offset, 0)
+            K.reduce_partials(self.wg_bparts, self.ns_head, S, 1, True, 1.0, gp + 4 * sec["head_b1"].offset, 0)
+        else:
+            with _Span(self, "wgrad_skip"):
+                K.wgrad(zs_p, NR, R, self.dtotal.data_ptr(), 0, S, None, L, self.wg_parts, self.wg_bparts, N, T, ns,
+                        dt, pro=K.PRO_GATE)                                           # 1x1 skip
+            K.reduce_partials(self.wg_parts, ns, R * S, L, True, 1.0, gp + 4 * sec["WS"].offset, R * S)
+            K.reduce_partials(self.wg_bparts, ns, S, L, True, 1.0, gp + 4 * sec["BS"].offset, S)
+            K.wgrad(self.r0.data_ptr(), 0, S, self.da1.data_ptr(), 0, S, None, 1, self.wg_parts, self.wg_bparts, N, T,
+                    ns, dt)                                                           # head 1x1 (S->S)
+            K.reduce_partials(self.wg_parts, ns, S * S, 1, True, 1.0, gp + 4 * sec["head_w1"].offset, 0)
+            K.reduce_partials(self.wg_bparts, ns, S, 1, True, 1.0, gp + 4 * sec["head_b1"].offset, 0)
+        if self.use_w256 and not self.pooled and Cp == 256:
+            K.wgrad256(self.r1.data_ptr(), 64, S, S // 64, self.dlogits, self.wg_parts, self.wg_bparts, N,
+                       self.ns_head)                                                  # last 1x1 (S->C)
+            K.reduce_partials(self.wg_parts, self.ns_head, S * Cp, 1, True, 1.0, gp + 4 * sec["head_w2"].offset, 0)
+            K.reduce_partials(self.wg_bparts, self.ns_head, Cp, 1, True, 1.0, gp + 4 * sec["head_b2"].offset, 0)
+        elif not self.pooled:   # (the pooled head wrote its own kernel/bias gradients in forward)
             K.wgrad(self.r1.data_ptr(), 0, S, self.dlogits.data_ptr(), 0, Cp, None, 1, self.wg_parts, self.wg_bparts,
                     N, T, ns, dt)                                                     # last 1x1 (S->C)
             K.reduce_partials(self.wg_parts, ns, S * Cp, 1, True, 1.0, gp + 4 * sec["head_w2"].offset, 0)

@@ -268,6 +268,29 @@ def wgrad(in_ptr: int, in_batch_stride: int, cin: int, dout_ptr: int, dout_batch
          int(nslabs), int(pro), abi_dtype(dtype), _stream())
 
 
+def wgrad256_slabs(rows: int, m_chunks: int) -> int:
+    return int(_lib.load().srwn_wgrad256_slabs(int(rows), int(m_chunks)))
+
+
+def wgrad256(a_ptr: int, a_chunk_stride: int, a_row_stride: int, m_chunks: int, d: torch.Tensor,
+             partials: torch.Tensor, bias_partials: Optional[torch.Tensor], rows: int, nslabs: int,
+             pro: int = PRO_NONE):
+    """d: [rows, 256] tensor; a: raw pointer to 64-channel chunks (see srwn.h)."""
+    pd = _chk(d, "d")
+    if d.shape[0] != rows or d.shape[-1] != 256:
+        raise ValueError("wgrad256: d must be [rows, 256], got %s" % (tuple(d.shape),))
+    pp = _chk(partials, "partials", torch.float32)
+    if partials.numel() < nslabs * m_chunks * 64 * 256:
+        raise ValueError("wgrad256: partials needs %d floats" % (nslabs * m_chunks * 64 * 256))
+    pb = None
+    if bias_partials is not None:
+        pb = _chk(bias_partials, "bias_partials", torch.float32)
+        if bias_partials.numel() < nslabs * 256:
+            raise ValueError("wgrad256: bias_partials needs %d floats" % (nslabs * 256))
+    call("srwn_wgrad256", a_ptr, int(a_chunk_stride), int(a_row_stride), int(m_chunks), pd, 256, pp, pb, int(rows),
+         int(nslabs), int(pro), abi_dtype(d.dtype), _stream())
+
+
 def reduce_partials(partials: torch.Tensor, nslabs: int, n: int, nbatch: int, partials_batched: bool, scale: float,
                     out_ptr: int, out_batch_stride: int):
     call("srwn_reduce_partials", _chk(partials, "partials", torch.float32), int(nslabs), int(n), int(nbatch),

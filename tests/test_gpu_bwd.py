@@ -152,3 +152,39 @@ def test_adam_matches_tf_formula():
         K.adam_step(p, dev(g), pm, pv, step, 1e-2, grad_scale=0.5)
     assert int(step.item()) == 5
     assert rel_err(p.cpu().numpy(), th) < 1e-5
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("mode,rows", [("stack", 5000), ("stack", 331), ("flat", 2100)])
+def test_wgrad256(dt, mode, rows):
+    """All skip kernels at once (stack of z, gate prologue) and the 256x256 head kernels."""
+    K = sub("kernels")
+    rng = np.random.default_rng(rows)
+    d = dev(rng.standard_normal((rows, 256)), dt)
+    if mode == "stack":
+        L = 6
+        a = dev(np.tanh(rng.standard_normal((L, rows, 64))), dt)
+        ns = K.wgrad256_slabs(rows, L)
+        parts = torch.full((ns * L * 64 * 256,), float("nan"), dtype=torch.float32, device=DEV)
+        bparts = torch.full((ns * 256,), float("nan"), dtype=torch.float32, device=DEV)
+        K.wgrad256(a.data_ptr(), rows * 64, 64, L, d, parts, bparts, rows, ns, pro=K.PRO_GATE)
+        out = torch.empty((L * 64, 256), dtype=torch.float32, device=DEV)
+        K.reduce_partials(parts, ns, L * 64 * 256, 1, True, 1.0, out.data_ptr(), 0)
+        az = a.double().cpu().numpy()
+        c = az * (1 / (1 + np.exp(-az)))
+        if dt == torch.bfloat16:
+            c = dev(c, dt).double().cpu().numpy()
+        ref = np.einsum("lrm,rn->lmn", c, d.double().cpu().numpy()).reshape(L * 64, 256)
+    else:
+        a = dev(rng.standard_normal((rows, 256)), dt)
+        ns = K.wgrad256_slabs(rows, 4)
+        parts = torch.full((ns * 256 * 256,), float("nan"), dtype=torch.float32, device=DEV)
+        bparts = torch.full((ns * 256,), float("nan"), dtype=torch.float32, device=DEV)
+        K.wgrad256(a.data_ptr(), 64, 256, 4, d, parts, bparts, rows, ns)
+        out = torch.empty((256, 256), dtype=torch.float32, device=DEV)
+        K.reduce_partials(parts, ns, 256 * 256, 1, True, 1.0, out.data_ptr(), 0)
+        ref = a.double().cpu().numpy().T @ d.double().cpu().numpy()
+    bout = torch.empty(256, dtype=torch.float32, device=DEV)
+    K.reduce_partials(bparts, ns, 256, 1, True, 1.0, bout.data_ptr(), 0)
+    assert rel_err(out.cpu().numpy(), ref) < TOL[dt]
+    assert rel_err(bout.cpu().numpy(), d.double().cpu().numpy().sum(0)) < TOL[dt]

@@ -60,6 +60,10 @@ def main():
         "wgrad_skip(30)": (lambda: K.wgrad(eng.zs.data_ptr(), NR, R, eng.dtotal.data_ptr(), 0, S, None, L,
                                            eng.wg_parts, eng.wg_bparts, N, T, eng.nslabs, dt, pro=K.PRO_GATE),
                            2.0 * N * L * R * S, N * L * R * 2 + N * S * 2),
+        "wgrad256_skip": (lambda: K.wgrad256(eng.zs.data_ptr(), NR, R, L, eng.dtotal, eng.wg_parts, eng.wg_bparts, N,
+                                             eng.ns_skip, pro=K.PRO_GATE), 2.0 * N * L * R * S, N * L * R * 2 + N * S * 2),
+        "wgrad256_head": (lambda: K.wgrad256(eng.r0.data_ptr(), 64, S, S // 64, eng.da1, eng.wg_parts, eng.wg_bparts,
+                                             N, eng.ns_head), 2.0 * N * S * S, N * S * 4),
         "wgrad_conv_tap(30)": (lambda: K.wgrad(eng.xs.data_ptr(), NR, R, eng.dfs.data_ptr(), NR, R, list(eng.dil), L,
                                                eng.wg_parts, None, N, T, eng.nslabs, dt),
                                2.0 * N * L * R * R, N * L * R * 4),
