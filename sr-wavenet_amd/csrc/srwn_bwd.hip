@@ -36,21 +36,12 @@ __global__ __launch_bounds__(256) void layer_bwd_kernel(LayerBwdArgs a) {
   Frag<T>* lds_conv = reinterpret_cast<Frag<T>*>(smem);            // [RT*K*KS][64]   (UP)
   Frag<T>* lds_res = lds_conv + (UP ? RT * K * KS * 64 : 0);       // [RT*KS][64]     (UP && DOWN)
   Frag<T>* lds_skip = lds_res + ((UP && DOWN) ? RT * KS * 64 : 0); // [RT*KSS][64]    (DOWN)
-  if (UP) {
-    const Frag<T>* g = reinterpret_cast<const Frag<T>*>(a.wconvT);
-    for (int i = threadIdx.x; i < RT * K * KS * 64; i += 256) lds_conv[i] = g[i];
-  }
-  if (UP && DOWN) {
-    const Frag<T>* g = reinterpret_cast<const Frag<T>*>(a.wresT);
-    for (int i = threadIdx.x; i < RT * KS * 64; i += 256) lds_res[i] = g[i];
-  }
-  if (DOWN) {
-    const Frag<T>* g = reinterpret_cast<const Frag<T>*>(a.wskipT);
-    for (int i = threadIdx.x; i < RT * KSS * 64; i += 256) lds_skip[i] = g[i];
-  }
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (UP) lds_dma_copy(a.wconvT, lds_conv, RT * K * KS * 64 * (int)sizeof(Frag<T>), wave, lane, 4);
+  if (UP && DOWN) lds_dma_copy(a.wresT, lds_res, RT * KS * 64 * (int)sizeof(Frag<T>), wave, lane, 4);
+  if (DOWN) lds_dma_copy(a.wskipT, lds_skip, RT * KSS * 64 * (int)sizeof(Frag<T>), wave, lane, 4);
   __syncthreads();
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 31, half = lane >> 5;
   const int b = blockIdx.y;
   const int t_wave = (blockIdx.x * 4 + wave) * (32 * NT);
@@ -189,8 +180,8 @@ extern "C" int srwn_residual_layer_bwd(const void* g_in, const void* df_up, cons
   LayerBwdArgs a{g_in, df_up, wconvT_up, g_out, wresT, wskipT, dtotal, z, df_out, T, dilation_up, S};
   hipStream_t st = (hipStream_t)stream;
   if (dtype == SRWN_BF16) {
-    if (R == 32) return launch_layer_bwd<bf16_t, 1, 2>(a, B, has_up, has_down, st);
-    if (R == 64) return launch_layer_bwd<bf16_t, 2, 2>(a, B, has_up, has_down, st);
+    if (R == 32) return launch_layer_bwd<bf16_t, 1, 1>(a, B, has_up, has_down, st);
+    if (R == 64) return launch_layer_bwd<bf16_t, 2, 1>(a, B, has_up, has_down, st);
   } else if (dtype == SRWN_F32) {
     if (R == 32) return launch_layer_bwd<float, 1, 1>(a, B, has_up, has_down, st);
     if (R == 64) return launch_layer_bwd<float, 2, 1>(a, B, has_up, has_down, st);

@@ -115,6 +115,20 @@ __device__ __forceinline__ f32x4 load4(const bf16_t* p) {
 __device__ __forceinline__ f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
 // ----------------------------------------------------------------------------------------------
+// weight images -> LDS with LDS-DMA (global_load_lds_dwordx4): 1-KiB lane-linear pieces, no VGPR round
+// trip and -- unlike a load/ds_write loop -- no dependent wait per piece: every piece of every wave is in
+// flight at once; the caller's __syncthreads() (vmcnt(0) + barrier) retires them.
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lds_dma_copy(const void* gsrc, void* lds_dst, int nbytes, int wave, int lane,
+                                             int nwaves) {
+  const char* g = reinterpret_cast<const char*>(gsrc) + lane * 16;
+  char* l = reinterpret_cast<char*>(lds_dst);
+  for (int p = wave; p < nbytes / 1024; p += nwaves)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + (size_t)p * 1024),
+                                     (__attribute__((address_space(3))) void*)(l + (size_t)p * 1024), 16, 0, 0);
+}
+
+// ----------------------------------------------------------------------------------------------
 // nonlinearities.  fp32 mode = libm-accurate (parity <= 1e-3 vs the oracle); bf16 mode = hardware
 // exp2/rcp (their ~1 ulp error is far below the bf16 storage rounding).
 // ----------------------------------------------------------------------------------------------

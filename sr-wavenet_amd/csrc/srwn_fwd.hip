@@ -24,15 +24,11 @@ __global__ __launch_bounds__(256) void layer_fwd_kernel(const T* __restrict__ x,
   extern __shared__ __attribute__((aligned(16))) char smem[];
   Frag<T>* lds_conv = reinterpret_cast<Frag<T>*>(smem);
   Frag<T>* lds_res = lds_conv + NCONV * 64;
-  {
-    const Frag<T>* gc = reinterpret_cast<const Frag<T>*>(wconv);
-    const Frag<T>* gr = reinterpret_cast<const Frag<T>*>(wres);
-    for (int i = threadIdx.x; i < NCONV * 64; i += 256) lds_conv[i] = gc[i];
-    for (int i = threadIdx.x; i < NRES * 64; i += 256) lds_res[i] = gr[i];
-  }
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  lds_dma_copy(wconv, lds_conv, NCONV * 64 * (int)sizeof(Frag<T>), wave, lane, 4);
+  lds_dma_copy(wres, lds_res, NRES * 64 * (int)sizeof(Frag<T>), wave, lane, 4);
   __syncthreads();
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 31, half = lane >> 5;
   const int b = blockIdx.y;
   const int t_wave = (blockIdx.x * 4 + wave) * (32 * NT);
@@ -188,8 +184,8 @@ extern "C" int srwn_residual_layer_fwd(const void* x, const void* cond, const vo
 #define SRWN_LF(TT, RT_, NT_) \
   return launch_layer_fwd<TT, RT_, 2, NT_>(x, cond, wconv, wres, bias_f, bias_r, h_out, z_out, B, T, dilation, cond_frames, pool_stride, cond_row_stride, st)
   if (dtype == SRWN_BF16) {
-    if (R == 32) SRWN_LF(bf16_t, 1, 2);
-    if (R == 64) SRWN_LF(bf16_t, 2, 2);
+    if (R == 32) SRWN_LF(bf16_t, 1, 1);
+    if (R == 64) SRWN_LF(bf16_t, 2, 1);
   } else if (dtype == SRWN_F32) {
     if (R == 32) SRWN_LF(float, 1, 1);
     if (R == 64) SRWN_LF(float, 2, 1);
