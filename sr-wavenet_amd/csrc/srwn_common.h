@@ -129,6 +129,48 @@ __device__ __forceinline__ void lds_dma_copy(const void* gsrc, void* lds_dst, in
 }
 
 // ----------------------------------------------------------------------------------------------
+// accumulator-layout tile -> HBM as whole rows.  In accumulator layout a lane owns ONE time row, so a
+// direct store writes 8 bytes into each of 32 different cache lines per instruction; measured on
+// MI355X (tools/micro/membench.hip) that partial-line pattern caps a layer kernel at ~2.8 TB/s versus
+// ~4.9 TB/s for whole-row stores.  So tiles are transposed through a wave-private LDS buffer
+// ([32 rows][W + pad] elements) and leave as 16 bytes per lane, consecutive lanes = consecutive bytes.
+// The buffer is private to the wave: LDS executes one wave's instructions in order, so only the
+// compiler has to be kept from reordering (the asm memory clobbers); no barrier is involved.
+// ----------------------------------------------------------------------------------------------
+template <typename T> struct RowStage {
+  static constexpr int VEC = 16 / (int)sizeof(T);   // elements per 16-byte piece
+  static __host__ __device__ __forceinline__ constexpr int stride(int W) { return W + VEC; }   // padded row, 16-B aligned
+};
+
+__device__ __forceinline__ void wave_lds_order() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// vals[mt][q]: accumulator-layout values of MTN row tiles (W = 32*MTN channels) for this lane's time row
+// `col`; gtile points at channel 0 of the tile's first row in HBM, rows `grow_stride` elements apart.
+template <typename T, int MTN>
+__device__ __forceinline__ void store_rows_via_lds(T* stage, T* gtile, int64_t grow_stride, const float (&vals)[MTN][16],
+                                                   int rows_valid, int lane) {
+  constexpr int W = 32 * MTN, LS = RowStage<T>::stride(W), VEC = RowStage<T>::VEC;
+  constexpr int LPR = W / VEC;          // lanes per row when reading back
+  constexpr int RPI = 64 / LPR;         // rows per store instruction
+  const int col = lane & 31, half = lane >> 5;
+  wave_lds_order();                     // earlier reads of the buffer are done
+#pragma unroll
+  for (int mt = 0; mt < MTN; ++mt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      store4(stage + col * LS + 32 * mt + 8 * g + 4 * half, vals[mt][4 * g], vals[mt][4 * g + 1], vals[mt][4 * g + 2],
+             vals[mt][4 * g + 3]);
+  wave_lds_order();
+  const int rsub = lane / LPR, piece = lane % LPR;
+#pragma unroll
+  for (int i = 0; i < 32 / RPI; ++i) {
+    const int r = i * RPI + rsub;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * LS + piece * VEC);
+    if (r < rows_valid) *reinterpret_cast<f32x4*>(gtile + (int64_t)r * grow_stride + piece * VEC) = v;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
 // nonlinearities.  fp32 mode = libm-accurate (parity <= 1e-3 vs the oracle); bf16 mode = hardware
 // exp2/rcp (their ~1 ulp error is far below the bf16 storage rounding).
 // ----------------------------------------------------------------------------------------------

@@ -1,5 +1,6 @@
 // Forward kernels: fused residual layer, pointwise linear (channels GEMM), softmax-CE head.
 // gfx950 (MI355X) only; see srwn_common.h for the MFMA orientation and lane maps.
+#include <cstdlib>
 #include "srwn_common.h"
 #include "srwn_host.h"
 #include "../../include/srwn.h"
@@ -8,16 +9,20 @@ using namespace srwn;
 
 // ------------------------------------------------------------------------------------------
 // fused residual layer forward (ops.py:23-46 + model.py:180-183)
-//   grid = (ceil(T / (4*32*NT)), B), block = 4 waves; each wave owns NT column tiles of 32 time steps.
-//   LDS holds only the layer's packed weights (A fragments); activations go HBM -> VGPR -> MFMA.
+//   Persistent waves: grid = O(#CUs) workgroups of 4 waves; a wave walks 32-step time tiles
+//   (tile id = b * tiles_per_clip + t/32) with stride = total waves, and keeps the NEXT tile's
+//   activation fragments in flight (HBM -> VGPR) while it runs the MFMAs / gate / stores of the
+//   current one, so loads, math and stores of different tiles overlap instead of running as three
+//   chip-wide phases.  LDS holds only the layer's packed weights (A fragments), filled by LDS-DMA.
 // ------------------------------------------------------------------------------------------
-template <typename T, int RT, int K, int NT, bool COND>
-__global__ __launch_bounds__(256) void layer_fwd_kernel(const T* __restrict__ x, const T* __restrict__ cond,
+template <typename T, int RT, int K, bool COND>
+__global__ __launch_bounds__(256, (sizeof(T) == 2) ? 2 : 1) void layer_fwd_kernel(const T* __restrict__ x, const T* __restrict__ cond,
                                                         const T* __restrict__ wconv, const T* __restrict__ wres,
                                                         const float* __restrict__ bias_f,
                                                         const float* __restrict__ bias_r, T* __restrict__ h_out,
                                                         T* __restrict__ z_out, int Tlen, int dilation,
-                                                        int cond_frames, int pool, int cond_stride) {
+                                                        int cond_frames, int pool, int cond_stride, int ntb,
+                                                        int ntiles) {
   constexpr int R = 32 * RT;
   constexpr int KS = R / 16;  // k-steps per tap
   constexpr int NCONV = RT * K * KS, NRES = RT * KS;
@@ -25,104 +30,114 @@ __global__ __launch_bounds__(256) void layer_fwd_kernel(const T* __restrict__ x,
   Frag<T>* lds_conv = reinterpret_cast<Frag<T>*>(smem);
   Frag<T>* lds_res = lds_conv + NCONV * 64;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  T* stage = reinterpret_cast<T*>(lds_res + NRES * 64) + wave * (32 * RowStage<T>::stride(R));   // wave-private
   lds_dma_copy(wconv, lds_conv, NCONV * 64 * (int)sizeof(Frag<T>), wave, lane, 4);
   lds_dma_copy(wres, lds_res, NRES * 64 * (int)sizeof(Frag<T>), wave, lane, 4);
   __syncthreads();
 
   const int col = lane & 31, half = lane >> 5;
-  const int b = blockIdx.y;
-  const int t_wave = (blockIdx.x * 4 + wave) * (32 * NT);
-  if (t_wave >= Tlen) return;
-  const T* xb = x + (size_t)b * Tlen * R;
-  const T* cb = COND ? cond + (size_t)b * cond_frames * cond_stride : nullptr;
-
-  // ---- B fragments: taps 0..K-2 natural k order, last tap (shift 0) permuted so that its
-  //      registers are also the residual-add operand in accumulator layout.
-  Frag<T> bx[NT][K][KS];
+  float bf[RT][16], br[RT][16];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int tc = t_wave + 32 * nt + col;
+  for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      bf[mt][q] = bias_f[32 * mt + crow(q, half)];
+      br[mt][q] = bias_r[32 * mt + crow(q, half)];
+    }
+
+  // B fragments of one tile: taps 0..K-2 natural k order, last tap (shift 0) permuted so that its
+  // registers are also the residual-add operand in accumulator layout.
+  // Loads are UNCONDITIONAL (clamped addresses, values zeroed afterwards by a select): a load under a
+  // branch makes the number of loads in flight path-dependent, and hipcc then waits vmcnt(0) before the
+  // first use of the previous tile's fragments, which would drain the prefetch it is supposed to overlap.
+  auto load_tile = [&](int tile_, Frag<T> (&bx)[K][KS]) {
+    const int tile = tile_ < ntiles ? tile_ : ntiles - 1;
+    const int b = tile / ntb;
+    const int tc = (tile - b * ntb) * 32 + col;
+    const T* xb = x + (size_t)b * Tlen * R;
+    const T* cb = COND ? cond + (size_t)b * cond_frames * cond_stride : nullptr;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const int tk = tc - (K - 1 - k) * dilation;
-      const bool valid = (tc < Tlen) && (tk >= 0);
-      const T* row = xb + (size_t)(valid ? tk : 0) * R;
-      const T* crow_ = COND ? cb + (size_t)((valid ? tk : 0) / pool) * cond_stride : nullptr;
+      const int tkc = tk < 0 ? 0 : (tk < Tlen ? tk : Tlen - 1);
+      const T* row = xb + (size_t)tkc * R;
+      const T* crow_ = COND ? cb + (size_t)(tkc / pool) * cond_stride : nullptr;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         Frag<T> f;
         if (k == K - 1) {
-          f = valid ? load_perm(row + 16 * ks + 4 * half) : zero_frag<T>();
-          if (COND && valid) {
+          f = load_perm(row + 16 * ks + 4 * half);
+          if (COND) {
             Frag<T> c = load_perm(crow_ + 16 * ks + 4 * half);
 #pragma unroll
             for (int j = 0; j < 8; ++j) f.set(j, f.get(j) + c.get(j));
           }
         } else {
-          f = valid ? load_nat(row + 16 * ks + 8 * half) : zero_frag<T>();
-          if (COND && valid) {
+          f = load_nat(row + 16 * ks + 8 * half);
+          if (COND) {
             Frag<T> c = load_nat(crow_ + 16 * ks + 8 * half);
 #pragma unroll
             for (int j = 0; j < 8; ++j) f.set(j, f.get(j) + c.get(j));
           }
         }
-        bx[nt][k][ks] = f;
+        bx[k][ks] = f;   // raw; out-of-range taps are zeroed at use time (process)
       }
     }
-  }
+  };
 
-  // ---- dilated causal conv as one (K*R)-deep contraction; accumulators start at the bias
-  f32x16 accF[RT][NT];
+  // one tile: conv MFMAs -> tanh/gate -> residual MFMAs -> whole-row stores
+  auto process = [&](int tile, const Frag<T> (&raw)[K][KS]) {
+    Frag<T> cur[K][KS];
+    {
+      const int b0 = tile / ntb;
+      const int tc0 = (tile - b0 * ntb) * 32 + col;
 #pragma unroll
-  for (int mt = 0; mt < RT; ++mt) {
+      for (int k = 0; k < K; ++k) {
+        const bool valid = (tc0 < Tlen) && (tc0 - (K - 1 - k) * dilation >= 0);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const float bv = bias_f[32 * mt + crow(q, half)];
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) accF[mt][nt][q] = bv;
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-      for (int mt = 0; mt < RT; ++mt) {
-        const Frag<T> a = lds_conv[(mt * (K * KS) + k * KS + ks) * 64 + lane];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) mma(accF[mt][nt], a, bx[nt][k][ks]);
+        for (int ks = 0; ks < KS; ++ks) cur[k][ks] = valid ? raw[k][ks] : zero_frag<T>();
       }
     }
-  }
-
-  // ---- epilogue per column tile: tanh, gate, 1x1 residual from registers, scaled residual add
+    // ---- dilated causal conv as one (K*R)-deep contraction; accumulators start at the bias
+    f32x16 accF[RT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int tc = t_wave + 32 * nt + col;
-    const bool ok = tc < Tlen;
-    T* zrow = z_out + ((size_t)b * Tlen + (ok ? tc : 0)) * R;
-    T* hrow = h_out + ((size_t)b * Tlen + (ok ? tc : 0)) * R;
+    for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) accF[mt][q] = bf[mt][q];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int mt = 0; mt < RT; ++mt) {
+          const Frag<T> a = lds_conv[(mt * (K * KS) + k * KS + ks) * 64 + lane];
+          mma(accF[mt], a, cur[k][ks]);
+        }
+
+    // ---- tanh, gate, 1x1 residual from registers, scaled residual add
+    const int b = tile / ntb;
+    const int t0 = (tile - b * ntb) * 32;
+    const int rows_valid = Tlen - t0;   // >= 1; rows beyond it do not exist
+    T* ztile = z_out + ((size_t)b * Tlen + t0) * R;
+    T* htile = h_out + ((size_t)b * Tlen + t0) * R;
     Frag<T> cf[KS];
+    {
+      float zz[RT][16];
 #pragma unroll
-    for (int mt = 0; mt < RT; ++mt) {
-      float zz[16];
+      for (int mt = 0; mt < RT; ++mt)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const float z = Math<T>::tanh_(accF[mt][nt][q]);
-        zz[q] = z;
-        cf[2 * mt + (q >> 3)].set(q & 7, gate_of_z<T>(z));
-      }
-      if (ok) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          store4(zrow + 32 * mt + 8 * g + 4 * half, zz[4 * g], zz[4 * g + 1], zz[4 * g + 2], zz[4 * g + 3]);
-      }
+        for (int q = 0; q < 16; ++q) {
+          const float z = Math<T>::tanh_(accF[mt][q]);
+          zz[mt][q] = z;
+          cf[2 * mt + (q >> 3)].set(q & 7, gate_of_z<T>(z));
+        }
+      store_rows_via_lds<T, RT>(stage, ztile, R, zz, rows_valid, lane);
     }
     f32x16 accR[RT];
 #pragma unroll
     for (int mt = 0; mt < RT; ++mt)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) accR[mt][q] = bias_r[32 * mt + crow(q, half)];
+      for (int q = 0; q < 16; ++q) accR[mt][q] = br[mt][q];
 #pragma unroll
     for (int s = 0; s < KS; ++s)
 #pragma unroll
@@ -130,40 +145,65 @@ __global__ __launch_bounds__(256) void layer_fwd_kernel(const T* __restrict__ x,
         const Frag<T> a = lds_res[(mt * KS + s) * 64 + lane];
         mma(accR[mt], a, cf[s]);
       }
-    if (ok) {
+    {
+      float hv[RT][16];
 #pragma unroll
-      for (int mt = 0; mt < RT; ++mt) {
-        float hv[16];
+      for (int mt = 0; mt < RT; ++mt)
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-          const float xin = bx[nt][K - 1][2 * mt + (q >> 3)].get(q & 7);
-          hv[q] = (xin + accR[mt][q]) * kSqrtHalf;
+          const float xin = cur[K - 1][2 * mt + (q >> 3)].get(q & 7);
+          hv[mt][q] = (xin + accR[mt][q]) * kSqrtHalf;
         }
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          store4(hrow + 32 * mt + 8 * g + 4 * half, hv[4 * g], hv[4 * g + 1], hv[4 * g + 2], hv[4 * g + 3]);
-      }
+      store_rows_via_lds<T, RT>(stage, htile, R, hv, rows_valid, lane);
     }
+  };
+
+  // ping-pong fragment sets (no register copies, and the compiler's waitcnt bookkeeping stays exact):
+  // the loads of the NEXT tile are always in flight while the current tile is processed.
+  const int stride = gridDim.x * 4;
+  Frag<T> fa[K][KS], fb[K][KS];
+  int tile = blockIdx.x * 4 + wave;
+  load_tile(tile, fa);
+  while (tile < ntiles) {
+    load_tile(tile + stride, fb);   // (clamped to the last tile when past the end: harmless re-read)
+    process(tile, fa);
+    tile += stride;
+    if (tile >= ntiles) break;
+    load_tile(tile + stride, fa);
+    process(tile, fb);
+    tile += stride;
   }
 }
 
-template <typename T, int RT, int K, int NT>
+static int layer_blocks_per_cu(const char* env, int dflt) {
+  const char* e = getenv(env);
+  int v = e ? atoi(e) : dflt;
+  return v < 1 ? 1 : (v > 8 ? 8 : v);
+}
+
+template <typename T, int RT, int K>
 static int launch_layer_fwd(const void* x, const void* cond, const void* wconv, const void* wres,
                             const float* bias_f, const float* bias_r, void* h_out, void* z_out, int B, int Tlen,
                             int dilation, int cond_frames, int pool, int cond_stride, hipStream_t st) {
   constexpr int R = 32 * RT, KS = R / 16;
-  const size_t sh = (size_t)(RT * K * KS + RT * KS) * 64 * sizeof(Frag<T>);
-  dim3 grid((unsigned)((Tlen + 4 * 32 * NT - 1) / (4 * 32 * NT)), (unsigned)B), block(256);
+  const size_t sh = (size_t)(RT * K * KS + RT * KS) * 64 * sizeof(Frag<T>) +
+                    (size_t)4 * 32 * RowStage<T>::stride(R) * sizeof(T);
+  const int ntb = (Tlen + 31) / 32;
+  const long long ntiles = (long long)B * ntb;
+  static const int bpc = layer_blocks_per_cu("SRWN_FWD_BPC", 2);
+  long long blocks = (ntiles + 3) / 4;
+  if (blocks > 256LL * bpc) blocks = 256LL * bpc;
+  dim3 grid((unsigned)blocks), block(256);
   if (cond) {
-    auto kfn = layer_fwd_kernel<T, RT, K, NT, true>;
+    auto kfn = layer_fwd_kernel<T, RT, K, true>;
     if (sh > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     hipLaunchKernelGGL(kfn, grid, block, sh, st, (const T*)x, (const T*)cond, (const T*)wconv, (const T*)wres, bias_f,
-                       bias_r, (T*)h_out, (T*)z_out, Tlen, dilation, cond_frames, pool, cond_stride);
+                       bias_r, (T*)h_out, (T*)z_out, Tlen, dilation, cond_frames, pool, cond_stride, ntb, (int)ntiles);
   } else {
-    auto kfn = layer_fwd_kernel<T, RT, K, NT, false>;
+    auto kfn = layer_fwd_kernel<T, RT, K, false>;
     if (sh > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     hipLaunchKernelGGL(kfn, grid, block, sh, st, (const T*)x, (const T*)nullptr, (const T*)wconv, (const T*)wres,
-                       bias_f, bias_r, (T*)h_out, (T*)z_out, Tlen, dilation, 1, 1, R);
+                       bias_f, bias_r, (T*)h_out, (T*)z_out, Tlen, dilation, 1, 1, R, ntb, (int)ntiles);
   }
   return check_launch("residual_layer_fwd");
 }
@@ -177,18 +217,19 @@ extern "C" int srwn_residual_layer_fwd(const void* x, const void* cond, const vo
   if (!x || !wconv || !wres || !bias_f || !bias_r || !h_out || !z_out)
     return set_error(SRWN_E_NULL, "residual_layer_fwd: null pointer");
   if (B < 0 || T < 0 || dilation < 1) return set_error(SRWN_E_SHAPE, "residual_layer_fwd: B=%d T=%d d=%d", B, T, dilation);
+  if ((long long)B * ((T + 31) / 32) > 0x7fffffffLL) return set_error(SRWN_E_SHAPE, "residual_layer_fwd: too many tiles");
   if (cond && (pool_stride < 1 || cond_row_stride < R || cond_row_stride % 8 || (int64_t)cond_frames * pool_stride < T))
     return set_error(SRWN_E_SHAPE, "residual_layer_fwd: cond frames %d x pool %d < T %d", cond_frames, pool_stride, T);
   if (K != 2) return set_error(SRWN_E_UNSUPPORTED, "residual_layer_fwd: filter_width %d (only 2 is built)", K);
   hipStream_t st = (hipStream_t)stream;
-#define SRWN_LF(TT, RT_, NT_) \
-  return launch_layer_fwd<TT, RT_, 2, NT_>(x, cond, wconv, wres, bias_f, bias_r, h_out, z_out, B, T, dilation, cond_frames, pool_stride, cond_row_stride, st)
+#define SRWN_LF(TT, RT_) \
+  return launch_layer_fwd<TT, RT_, 2>(x, cond, wconv, wres, bias_f, bias_r, h_out, z_out, B, T, dilation, cond_frames, pool_stride, cond_row_stride, st)
   if (dtype == SRWN_BF16) {
-    if (R == 32) SRWN_LF(bf16_t, 1, 1);
-    if (R == 64) SRWN_LF(bf16_t, 2, 1);
+    if (R == 32) SRWN_LF(bf16_t, 1);
+    if (R == 64) SRWN_LF(bf16_t, 2);
   } else if (dtype == SRWN_F32) {
-    if (R == 32) SRWN_LF(float, 1, 1);
-    if (R == 64) SRWN_LF(float, 2, 1);
+    if (R == 32) SRWN_LF(float, 1);
+    if (R == 64) SRWN_LF(float, 2);
   } else {
     return set_error(SRWN_E_DTYPE, "residual_layer_fwd: dtype %d", dtype);
   }
