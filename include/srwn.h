@@ -122,12 +122,13 @@ int srwn_reduce_loss(const float* loss_partials, int64_t n, float scale, float* 
  *   has_up  : G_{l+1}[t] = g_in[t]*sqrt(.5) + sum_k Wf_{l+1}[k] . df_up[t + (K-1-k)*dilation_up]  -> g_out
  *             (g_in = G_{l+2}, may be NULL = 0; wconvT_up packed [R/32][K*R/16], rows = in channel)
  *   has_down: dc = Wr_l . (G_{l+1} sqrt(.5)) + Ws_l . dtotal;  df_l = dc * d(z sigmoid z)/df      -> df_out
- *             (wresT packed permuted [R/32][R/16]; wskipT packed natural [R/32][S/16]; z = z_l)
+ *             (wresT packed permuted [R/32][R/16]; z = z_l; the skip term Ws_l . dtotal is either `dcs`
+ *             = layer l's slice from srwn_skip_dgrad_all, or computed here from wskipT [R/32][S/16] + dtotal)
  * Layer L-1: has_up=0 (its dense output is unused, model.py:45-50).  Below layer 0: has_down=0. */
 int srwn_residual_layer_bwd(const void* g_in, const void* df_up, const void* wconvT_up, void* g_out,
-                            const void* wresT, const void* wskipT, const void* dtotal, const void* z, void* df_out,
-                            int32_t B, int32_t T, int32_t R, int32_t S, int32_t K, int32_t dilation_up,
-                            int32_t has_up, int32_t has_down, int32_t dtype, void* stream);
+                            const void* wresT, const void* wskipT, const void* dtotal, const void* dcs,
+                            const void* z, void* df_out, int32_t B, int32_t T, int32_t R, int32_t S, int32_t K,
+                            int32_t dilation_up, int32_t has_up, int32_t has_down, int32_t dtype, void* stream);
 
 /* ---- weight gradients (the tf.gradients of every kernel on the path), batched over `nbatch` layers:
  *   partials[l][slab][i][o] = sum_{rows of slab} pro(in_l[row - shifts[l], i] + cond_l[b, (t-shift)/pool, i])
@@ -183,6 +184,13 @@ int32_t srwn_wgrad256_slabs(int64_t rows, int32_t m_chunks);
 int srwn_wgrad256(const void* a, int64_t a_chunk_stride, int64_t a_row_stride, int32_t m_chunks, const void* d,
                   int64_t d_row_stride, float* partials, float* bias_partials, int64_t rows, int32_t nslabs,
                   int32_t pro, int32_t dtype, void* stream);
+
+/* ---- skip-path data gradient of every layer in one launch (autodiff of ops.py:44):
+ *   dcs[l][row][n] = sum_s dtotal[row][s] * Ws_l[n][s],   dcs + l*dcs_layer_stride, rows of R elements.
+ * wskipT_all: the nlayers packed images [R/32][S/16] (natural k order) laid out back to back.
+ * srwn_residual_layer_bwd then takes dcs_l instead of recomputing Ws_l . dtotal (pass wskipT = dtotal = NULL). */
+int srwn_skip_dgrad_all(const void* dtotal, const void* wskipT_all, void* dcs, int64_t dcs_layer_stride,
+                        int32_t nlayers, int64_t rows, int32_t R, int32_t S, int32_t dtype, void* stream);
 
 #ifdef __cplusplus
 }

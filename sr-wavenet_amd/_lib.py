@@ -35,7 +35,7 @@ SIGNATURES = {
     "srwn_softmax_ce_partials": (_i64, [_i64]),
     "srwn_head_softmax_ce": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _p, _p, _p, _i32, _i32, _i64, _f32, _i32, _p]),
     "srwn_reduce_loss": (C.c_int, [_p, _i64, _f32, _p, _p]),
-    "srwn_residual_layer_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32,
+    "srwn_residual_layer_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32,
                                           _i32, _i32, _i32, _p]),
     "srwn_wgrad_slabs": (_i32, [_i64]),
     "srwn_wgrad": (C.c_int, [_p, _i64, _i32, _p, _i64, _i32, _p, _i64, _i32, _i32, _i32, _p, _i32, _p, _p, _i64,
@@ -47,6 +47,7 @@ SIGNATURES = {
     "srwn_time_mean": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "srwn_pooled_head": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "srwn_bcast_mask": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _f32, _i32, _p]),
+    "srwn_skip_dgrad_all": (C.c_int, [_p, _p, _p, _i64, _i32, _i64, _i32, _i32, _i32, _p]),
     "srwn_wgrad256_slabs": (_i32, [_i64, _i32]),
     "srwn_wgrad256": (C.c_int, [_p, _i64, _i64, _i32, _p, _i64, _p, _p, _i64, _i32, _i32, _i32, _p]),
 }

@@ -1,5 +1,6 @@
 // Backward kernels: fused residual-layer data gradient, time-contraction weight gradients,
 // deterministic partial reduction.  gfx950 (MI355X) only.
+#include <cstdlib>
 #include "srwn_common.h"
 #include "srwn_host.h"
 #include "../../include/srwn.h"
@@ -10,71 +11,131 @@ using namespace srwn;
 // fused residual layer backward (autodiff of ops.py:23-46), one launch per layer l, top to bottom.
 //   UP   : G_{l+1}[t] = G_{l+2}[t]*sqrt(.5) + sum_k Wf_{l+1}[k] . df_{l+1}[t + (K-1-k) d_{l+1}]   -> g_out
 //          (data gradient of the layer above; anti-causal taps, zero beyond T)
-//   DOWN : dc = Wr_l . (G_{l+1} sqrt(.5)) + Ws_l . dtotal ;  df_l = dc * d(z sigmoid(z))/df        -> df_out
+//   DOWN : dc = Wr_l . (G_{l+1} sqrt(.5)) + dcs_l ;  df_l = dc * d(z sigmoid(z))/df                -> df_out
+//          dcs_l = Ws_l . dtotal comes precomputed from srwn_skip_dgrad_all (DCS), or is computed
+//          here from dtotal (legacy path for shapes that kernel does not cover).
 //   The UP accumulator tile is the B operand of the Wr product (no LDS / HBM round trip).
 //   Flags: layer L-1 runs DOWN only (G_L = 0: the last dense output is unused, model.py:45-50);
 //          the call below layer 0 runs UP only (gradient wrt the input conv output).
+//   Same execution shape as the forward kernel: persistent waves over 32-step tiles, the next tile's
+//   operands in flight (ping-pong register sets, unconditional clamped loads), whole-row stores via LDS.
 // ------------------------------------------------------------------------------------------
 struct LayerBwdArgs {
-  const void* g_in;      // G_{l+2} [B,T,R] or nullptr (zero)
+  const void* g_in;      // G_{l+2} [B,T,R] (GIN)
   const void* df_up;     // df_{l+1} [B,T,R]
   const void* wconvT;    // packed [R/32][K*R/16] natural: rows = in channel i, k = tap*R + o
   void* g_out;           // G_{l+1}
   const void* wresT;     // packed [R/32][R/16] permuted: rows = n, k = m  (Wr[n][m])
-  const void* wskipT;    // packed [R/32][S/16] natural: rows = n, k = s   (Ws[n][s])
-  const void* dtotal;    // [B*T, S]
+  const void* wskipT;    // packed [R/32][S/16] natural: rows = n, k = s   (Ws[n][s])   (!DCS)
+  const void* dtotal;    // [B*T, S]                                                    (!DCS)
+  const void* dcs;       // dcs_l [B,T,R]                                               (DCS)
   const void* z;         // z_l [B,T,R]
   void* df_out;          // df_l
-  int Tlen, dil_up, S;
+  int Tlen, dil_up, S, ntb, ntiles;
 };
 
-template <typename T, int RT, int K, int NT, bool UP, bool DOWN>
+template <typename T> struct Raw4;
+template <> struct Raw4<bf16_t> {
+  typedef bf16x4 type;
+  static __device__ __forceinline__ type load(const bf16_t* p) { return *reinterpret_cast<const bf16x4*>(p); }
+  static __device__ __forceinline__ float get(const type& v, int e) { return (float)v[e]; }
+};
+template <> struct Raw4<float> {
+  typedef f32x4 type;
+  static __device__ __forceinline__ type load(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+  static __device__ __forceinline__ float get(const type& v, int e) { return v[e]; }
+};
+
+template <typename T, int RT, int K, bool UP, bool GIN, bool DOWN, bool DCS>
 __global__ __launch_bounds__(256) void layer_bwd_kernel(LayerBwdArgs a) {
   constexpr int R = 32 * RT, KS = R / 16;
+  typedef typename Raw4<T>::type raw4;
   const int KSS = a.S / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  Frag<T>* lds_conv = reinterpret_cast<Frag<T>*>(smem);            // [RT*K*KS][64]   (UP)
-  Frag<T>* lds_res = lds_conv + (UP ? RT * K * KS * 64 : 0);       // [RT*KS][64]     (UP && DOWN)
-  Frag<T>* lds_skip = lds_res + ((UP && DOWN) ? RT * KS * 64 : 0); // [RT*KSS][64]    (DOWN)
+  Frag<T>* lds_conv = reinterpret_cast<Frag<T>*>(smem);                    // [RT*K*KS][64]   (UP)
+  Frag<T>* lds_res = lds_conv + (UP ? RT * K * KS * 64 : 0);               // [RT*KS][64]     (UP && DOWN)
+  Frag<T>* lds_skip = lds_res + ((UP && DOWN) ? RT * KS * 64 : 0);         // [RT*KSS][64]    (DOWN && !DCS)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  T* stage = reinterpret_cast<T*>(lds_skip + ((DOWN && !DCS) ? RT * KSS * 64 : 0)) +
+             wave * (32 * RowStage<T>::stride(R));
   if (UP) lds_dma_copy(a.wconvT, lds_conv, RT * K * KS * 64 * (int)sizeof(Frag<T>), wave, lane, 4);
   if (UP && DOWN) lds_dma_copy(a.wresT, lds_res, RT * KS * 64 * (int)sizeof(Frag<T>), wave, lane, 4);
-  if (DOWN) lds_dma_copy(a.wskipT, lds_skip, RT * KSS * 64 * (int)sizeof(Frag<T>), wave, lane, 4);
+  if (DOWN && !DCS) lds_dma_copy(a.wskipT, lds_skip, RT * KSS * 64 * (int)sizeof(Frag<T>), wave, lane, 4);
   __syncthreads();
 
   const int col = lane & 31, half = lane >> 5;
-  const int b = blockIdx.y;
-  const int t_wave = (blockIdx.x * 4 + wave) * (32 * NT);
-  if (t_wave >= a.Tlen) return;
-  const size_t boff = (size_t)b * a.Tlen;
+  struct Tile {
+    raw4 gin[RT][4];
+    Frag<T> dfu[K][KS];
+    raw4 dcs[RT][4];
+    raw4 zz[RT][4];
+  };
 
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int tc = t_wave + 32 * nt + col;
-    const bool ok = tc < a.Tlen;
-    const size_t rowi = boff + (ok ? tc : 0);
-    f32x16 accG[RT];
+  auto load_tile = [&](int tile_, Tile& t) {
+    const int tile = tile_ < a.ntiles ? tile_ : a.ntiles - 1;
+    const int b = tile / a.ntb;
+    const int tc = (tile - b * a.ntb) * 32 + col;
+    const int tcc = tc < a.Tlen ? tc : a.Tlen - 1;
+    const size_t boff = (size_t)b * a.Tlen;
+    const size_t rowi = boff + tcc;
     if (UP) {
-      // residual path: G_{l+2} * sqrt(.5) in accumulator layout
-      const T* gin = a.g_in ? reinterpret_cast<const T*>(a.g_in) + rowi * R : nullptr;
+      if (GIN) {
+        const T* gin = reinterpret_cast<const T*>(a.g_in) + rowi * R;
 #pragma unroll
-      for (int mt = 0; mt < RT; ++mt)
+        for (int mt = 0; mt < RT; ++mt)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          f32x4 v = (gin && ok) ? load4(gin + 32 * mt + 8 * g + 4 * half) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) accG[mt][4 * g + e] = v[e] * kSqrtHalf;
-        }
-      // conv data gradient: taps read df_up at t + (K-1-k)*d
+          for (int g = 0; g < 4; ++g) t.gin[mt][g] = Raw4<T>::load(gin + 32 * mt + 8 * g + 4 * half);
+      }
       const T* dfu = reinterpret_cast<const T*>(a.df_up);
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        const int tk = tc + (K - 1 - k) * a.dil_up;
-        const bool valid = ok && (tk < a.Tlen);
-        const T* row = dfu + (boff + (valid ? tk : 0)) * R;
+        const int tk = tcc + (K - 1 - k) * a.dil_up;
+        const int tkc = tk < a.Tlen ? tk : a.Tlen - 1;
+        const T* row = dfu + (boff + tkc) * R;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) t.dfu[k][ks] = load_nat(row + 16 * ks + 8 * half);
+      }
+    }
+    if (DOWN) {
+      if (DCS) {
+        const T* dr = reinterpret_cast<const T*>(a.dcs) + rowi * R;
+#pragma unroll
+        for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) t.dcs[mt][g] = Raw4<T>::load(dr + 32 * mt + 8 * g + 4 * half);
+      }
+      const T* zr = reinterpret_cast<const T*>(a.z) + rowi * R;
+#pragma unroll
+      for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) t.zz[mt][g] = Raw4<T>::load(zr + 32 * mt + 8 * g + 4 * half);
+    }
+  };
+
+  auto process = [&](int tile, const Tile& t) {
+    const int b = tile / a.ntb;
+    const int t0 = (tile - b * a.ntb) * 32;
+    const int tc = t0 + col;
+    const bool ok = tc < a.Tlen;
+    const int rows_valid = a.Tlen - t0;
+    const size_t boff = (size_t)b * a.Tlen;
+    f32x16 accG[RT];
+    if (UP) {
+      // residual path: G_{l+2} * sqrt(.5) in accumulator layout
+#pragma unroll
+      for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            accG[mt][4 * g + e] = (GIN && ok) ? Raw4<T>::get(t.gin[mt][g], e) * kSqrtHalf : 0.0f;
+      // conv data gradient: taps read df_up at t + (K-1-k)*d (zero beyond the clip)
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const bool valid = ok && (tc + (K - 1 - k) * a.dil_up < a.Tlen);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          const Frag<T> bf = valid ? load_nat(row + 16 * ks + 8 * half) : zero_frag<T>();
+          const Frag<T> bf = valid ? t.dfu[k][ks] : zero_frag<T>();
 #pragma unroll
           for (int mt = 0; mt < RT; ++mt) {
             const Frag<T> af = lds_conv[(mt * (K * KS) + k * KS + ks) * 64 + lane];
@@ -82,22 +143,21 @@ __global__ __launch_bounds__(256) void layer_bwd_kernel(LayerBwdArgs a) {
           }
         }
       }
-      if (ok) {
-        T* go = reinterpret_cast<T*>(a.g_out) + rowi * R;
+      float gv[RT][16];
 #pragma unroll
-        for (int mt = 0; mt < RT; ++mt)
+      for (int mt = 0; mt < RT; ++mt)
 #pragma unroll
-          for (int g = 0; g < 4; ++g)
-            store4(go + 32 * mt + 8 * g + 4 * half, accG[mt][4 * g], accG[mt][4 * g + 1], accG[mt][4 * g + 2],
-                   accG[mt][4 * g + 3]);
-      }
+        for (int q = 0; q < 16; ++q) gv[mt][q] = accG[mt][q];
+      store_rows_via_lds<T, RT>(stage, reinterpret_cast<T*>(a.g_out) + (boff + t0) * R, R, gv, rows_valid, lane);
     }
     if (DOWN) {
       f32x16 accC[RT];
 #pragma unroll
       for (int mt = 0; mt < RT; ++mt)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) accC[mt][q] = 0.0f;
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) accC[mt][4 * g + e] = (DCS && ok) ? Raw4<T>::get(t.dcs[mt][g], e) : 0.0f;
       if (UP) {
         // dres = G_{l+1} * sqrt(.5): the accumulator tile is the B operand (permuted k order)
 #pragma unroll
@@ -112,79 +172,113 @@ __global__ __launch_bounds__(256) void layer_bwd_kernel(LayerBwdArgs a) {
           }
         }
       }
-      const T* dt = reinterpret_cast<const T*>(a.dtotal) + rowi * a.S + 8 * half;
-      for (int ks = 0; ks < KSS; ++ks) {
-        const Frag<T> bf = ok ? load_nat(dt + 16 * ks) : zero_frag<T>();
+      if (!DCS) {
+        const T* dt = reinterpret_cast<const T*>(a.dtotal) + (boff + (ok ? tc : 0)) * a.S + 8 * half;
+        for (int ks = 0; ks < KSS; ++ks) {
+          const Frag<T> bf = ok ? load_nat(dt + 16 * ks) : zero_frag<T>();
 #pragma unroll
-        for (int mt = 0; mt < RT; ++mt) {
-          const Frag<T> af = lds_skip[(mt * KSS + ks) * 64 + lane];
-          mma(accC[mt], af, bf);
+          for (int mt = 0; mt < RT; ++mt) {
+            const Frag<T> af = lds_skip[(mt * KSS + ks) * 64 + lane];
+            mma(accC[mt], af, bf);
+          }
         }
       }
-      if (ok) {
-        const T* zr = reinterpret_cast<const T*>(a.z) + rowi * R;
-        T* dfo = reinterpret_cast<T*>(a.df_out) + rowi * R;
+      float dv[RT][16];
 #pragma unroll
-        for (int mt = 0; mt < RT; ++mt)
+      for (int mt = 0; mt < RT; ++mt)
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const f32x4 zv = load4(zr + 32 * mt + 8 * g + 4 * half);
-            float v[4];
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = accC[mt][4 * g + e] * dgate_df<T>(zv[e]);
-            store4(dfo + 32 * mt + 8 * g + 4 * half, v[0], v[1], v[2], v[3]);
-          }
-      }
+          for (int e = 0; e < 4; ++e)
+            dv[mt][4 * g + e] = accC[mt][4 * g + e] * dgate_df<T>(Raw4<T>::get(t.zz[mt][g], e));
+      store_rows_via_lds<T, RT>(stage, reinterpret_cast<T*>(a.df_out) + (boff + t0) * R, R, dv, rows_valid, lane);
     }
+  };
+
+  const int stride = gridDim.x * 4;
+  Tile ta, tb;
+  int tile = blockIdx.x * 4 + wave;
+  load_tile(tile, ta);
+  while (tile < a.ntiles) {
+    load_tile(tile + stride, tb);
+    process(tile, ta);
+    tile += stride;
+    if (tile >= a.ntiles) break;
+    load_tile(tile + stride, ta);
+    process(tile, tb);
+    tile += stride;
   }
 }
 
-template <typename T, int RT, int NT>
-static int launch_layer_bwd(const LayerBwdArgs& a, int B, bool up, bool down, hipStream_t st) {
+static int bwd_blocks_per_cu() {
+  static const int v = [] {
+    const char* e = getenv("SRWN_BWD_BPC");
+    int x = e ? atoi(e) : 1;
+    return x < 1 ? 1 : (x > 8 ? 8 : x);
+  }();
+  return v;
+}
+
+template <typename T, int RT>
+static int launch_layer_bwd(LayerBwdArgs a, int B, bool up, bool gin, bool down, bool dcs, hipStream_t st) {
   constexpr int K = 2, R = 32 * RT, KS = R / 16;
   size_t frags = 0;
   if (up) frags += RT * K * KS;
   if (up && down) frags += RT * KS;
-  if (down) frags += (size_t)RT * (a.S / 16);
-  const size_t sh = frags * 64 * sizeof(Frag<T>);
-  dim3 grid((unsigned)((a.Tlen + 4 * 32 * NT - 1) / (4 * 32 * NT)), (unsigned)B), block(256);
-#define SRWN_LB(U, D)                                                                                          \
-  {                                                                                                            \
-    auto kfn = layer_bwd_kernel<T, RT, K, NT, U, D>;                                                           \
-    if (sh > 65536) {                                                                                          \
+  if (down && !dcs) frags += (size_t)RT * (a.S / 16);
+  const size_t sh = frags * 64 * sizeof(Frag<T>) + (size_t)4 * 32 * RowStage<T>::stride(R) * sizeof(T);
+  a.ntb = (a.Tlen + 31) / 32;
+  const long long ntiles = (long long)B * a.ntb;
+  a.ntiles = (int)ntiles;
+  long long blocks = (ntiles + 3) / 4;
+  if (blocks > 256LL * bwd_blocks_per_cu()) blocks = 256LL * bwd_blocks_per_cu();
+  dim3 grid((unsigned)blocks), block(256);
+#define SRWN_LB(U, G, D, C)                                                                                    \
+  if (up == U && gin == G && down == D && dcs == C) {                                                          \
+    auto kfn = layer_bwd_kernel<T, RT, K, U, G, D, C>;                                                         \
+    if (sh > 32768) {                                                                                          \
       hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
       if (e != hipSuccess) return set_error((int)e, "layer_bwd: LDS %zu: %s", sh, hipGetErrorString(e));       \
     }                                                                                                          \
     hipLaunchKernelGGL(kfn, grid, block, sh, st, a);                                                           \
+    return check_launch("residual_layer_bwd");                                                                 \
   }
-  if (up && down) SRWN_LB(true, true)
-  else if (up) SRWN_LB(true, false)
-  else SRWN_LB(false, true)
+  SRWN_LB(true, true, true, true)
+  SRWN_LB(true, false, true, true)
+  SRWN_LB(false, false, true, true)
+  SRWN_LB(true, true, true, false)
+  SRWN_LB(true, false, true, false)
+  SRWN_LB(false, false, true, false)
+  SRWN_LB(true, true, false, false)
+  SRWN_LB(true, false, false, false)
 #undef SRWN_LB
-  return check_launch("residual_layer_bwd");
+  return set_error(SRWN_E_UNSUPPORTED, "residual_layer_bwd: flag combination not built");
 }
 
 extern "C" int srwn_residual_layer_bwd(const void* g_in, const void* df_up, const void* wconvT_up, void* g_out,
-                                       const void* wresT, const void* wskipT, const void* dtotal, const void* z,
-                                       void* df_out, int32_t B, int32_t T, int32_t R, int32_t S, int32_t K,
-                                       int32_t dilation_up, int32_t has_up, int32_t has_down, int32_t dtype,
-                                       void* stream) {
+                                       const void* wresT, const void* wskipT, const void* dtotal, const void* dcs,
+                                       const void* z, void* df_out, int32_t B, int32_t T, int32_t R, int32_t S,
+                                       int32_t K, int32_t dilation_up, int32_t has_up, int32_t has_down,
+                                       int32_t dtype, void* stream) {
   if (B == 0 || T == 0) return 0;
   if (!has_up && !has_down) return set_error(SRWN_E_SHAPE, "residual_layer_bwd: neither UP nor DOWN");
   if (has_up && (!df_up || !wconvT_up || !g_out)) return set_error(SRWN_E_NULL, "residual_layer_bwd: UP needs df_up, wconvT_up, g_out");
-  if (has_down && (!wskipT || !dtotal || !z || !df_out)) return set_error(SRWN_E_NULL, "residual_layer_bwd: DOWN needs wskipT, dtotal, z, df_out");
+  if (has_down && (!z || !df_out)) return set_error(SRWN_E_NULL, "residual_layer_bwd: DOWN needs z, df_out");
+  if (has_down && !dcs && (!wskipT || !dtotal)) return set_error(SRWN_E_NULL, "residual_layer_bwd: DOWN needs dcs, or wskipT + dtotal");
   if (has_up && has_down && !wresT) return set_error(SRWN_E_NULL, "residual_layer_bwd: UP+DOWN needs wresT");
   if (K != 2) return set_error(SRWN_E_UNSUPPORTED, "residual_layer_bwd: filter_width %d (only 2 is built)", K);
   if (B < 0 || T < 0 || S < 16 || S % 16 || (has_up && dilation_up < 1))
     return set_error(SRWN_E_SHAPE, "residual_layer_bwd: B=%d T=%d S=%d d=%d", B, T, S, dilation_up);
-  LayerBwdArgs a{g_in, df_up, wconvT_up, g_out, wresT, wskipT, dtotal, z, df_out, T, dilation_up, S};
+  if ((long long)B * ((T + 31) / 32) > 0x7fffffffLL) return set_error(SRWN_E_SHAPE, "residual_layer_bwd: too many tiles");
+  LayerBwdArgs a{g_in, df_up, wconvT_up, g_out, wresT, wskipT, dtotal, dcs, z, df_out, T, dilation_up, S, 0, 0};
   hipStream_t st = (hipStream_t)stream;
+  const bool up = has_up != 0, down = has_down != 0, gin = up && g_in != nullptr, use_dcs = down && dcs != nullptr;
   if (dtype == SRWN_BF16) {
-    if (R == 32) return launch_layer_bwd<bf16_t, 1, 1>(a, B, has_up, has_down, st);
-    if (R == 64) return launch_layer_bwd<bf16_t, 2, 1>(a, B, has_up, has_down, st);
+    if (R == 32) return launch_layer_bwd<bf16_t, 1>(a, B, up, gin, down, use_dcs, st);
+    if (R == 64) return launch_layer_bwd<bf16_t, 2>(a, B, up, gin, down, use_dcs, st);
   } else if (dtype == SRWN_F32) {
-    if (R == 32) return launch_layer_bwd<float, 1, 1>(a, B, has_up, has_down, st);
-    if (R == 64) return launch_layer_bwd<float, 2, 1>(a, B, has_up, has_down, st);
+    if (R == 32) return launch_layer_bwd<float, 1>(a, B, up, gin, down, use_dcs, st);
+    if (R == 64) return launch_layer_bwd<float, 2>(a, B, up, gin, down, use_dcs, st);
   } else {
     return set_error(SRWN_E_DTYPE, "residual_layer_bwd: dtype %d", dtype);
   }

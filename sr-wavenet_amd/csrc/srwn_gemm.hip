@@ -188,6 +188,108 @@ __global__ __launch_bounds__(256, (EPI == SRWN_EPI_SOFTMAX_CE) ? 1 : 2) void row
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Output-streaming GEMM: the skip-path data gradient of EVERY layer in one launch
+//   dcs[l][row][n] = sum_s dtotal[row][s] * Ws_l[n][s]          (autodiff of ops.py:44 for all l)
+// Each wave keeps its 32 rows of dtotal as B fragments in registers for the whole kernel (loaded
+// once), the per-layer weight images [R/32][S/16] stream through LDS (LDS-DMA, double-buffered in
+// bf16 mode), and every layer's [32 x R] result leaves as whole rows.  This moves 2*R*S flop/sample
+// per layer out of the latency-bound per-layer backward kernels into one MFMA-dense pass.
+// ------------------------------------------------------------------------------------------
+struct CgArgs {
+  const void* x; int64_t x_row_stride; const void* wpack; void* y; int64_t y_layer_stride; int nlayers; int64_t rows;
+};
+
+template <typename T, int RT, int KSS, int NBUF>
+__global__ __launch_bounds__(256) void colgemm_kernel(CgArgs a) {
+  constexpr int R = 32 * RT;
+  constexpr int FB = sizeof(Frag<T>) * 64;
+  constexpr int CHUNK_B = RT * KSS * FB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [NBUF][CHUNK_B] weights | 4 row stages
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int col = lane & 31, half = lane >> 5;
+  T* stage = reinterpret_cast<T*>(smem + NBUF * CHUNK_B) + wave * (32 * RowStage<T>::stride(R));
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
+  const int64_t row = row0 + col;
+  const bool valid = row < a.rows;
+  const int rows_valid = (a.rows - row0) < 32 ? (int)(a.rows - row0) : 32;   // may be <= 0 for idle waves
+  const char* wbase = reinterpret_cast<const char*>(a.wpack);
+
+  lds_dma_copy(wbase, smem, CHUNK_B, wave, lane, 4);
+  Frag<T> bf[KSS];
+  {
+    const T* p = reinterpret_cast<const T*>(a.x) + (valid ? row : 0) * a.x_row_stride + 8 * half;
+#pragma unroll
+    for (int ks = 0; ks < KSS; ++ks) bf[ks] = load_nat(p + 16 * ks);
+#pragma unroll
+    for (int ks = 0; ks < KSS; ++ks) bf[ks] = valid ? bf[ks] : zero_frag<T>();
+  }
+  __syncthreads();
+  for (int l = 0; l < a.nlayers; ++l) {
+    const int buf = (NBUF == 2) ? (l & 1) : 0;
+    if (NBUF == 2 && l + 1 < a.nlayers)
+      lds_dma_copy(wbase + (size_t)(l + 1) * CHUNK_B, smem + ((l + 1) & 1) * CHUNK_B, CHUNK_B, wave, lane, 4);
+    const Frag<T>* lw = reinterpret_cast<const Frag<T>*>(smem + buf * CHUNK_B) + lane;
+    f32x16 acc[RT];
+#pragma unroll
+    for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[mt][q] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < KSS; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < RT; ++mt) {
+        const Frag<T> af = lw[(mt * KSS + ks) * 64];
+        mma(acc[mt], af, bf[ks]);
+      }
+    float v[RT][16];
+#pragma unroll
+    for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v[mt][q] = acc[mt][q];
+    T* ytile = reinterpret_cast<T*>(a.y) + (int64_t)l * a.y_layer_stride + (rows_valid > 0 ? row0 : 0) * R;
+    store_rows_via_lds<T, RT>(stage, ytile, R, v, rows_valid, lane);
+    __syncthreads();
+    if (NBUF == 1 && l + 1 < a.nlayers) {
+      lds_dma_copy(wbase + (size_t)(l + 1) * CHUNK_B, smem, CHUNK_B, wave, lane, 4);
+      __syncthreads();
+    }
+  }
+}
+
+template <typename T, int RT, int KSS, int NBUF>
+static int launch_cg(const CgArgs& a, hipStream_t st) {
+  constexpr int R = 32 * RT;
+  const size_t sh = (size_t)NBUF * RT * KSS * sizeof(Frag<T>) * 64 + (size_t)4 * 32 * RowStage<T>::stride(R) * sizeof(T);
+  auto kfn = colgemm_kernel<T, RT, KSS, NBUF>;
+  hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+  if (e != hipSuccess) return set_error((int)e, "skip_dgrad_all: LDS %zu: %s", sh, hipGetErrorString(e));
+  hipLaunchKernelGGL(kfn, dim3((unsigned)((a.rows + 127) / 128)), dim3(256), sh, st, a);
+  return check_launch("skip_dgrad_all");
+}
+
+extern "C" int srwn_skip_dgrad_all(const void* dtotal, const void* wskipT_all, void* dcs, int64_t dcs_layer_stride,
+                                   int32_t nlayers, int64_t rows, int32_t R, int32_t S, int32_t dtype, void* stream) {
+  if (rows == 0 || nlayers == 0) return 0;
+  if (!dtotal || !wskipT_all || !dcs) return set_error(SRWN_E_NULL, "skip_dgrad_all: null pointer");
+  if (rows < 0 || nlayers < 0) return set_error(SRWN_E_SHAPE, "skip_dgrad_all: rows=%lld layers=%d", (long long)rows, nlayers);
+  CgArgs a{dtotal, S, wskipT_all, dcs, dcs_layer_stride, nlayers, rows};
+  hipStream_t st = (hipStream_t)stream;
+  if (R == 64 && S == 256) {
+    if (dtype == SRWN_BF16) return launch_cg<bf16_t, 2, 16, 2>(a, st);
+    if (dtype == SRWN_F32) return launch_cg<float, 2, 16, 1>(a, st);
+    return set_error(SRWN_E_DTYPE, "skip_dgrad_all: dtype %d", dtype);
+  }
+  if (R == 32 && S == 128) {
+    if (dtype == SRWN_BF16) return launch_cg<bf16_t, 1, 8, 2>(a, st);
+    if (dtype == SRWN_F32) return launch_cg<float, 1, 8, 2>(a, st);
+    return set_error(SRWN_E_DTYPE, "skip_dgrad_all: dtype %d", dtype);
+  }
+  return set_error(SRWN_E_UNSUPPORTED, "skip_dgrad_all: built for (R,S) = (64,256) and (32,128), got (%d,%d)", R, S);
+}
+
 namespace srwn {
 
 template <typename T, int MT, int KSC>

@@ -112,7 +112,8 @@ class WaveNetEngine:
             self._build_packing()
         else:   # another (batch, length) view of the same model: parameters, moments, images are shared
             for a in ("sections", "nparams", "params", "grads", "adam_m", "adam_v", "adam_step", "dead_gate",
-                      "packer", "packed", "o_conv", "o_res", "o_convT", "o_resT", "o_skipT", "o_skip", "o_w1", "o_w2",
+                      "packer", "packed", "o_conv", "o_res", "o_convT", "o_resT", "o_skipT", "o_skipT_all", "o_skip",
+                      "o_w1", "o_w2",
                       "o_w1T", "o_w2T"):
                 setattr(self, a, getattr(share_from, a))
             if self.E:
@@ -266,7 +267,12 @@ class WaveNetEngine:
             self.o_res.append(P.pack_res(pk, sec["WR"].offset + l * R * R, R))
             self.o_convT.append(P.pack_conv_T(pk, sec["WF"].offset + l * Kw * R * R, Kw, R))
             self.o_resT.append(P.pack_linear_T(pk, sec["WR"].offset + l * R * R, R, R, R, perm=True))
-            self.o_skipT.append(P.pack_linear_T(pk, sec["WS"].offset + l * R * S, R, S, R))
+        # transposed skip kernels of all layers back to back (srwn_skip_dgrad_all streams them in order)
+        per = (R // 32) * (S // 16) * 512
+        self.o_skipT_all = pk.reserve(L * (R // 32), S // 16)
+        for l in range(L):
+            P.fill_linear_T(pk, self.o_skipT_all + l * per, sec["WS"].offset + l * R * S, R, S, R // 32, S // 16)
+            self.o_skipT.append(self.o_skipT_all + l * per)
         # all skip 1x1s as one image: rows = skip channel, k = layer*R + n
         self.o_skip = pk.reserve(S // 32, L * R // 16)
         for l in range(L):
@@ -304,6 +310,9 @@ class WaveNetEngine:
         self.zs = z(L, B, T, R)
         self.dfs = z(L, B, T, R)
         self.gs = z(L + 1, B, T, R)   # gs[L] is never written: the last dense output is unused
+        self.use_dcs = (R, S) in ((64, 256), (32, 128))
+        if self.use_dcs:
+            self.dcs = z(L, B, T, R)  # Ws_l . dtotal of every layer (one output-streaming GEMM)
         self.r0 = z(N, S); self.r1 = z(N, S); self.da1 = z(N, S); self.dtotal = z(N, S)
         self.dlogits = z(N, Cp)
         self.bs_sum = z(S, dt=torch.float32)
@@ -432,6 +441,9 @@ class WaveNetEngine:
                             aux=self.r1, epi=K.EPI_MASK)
             K.pw_linear(self.da1.data_ptr(), S, 0, S, S, self.wptr(self.o_w1T), None, self.dtotal, S, S, N,
                         aux=self.r0, epi=K.EPI_MASK)
+        if self.use_dcs:
+            with _Span(self, "skip_dgrad_all"):
+                K.skip_dgrad_all(self.dtotal, self.wptr(self.o_skipT_all), self.dcs.view(L, N, R), R, S)
         # ---- residual stack, top down
         span = _Span(self, "bwd_layers").__enter__()
         for l in range(L - 1, -1, -1):
@@ -440,9 +452,11 @@ class WaveNetEngine:
             K.residual_layer_bwd(g_in, self.dfs[l + 1] if has_up else None,
                                  self.wptr(self.o_convT[l + 1]) if has_up else None,
                                  self.gs[l + 1] if has_up else None,
-                                 self.wptr(self.o_resT[l]) if has_up else None, self.wptr(self.o_skipT[l]),
-                                 self.dtotal, self.zs[l], self.dfs[l], B, T, R, S, Kw,
-                                 self.dil[l + 1] if has_up else 1, has_up, True, dt)
+                                 self.wptr(self.o_resT[l]) if has_up else None,
+                                 None if self.use_dcs else self.wptr(self.o_skipT[l]),
+                                 None if self.use_dcs else self.dtotal, self.zs[l], self.dfs[l], B, T, R, S, Kw,
+                                 self.dil[l + 1] if has_up else 1, has_up, True, dt,
+                                 dcs=self.dcs[l] if self.use_dcs else None)
         K.residual_layer_bwd(self.gs[1] if L > 1 else None, self.dfs[0], self.wptr(self.o_convT[0]), self.gs[0],
                              None, None, None, None, None, B, T, R, S, Kw, self.dil[0], True, False, dt)
         span.__exit__()

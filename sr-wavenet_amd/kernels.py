@@ -223,8 +223,9 @@ def residual_layer_bwd(g_in: Optional[torch.Tensor], df_up: Optional[torch.Tenso
                        g_out: Optional[torch.Tensor], wresT_ptr: Optional[int], wskipT_ptr: Optional[int],
                        dtotal: Optional[torch.Tensor], z: Optional[torch.Tensor], df_out: Optional[torch.Tensor],
                        B: int, T: int, R: int, S: int, K: int, dilation_up: int, has_up: bool, has_down: bool,
-                       dtype: torch.dtype):
+                       dtype: torch.dtype, dcs: Optional[torch.Tensor] = None):
     shp = (B, T, R)
+    pdc = _opt(dcs, "dcs", dtype, shp)
     pg = _opt(g_in, "g_in", dtype, shp)
     pdu = _opt(df_up, "df_up", dtype, shp)
     pgo = _opt(g_out, "g_out", dtype, shp)
@@ -235,8 +236,17 @@ def residual_layer_bwd(g_in: Optional[torch.Tensor], df_up: Optional[torch.Tenso
         pdt = _chk(dtotal, "dtotal", dtype)
         if dtotal.numel() != B * T * S:
             raise ValueError("dtotal: %d elements, expected %d" % (dtotal.numel(), B * T * S))
-    call("srwn_residual_layer_bwd", pg, pdu, wconvT_up_ptr, pgo, wresT_ptr, wskipT_ptr, pdt, pz, pdo, B, T, R, S, K,
+    call("srwn_residual_layer_bwd", pg, pdu, wconvT_up_ptr, pgo, wresT_ptr, wskipT_ptr, pdt, pdc, pz, pdo, B, T, R, S, K,
          int(dilation_up), int(has_up), int(has_down), abi_dtype(dtype), _stream())
+
+
+def skip_dgrad_all(dtotal: torch.Tensor, wskipT_all_ptr: int, dcs: torch.Tensor, R: int, S: int):
+    """dcs[l] = dtotal @ Ws_l^T for every layer (dcs: [L, rows, R])."""
+    L, rows, R2 = dcs.shape
+    if R2 != R or dtotal.numel() != rows * S:
+        raise ValueError("skip_dgrad_all: dcs %s / dtotal %s" % (tuple(dcs.shape), tuple(dtotal.shape)))
+    call("srwn_skip_dgrad_all", _chk(dtotal, "dtotal", dcs.dtype), wskipT_all_ptr, _chk(dcs, "dcs"), rows * R, L, rows,
+         R, S, abi_dtype(dcs.dtype), _stream())
 
 
 def wgrad_slabs(rows: int) -> int:

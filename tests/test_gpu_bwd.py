@@ -16,8 +16,8 @@ def _gate_grad(z):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("R,S", [(64, 256), (32, 64)])
-@pytest.mark.parametrize("B,T,d_up", [(2, 64, 1), (1, 100, 8), (2, 300, 64), (1, 50, 128)])
+@pytest.mark.parametrize("R,S", [(64, 256), (32, 64), (32, 128)])
+@pytest.mark.parametrize("B,T,d_up", [(2, 64, 1), (1, 100, 8), (2, 300, 64), (1, 50, 128), (3, 1000, 16)])
 def test_residual_layer_bwd(dt, R, S, B, T, d_up):
     K = sub("kernels"); P = sub("packing")
     rng = np.random.default_rng(R + T + d_up)
@@ -49,6 +49,27 @@ def test_residual_layer_bwd(dt, R, S, B, T, d_up):
     dc = (G * O.SQRT_HALF) @ wq(wr).T + q(dtotal) @ wq(ws).T
     df = dc * _gate_grad(q(z))
     assert rel_err(q(df_out), df) < TOL[dt]
+    # same through the precomputed skip term (srwn_skip_dgrad_all), two "layers" sharing dtotal
+    if (R, S) in ((64, 256), (32, 128)):
+        ws2 = rng.standard_normal((R, S)) / np.sqrt(S)
+        flat2 = torch.cat([dev(ws).flatten(), dev(ws2).flatten()])
+        pk2 = K.Packer(DEV)
+        o_all = pk2.reserve(2 * (R // 32), S // 16)
+        per = (R // 32) * (S // 16) * 512
+        P.fill_linear_T(pk2, o_all, 0, R, S, R // 32, S // 16)
+        P.fill_linear_T(pk2, o_all + per, R * S, R, S, R // 32, S // 16)
+        pk2.finalize()
+        buf2 = torch.empty(pk2.total, dtype=dt, device=DEV); pk2.gather(flat2, buf2)
+        dcs = torch.full((2, B * T, R), float("nan"), dtype=dt, device=DEV)
+        K.skip_dgrad_all(dtotal, buf2.data_ptr() + o_all * es, dcs, R, S)
+        assert rel_err(q(dcs[0]).reshape(B, T, R), q(dtotal) @ wq(ws).T) < TOL[dt]
+        assert rel_err(q(dcs[1]).reshape(B, T, R), q(dtotal) @ wq(ws2).T) < TOL[dt]
+        g3 = torch.full_like(g_out, float("nan")); df3 = torch.full_like(g_out, float("nan"))
+        K.residual_layer_bwd(g_in, df_up, base + oc * es, g3, base + orr * es, None, None, z, df3, B, T, R, S, 2, d_up,
+                             True, True, dt, dcs=dcs[0].view(B, T, R))
+        assert rel_err(q(g3), G) < TOL[dt]
+        dc3 = (G * O.SQRT_HALF) @ wq(wr).T + q(dcs[0]).reshape(B, T, R)
+        assert rel_err(q(df3), dc3 * _gate_grad(q(z))) < TOL[dt]
     # DOWN only (top layer) and UP only (below layer 0)
     df2 = torch.full_like(df_out, float("nan"))
     K.residual_layer_bwd(None, None, None, None, None, base + osk * es, dtotal, z, df2, B, T, R, S, 2, 1, False, True, dt)

@@ -63,6 +63,13 @@ def main():
                                                          eng.wptr(eng.o_skipT[10]), eng.dtotal, eng.zs[10],
                                                          eng.dfs[10], B, T, R, S, 2, eng.dil[11], True, True, dt),
                             2.0 * N * (2 * R * R + R * R + R * S), N * (R * 2 * 6 + S * 2)),
+        "layer_bwd_dcs(l=10)": (lambda: K.residual_layer_bwd(eng.gs[12], eng.dfs[11], eng.wptr(eng.o_convT[11]),
+                                                             eng.gs[11], eng.wptr(eng.o_resT[10]), None, None,
+                                                             eng.zs[10], eng.dfs[10], B, T, R, S, 2, eng.dil[11],
+                                                             True, True, dt, dcs=eng.dcs[10]),
+                                2.0 * N * (2 * R * R + R * R), N * R * 2 * 6),
+        "skip_dgrad_all": (lambda: K.skip_dgrad_all(eng.dtotal, eng.wptr(eng.o_skipT_all), eng.dcs.view(L, N, R), R, S),
+                           2.0 * N * L * R * S, N * (L * R + S) * 2),
         "wgrad_skip(30)": (lambda: K.wgrad(eng.zs.data_ptr(), NR, R, eng.dtotal.data_ptr(), 0, S, None, L,
                                            eng.wg_parts, eng.wg_bparts, N, T, eng.nslabs, dt, pro=K.PRO_GATE),
                            2.0 * N * L * R * S, N * L * R * 2 + N * S * 2),
