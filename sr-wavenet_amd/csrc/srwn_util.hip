@@ -205,30 +205,54 @@ template <typename T>
 __global__ __launch_bounds__(256) void init_conv_wgrad_stage1(const float* __restrict__ audio,
                                                               const T* __restrict__ g, float* __restrict__ partials,
                                                               int B, int Tlen, int R, int K, int shift) {
-  // thread = (channel o = tid % R, row group rg = tid / R); R in {32, 64, 128}
-  extern __shared__ float red[];  // [256 / R][(K+1)*R]
-  const int o = threadIdx.x % R, rg = threadIdx.x / R, ngrp = 256 / R;
+  // thread = (8-channel group cg, row group rg): 16-byte loads of g, K+1 running sums per channel
+  extern __shared__ float red[];  // [nrg][(K+1)*R]
+  const int ncg = R / 8, nrg = 256 / ncg;
+  const int cg = threadIdx.x % ncg, rg = threadIdx.x / ncg;
   const int64_t rows = (int64_t)B * Tlen;
   const int64_t r0 = (int64_t)blockIdx.x * kIcRows;
-  float acc[9];  // K <= 8
+  float acc[9][8];  // K <= 8
 #pragma unroll
-  for (int k = 0; k < 9; ++k) acc[k] = 0.0f;
-  for (int rr = rg; rr < kIcRows; rr += ngrp) {
-    int64_t row = r0 + rr;
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[k][e] = 0.0f;
+  for (int rr = rg; rr < kIcRows; rr += nrg) {
+    const int64_t row = r0 + rr;
     if (row >= rows) break;
-    int t = (int)(row % Tlen);
-    float gv = (float)g[row * R + o];
-    acc[K] += gv;
-    for (int k = 0; k < K; ++k) {
-      int tk = t - (K - 1 - k) - shift;
-      if (tk >= 0) acc[k] = fmaf(audio[row - t + tk], gv, acc[k]);
+    const int t = (int)(row % Tlen);
+    float gv[8];
+    const T* gp = g + row * R + cg * 8;
+    if (sizeof(T) == 2) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(gp);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gv[e] = (float)v[e];
+    } else {
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(gp), v1 = *reinterpret_cast<const f32x4*>(gp + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { gv[e] = v0[e]; gv[4 + e] = v1[e]; }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      if (k > K) break;
+      float xv = 1.0f;                       // k == K: bias gradient (sum of g)
+      if (k < K) {
+        const int tk = t - (K - 1 - k) - shift;
+        xv = (tk >= 0) ? audio[row - t + tk] : 0.0f;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[k][e] = fmaf(xv, gv[e], acc[k][e]);
     }
   }
-  for (int k = 0; k <= K; ++k) red[(rg * (K + 1) + k) * R + o] = acc[k];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    if (k > K) break;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[(rg * (K + 1) + k) * R + cg * 8 + e] = acc[k][e];
+  }
   __syncthreads();
   for (int i = threadIdx.x; i < (K + 1) * R; i += 256) {
     float s = 0.0f;
-    for (int q = 0; q < ngrp; ++q) s += red[q * (K + 1) * R + i];
+    for (int q = 0; q < nrg; ++q) s += red[q * (K + 1) * R + i];
     partials[(int64_t)blockIdx.x * (K + 1) * R + i] = s;
   }
 }
@@ -255,7 +279,8 @@ extern "C" int srwn_init_conv_wgrad(const float* audio, const void* g, float* pa
     return set_error(SRWN_E_SHAPE, "init_conv_wgrad: B=%d T=%d R=%d K=%d", B, T, R, K);
   int64_t rows = (int64_t)B * T;
   int64_t nparts = (rows + kIcRows - 1) / kIcRows;
-  size_t sh = (size_t)(256 / R) * (K + 1) * R * sizeof(float);
+  size_t sh = (size_t)(256 / (R / 8)) * (K + 1) * R * sizeof(float);
+  if (sh > 65536) return set_error(SRWN_E_UNSUPPORTED, "init_conv_wgrad: K=%d too large for the reduction buffer", K);
   if (dtype == SRWN_F32)
     hipLaunchKernelGGL(init_conv_wgrad_stage1<float>, dim3((unsigned)nparts), dim3(256), sh, (hipStream_t)stream,
                        audio, (const float*)g, partials, B, T, R, K, shift);

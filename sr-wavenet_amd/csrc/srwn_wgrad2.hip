@@ -53,18 +53,23 @@ constexpr int kRows = 32;      // rows per staged chunk
 constexpr int kW = 256;        // tile width (channels) of both operands
 constexpr int kStride = 288;   // LDS row stride in elements: 576 B (bf16) puts 4 consecutive rows on disjoint banks
 
-template <typename T, int PRO>
+template <typename T, int PRO, int MB>
 __global__ __launch_bounds__(512) void wgrad256_kernel(Wg2Args a) {
+  constexpr int NTW = (MB == 4) ? 4 : 1;   // n-tiles per wave
+  constexpr int AW = MB * 64;                // staged A tile width (channels)
   constexpr int VEC = 16 / sizeof(T);
-  constexpr int VPR = kW / VEC;                  // 16-byte vectors per tile row
-  constexpr int NV = kRows * VPR / 512;          // vectors per thread per tile (2 bf16, 4 f32)
+  constexpr int VPR = kW / VEC;                  // 16-byte vectors per D tile row
+  constexpr int NV = kRows * VPR / 512;          // D vectors per thread (2 bf16, 4 f32)
+  constexpr int VPRA = AW / VEC;                 // 16-byte vectors per A tile row
+  constexpr int NVA = (kRows * VPRA + 511) / 512;  // A vectors per thread
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* lds = reinterpret_cast<T*>(smem);           // [2 buffers][A tile | D tile][kRows][kStride]
   auto tileA = [&](int buf) { return lds + (size_t)(buf * 2 + 0) * kRows * kStride; };
   auto tileD = [&](int buf) { return lds + (size_t)(buf * 2 + 1) * kRows * kStride; };
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;       // wave -> 64 m-channels (one A chunk) x 128 n-channels
+  const int wm = (MB == 4) ? (wave >> 1) : 0;    // wave -> A chunk
+  const int wn = (MB == 4) ? (wave & 1) : wave;  // wave -> group of NTW n-tiles
   const int slab = blockIdx.x, mblk = blockIdx.y;
   const int64_t r_begin = (int64_t)slab * a.rows_per_slab;
   const int64_t r_end = (r_begin + a.rows_per_slab < a.rows) ? r_begin + a.rows_per_slab : a.rows;
@@ -72,30 +77,35 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(Wg2Args a) {
   const T* abase = reinterpret_cast<const T*>(a.a);
   const T* dbase = reinterpret_cast<const T*>(a.d);
 
-  f32x16 acc[2][4];
+  f32x16 acc[2][NTW];
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
-    for (int n = 0; n < 4; ++n)
+    for (int n = 0; n < NTW; ++n)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[m][n][q] = 0.0f;
   float bsum = 0.0f;
   const bool do_bias = (a.bias_partials != nullptr) && (mblk == 0) && (tid < kW);
 
-  f32x4 ra[NV], rd[NV];   // raw 16-byte vectors in flight (bit containers)
+  f32x4 ra[NVA], rd[NV];   // raw 16-byte vectors in flight (bit containers)
   auto gload = [&](int it) {
     const int64_t r0 = r_begin + (int64_t)it * kRows;
+#pragma unroll
+    for (int v = 0; v < NVA; ++v) {
+      const int idx = tid + v * 512;
+      const int rr = idx / VPRA, cv = (idx % VPRA) * VEC;
+      const int64_t row = r0 + rr;
+      const int chunk = mblk * MB + cv / 64;
+      const bool ok = (idx < kRows * VPRA) && (row < r_end) && (chunk < a.m_chunks);
+      ra[v] = ok ? *reinterpret_cast<const f32x4*>(abase + (int64_t)chunk * a.a_chunk_stride + row * a.a_row_stride + (cv & 63))
+                 : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       const int idx = tid + v * 512;
       const int rr = idx / VPR, cv = (idx % VPR) * VEC;
       const int64_t row = r0 + rr;
-      const int chunk = mblk * 4 + cv / 64;
-      const bool okr = row < r_end;
-      ra[v] = (okr && chunk < a.m_chunks)
-                  ? *reinterpret_cast<const f32x4*>(abase + (int64_t)chunk * a.a_chunk_stride + row * a.a_row_stride + (cv & 63))
-                  : f32x4{0.f, 0.f, 0.f, 0.f};
-      rd[v] = okr ? *reinterpret_cast<const f32x4*>(dbase + row * a.d_row_stride + cv) : f32x4{0.f, 0.f, 0.f, 0.f};
+      rd[v] = (row < r_end) ? *reinterpret_cast<const f32x4*>(dbase + row * a.d_row_stride + cv) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
   auto lstore = [&](int buf) {
@@ -104,6 +114,13 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(Wg2Args a) {
     for (int v = 0; v < NV; ++v) {
       const int idx = tid + v * 512;
       const int rr = idx / VPR, cv = (idx % VPR) * VEC;
+      *reinterpret_cast<f32x4*>(td + rr * kStride + cv) = rd[v];
+    }
+#pragma unroll
+    for (int v = 0; v < NVA; ++v) {
+      const int idx = tid + v * 512;
+      if (idx >= kRows * VPRA) continue;
+      const int rr = idx / VPRA, cv = (idx % VPRA) * VEC;
       f32x4 x = ra[v];
       if (PRO == SRWN_PRO_GATE) {
         if (sizeof(T) == 2) {
@@ -117,7 +134,6 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(Wg2Args a) {
         }
       }
       *reinterpret_cast<f32x4*>(ta + rr * kStride + cv) = x;
-      *reinterpret_cast<f32x4*>(td + rr * kStride + cv) = rd[v];
     }
   };
 
@@ -136,29 +152,29 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(Wg2Args a) {
     }
 #pragma unroll
     for (int ks = 0; ks < kRows / 16; ++ks) {
-      Frag<T> af[2], bf[4];
+      Frag<T> af[2], bf[NTW];
 #pragma unroll
       for (int m = 0; m < 2; ++m) af[m] = Ld2<T>::load(ta, kStride, 16 * ks, wm * 64 + 32 * m, lane);
 #pragma unroll
-      for (int n = 0; n < 4; ++n) bf[n] = Ld2<T>::load(td, kStride, 16 * ks, wn * 128 + 32 * n, lane);
+      for (int n = 0; n < NTW; ++n) bf[n] = Ld2<T>::load(td, kStride, 16 * ks, (wn * NTW + n) * 32, lane);
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) mma(acc[m][n], af[m], bf[n]);
+        for (int n = 0; n < NTW; ++n) mma(acc[m][n], af[m], bf[n]);
     }
     if (it + 1 < nit) lstore(buf ^ 1);
     __syncthreads();
   }
 
   const int col = lane & 31, half = lane >> 5;
-  const int chunk = mblk * 4 + wm;
+  const int chunk = mblk * MB + wm;
   if (chunk < a.m_chunks) {
     float* pbase = a.partials + ((int64_t)slab * a.m_chunks * 64 + (int64_t)chunk * 64) * kW;
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        const int o = wn * 128 + 32 * n + col;
+      for (int n = 0; n < NTW; ++n) {
+        const int o = (wn * NTW + n) * 32 + col;
 #pragma unroll
         for (int q = 0; q < 16; ++q) pbase[(int64_t)(32 * m + crow(q, half)) * kW + o] = acc[m][n][q];
       }
@@ -168,8 +184,11 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(Wg2Args a) {
 
 }  // namespace
 
+static int wg2_chunks_per_block(int m_chunks) { return m_chunks >= 8 ? 4 : 1; }
+
 extern "C" int32_t srwn_wgrad256_slabs(int64_t rows, int32_t m_chunks) {
-  const int mblocks = (m_chunks + 3) / 4;
+  const int mb = wg2_chunks_per_block(m_chunks);
+  const int mblocks = (m_chunks + mb - 1) / mb;
   int64_t target = 256 / (mblocks > 0 ? mblocks : 1);
   if (target < 1) target = 1;
   int64_t maxs = (rows + 255) / 256;   // at least 256 rows per slab
@@ -189,11 +208,14 @@ extern "C" int srwn_wgrad256(const void* a, int64_t a_chunk_stride, int64_t a_ro
   int64_t rps = (rows + nslabs - 1) / nslabs;
   rps = (rps + kRows - 1) / kRows * kRows;
   g.rows_per_slab = (int)rps;
-  dim3 grid((unsigned)nslabs, (unsigned)((m_chunks + 3) / 4)), block(512);
+  const int mb = wg2_chunks_per_block(m_chunks);
+  dim3 grid((unsigned)nslabs, (unsigned)((m_chunks + mb - 1) / mb)), block(512);
   hipStream_t st = (hipStream_t)stream;
 #define SRWN_W2(TT, P)                                                                                        \
+  if (mb == 4) SRWN_W2B(TT, P, 4) else SRWN_W2B(TT, P, 1)
+#define SRWN_W2B(TT, P, MBV)                                                                                  \
   {                                                                                                           \
-    auto kfn = wgrad256_kernel<TT, P>;                                                                        \
+    auto kfn = wgrad256_kernel<TT, P, MBV>;                                                                   \
     const size_t sh = (size_t)4 * kRows * kStride * sizeof(TT);                                               \
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
     if (e != hipSuccess) return set_error((int)e, "wgrad256: LDS %zu: %s", sh, hipGetErrorString(e));         \
@@ -210,5 +232,6 @@ extern "C" int srwn_wgrad256(const void* a, int64_t a_chunk_stride, int64_t a_ro
     return set_error(SRWN_E_DTYPE, "wgrad256: dtype %d", dtype);
   }
 #undef SRWN_W2
+#undef SRWN_W2B
   return set_error(SRWN_E_UNSUPPORTED, "wgrad256: pro %d", pro);
 }
