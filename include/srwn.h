@@ -192,6 +192,18 @@ int srwn_wgrad256(const void* a, int64_t a_chunk_stride, int64_t a_row_stride, i
 int srwn_skip_dgrad_all(const void* dtotal, const void* wskipT_all, void* dcs, int64_t dcs_layer_stride,
                         int32_t nlayers, int64_t rows, int32_t R, int32_t S, int32_t dtype, void* stream);
 
+/* ---- all per-layer weight gradients of ResidualDilationLayer (ops.py:27,39) in one pass over the
+ * saved tensors, batched over layers ([L][rows][64] stacks, `layer_stride` elements apart; R=64, K=2):
+ *   part_f [l][slab][k*64+i][o] = sum x_l[t-(1-k)*d_l, i] * df_l[t, o]   (x_l + cond_l when cond != NULL)
+ *   part_r [l][slab][n][m]      = sum c_l[t, n] * g_l[t, m]              (c = z sigmoid z; g_l = G_{l+1})
+ *   part_bf[l][slab][o] = sum df_l[t,o];  part_br[l][slab][m] = sum g_l[t,m]
+ * dilations: host array [nlayers].  Finish with srwn_reduce_partials (sqrt(.5) on the residual pair). */
+int srwn_wgrad_layers(const void* x, const void* z, const void* df, const void* g, int64_t layer_stride,
+                      const void* cond, int64_t cond_layer_stride, int32_t cond_frames, int32_t pool_stride,
+                      int32_t cond_row_stride, const int32_t* dilations, int32_t nlayers, float* part_f,
+                      float* part_r, float* part_bf, float* part_br, int64_t rows, int32_t T, int32_t nslabs,
+                      int32_t R, int32_t K, int32_t dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -235,3 +235,207 @@ extern "C" int srwn_wgrad256(const void* a, int64_t a_chunk_stride, int64_t a_ro
 #undef SRWN_W2B
   return set_error(SRWN_E_UNSUPPORTED, "wgrad256: pro %d", pro);
 }
+
+// ------------------------------------------------------------------------------------------
+// Per-layer weight gradients of the residual layer in ONE pass over the saved tensors, batched over
+// layers (grid.y):   dWf_l[k] = x_l[t-(K-1-k)d]^T . df_l      (K = 2 taps; x_l optionally + cond)
+//                    dbf_l    = colsum(df_l)
+//                    dWr_l    = c_l^T . G_{l+1}               (c = z sigmoid(z); scaled by sqrt(.5) at reduce)
+//                    dbr_l    = colsum(G_{l+1})
+// x, z, df, G are each read once (the separate per-product kernels read x and df twice and z again).
+// One workgroup = 4 waves over one slab of rows of one layer; 32-row chunks register-staged into LDS
+// (one barrier per chunk), fragments by transposing LDS reads.  Wave w owns conv row tile w
+// (rows 32w..32w+31 of [x(t-d) | x(t)]) x both df column tiles, and dWr tile (w>>1, w&1).
+// ------------------------------------------------------------------------------------------
+struct WgLArgs {
+  const void* x; const void* z; const void* df; const void* g; int64_t layer_stride;   // [L][rows][64]
+  const void* cond; int64_t cond_layer_stride; int cond_frames; int pool; int cond_stride;
+  float* part_f; float* part_r; float* part_bf; float* part_br;   // [L][ns][2*64*64], [L][ns][64*64], [L][ns][64] x2
+  int64_t rows; int Tlen; int rows_per_slab; int nslabs;
+  int dil[64];
+};
+
+namespace {
+
+constexpr int kLA = 192 + 16;   // LDS row stride of the A tile [x(t-d) | x(t) | c] in elements (16-B multiple)
+constexpr int kLD = 128 + 16;   // LDS row stride of the D tile [df | G]
+
+template <typename T, bool COND>
+__global__ __launch_bounds__(256) void wgrad_layer_kernel(WgLArgs a) {
+  constexpr int VEC = 16 / sizeof(T);
+  constexpr int VPC = 64 / VEC;                 // 16-byte vectors per 64-channel row
+  constexpr int NV = kRows * VPC / 256;         // vectors per thread per 64-wide tensor tile (1 bf16, 2 f32)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* lds = reinterpret_cast<T*>(smem);          // [2 buffers][A tile kRows x kLA | D tile kRows x kLD]
+  auto tileA = [&](int buf) { return lds + (size_t)buf * kRows * (kLA + kLD); };
+  auto tileD = [&](int buf) { return lds + (size_t)buf * kRows * (kLA + kLD) + kRows * kLA; };
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int slab = blockIdx.x, layer = blockIdx.y;
+  const int d = a.dil[layer];
+  const int64_t r_begin = (int64_t)slab * a.rows_per_slab;
+  const int64_t r_end = (r_begin + a.rows_per_slab < a.rows) ? r_begin + a.rows_per_slab : a.rows;
+  const int nit = (r_end > r_begin) ? (int)((r_end - r_begin + kRows - 1) / kRows) : 0;
+  const T* xb = reinterpret_cast<const T*>(a.x) + (int64_t)layer * a.layer_stride;
+  const T* zb = reinterpret_cast<const T*>(a.z) + (int64_t)layer * a.layer_stride;
+  const T* fb = reinterpret_cast<const T*>(a.df) + (int64_t)layer * a.layer_stride;
+  const T* gb = reinterpret_cast<const T*>(a.g) + (int64_t)layer * a.layer_stride;
+  const T* cb = COND ? reinterpret_cast<const T*>(a.cond) + (int64_t)layer * a.cond_layer_stride : nullptr;
+
+  f32x16 accF[2], accR;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) { accF[0][q] = 0.0f; accF[1][q] = 0.0f; accR[q] = 0.0f; }
+  float bsum = 0.0f;   // threads 0..63: colsum(df); 64..127: colsum(G)
+
+  f32x4 rxd[NV], rxc[NV], rz[NV], rf[NV], rg[NV];
+  f32x4 rcd[COND ? NV : 1], rcc[COND ? NV : 1];
+  bool okd[NV];
+  auto gload = [&](int it) {
+    const int64_t r0 = r_begin + (int64_t)it * kRows;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int idx = tid + v * 256;
+      const int rr = idx / VPC, cv = (idx % VPC) * VEC;
+      const int64_t row = r0 + rr;
+      const bool okr = row < r_end;
+      const int64_t rowc = okr ? row : (a.rows - 1);
+      const int t = (int)(rowc % a.Tlen);
+      okd[v] = okr && (t - d >= 0);
+      const int64_t rowd = (t - d >= 0) ? rowc - d : rowc;
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+      rxd[v] = *reinterpret_cast<const f32x4*>(xb + rowd * 64 + cv);
+      rxc[v] = *reinterpret_cast<const f32x4*>(xb + rowc * 64 + cv);
+      rz[v] = *reinterpret_cast<const f32x4*>(zb + rowc * 64 + cv);
+      rf[v] = *reinterpret_cast<const f32x4*>(fb + rowc * 64 + cv);
+      rg[v] = *reinterpret_cast<const f32x4*>(gb + rowc * 64 + cv);
+      if (COND) {
+        const int64_t bidx = rowc / a.Tlen;
+        const int td = (t - d >= 0) ? t - d : t;
+        rcd[v] = *reinterpret_cast<const f32x4*>(cb + (bidx * a.cond_frames + td / a.pool) * a.cond_stride + cv);
+        rcc[v] = *reinterpret_cast<const f32x4*>(cb + (bidx * a.cond_frames + t / a.pool) * a.cond_stride + cv);
+      }
+      if (!okr) { rxc[v] = zero; rz[v] = zero; rf[v] = zero; rg[v] = zero; }
+    }
+  };
+  auto addc = [&](f32x4 x, f32x4 c) {   // x + c in T precision
+    if (sizeof(T) == 2) {
+      bf16x8 xb_ = __builtin_bit_cast(bf16x8, x), cb_ = __builtin_bit_cast(bf16x8, c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xb_[e] = (bf16_t)((float)xb_[e] + (float)cb_[e]);
+      return __builtin_bit_cast(f32x4, xb_);
+    } else {
+      return x + c;
+    }
+  };
+  auto lstore = [&](int buf) {
+    T* ta = tileA(buf); T* td = tileD(buf);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int idx = tid + v * 256;
+      const int rr = idx / VPC, cv = (idx % VPC) * VEC;
+      f32x4 xd = rxd[v], xc = rxc[v], zc = rz[v];
+      if (COND) { xd = addc(xd, rcd[v]); xc = addc(xc, rcc[v]); }
+      if (!okd[v]) xd = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (sizeof(T) == 2) {
+        bf16x8 b = __builtin_bit_cast(bf16x8, zc);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) b[e] = (bf16_t)gate_of_z<T>((float)b[e]);
+        zc = __builtin_bit_cast(f32x4, b);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) zc[e] = gate_of_z<T>(zc[e]);
+      }
+      *reinterpret_cast<f32x4*>(ta + rr * kLA + cv) = xd;
+      *reinterpret_cast<f32x4*>(ta + rr * kLA + 64 + cv) = xc;
+      *reinterpret_cast<f32x4*>(ta + rr * kLA + 128 + cv) = zc;
+      *reinterpret_cast<f32x4*>(td + rr * kLD + cv) = rf[v];
+      *reinterpret_cast<f32x4*>(td + rr * kLD + 64 + cv) = rg[v];
+    }
+  };
+
+  if (nit > 0) { gload(0); lstore(0); }
+  __syncthreads();
+  for (int it = 0; it < nit; ++it) {
+    const int buf = it & 1;
+    if (it + 1 < nit) gload(it + 1);
+    const T* ta = tileA(buf); const T* td = tileD(buf);
+    if (tid < 128) {
+#pragma unroll 8
+      for (int rr = 0; rr < kRows; ++rr) bsum += (float)td[rr * kLD + tid];
+    }
+#pragma unroll
+    for (int ks = 0; ks < kRows / 16; ++ks) {
+      const Frag<T> a_conv = Ld2<T>::load(ta, kLA, 16 * ks, 32 * wave, lane);           // rows 32w.. of [xd|xc]
+      const Frag<T> a_c = Ld2<T>::load(ta, kLA, 16 * ks, 128 + 32 * (wave >> 1), lane);  // c row tile
+      const Frag<T> b_f0 = Ld2<T>::load(td, kLD, 16 * ks, 0, lane);
+      const Frag<T> b_f1 = Ld2<T>::load(td, kLD, 16 * ks, 32, lane);
+      const Frag<T> b_g = Ld2<T>::load(td, kLD, 16 * ks, 64 + 32 * (wave & 1), lane);
+      mma(accF[0], a_conv, b_f0);
+      mma(accF[1], a_conv, b_f1);
+      mma(accR, a_c, b_g);
+    }
+    if (it + 1 < nit) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  const int col = lane & 31, half = lane >> 5;
+  const int64_t ls = (int64_t)layer * a.nslabs + slab;
+  float* pf = a.part_f + ls * (2 * 64 * 64);   // [k*64 + i][o]: conv row tile w covers rows 32w..32w+31
+  float* pr = a.part_r + ls * (64 * 64);
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) pf[(int64_t)(32 * wave + crow(q, half)) * 64 + 32 * n + col] = accF[n][q];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) pr[(int64_t)(32 * (wave >> 1) + crow(q, half)) * 64 + 32 * (wave & 1) + col] = accR[q];
+  if (tid < 64) a.part_bf[ls * 64 + tid] = bsum;
+  else if (tid < 128) a.part_br[ls * 64 + (tid - 64)] = bsum;
+}
+
+}  // namespace
+
+extern "C" int srwn_wgrad_layers(const void* x, const void* z, const void* df, const void* g, int64_t layer_stride,
+                                 const void* cond, int64_t cond_layer_stride, int32_t cond_frames,
+                                 int32_t pool_stride, int32_t cond_row_stride, const int32_t* dilations,
+                                 int32_t nlayers, float* part_f, float* part_r, float* part_bf, float* part_br,
+                                 int64_t rows, int32_t T, int32_t nslabs, int32_t R, int32_t K, int32_t dtype,
+                                 void* stream) {
+  if (rows == 0 || nlayers == 0) return 0;
+  if (!x || !z || !df || !g || !dilations || !part_f || !part_r || !part_bf || !part_br)
+    return set_error(SRWN_E_NULL, "wgrad_layers: null pointer");
+  if (R != 64 || K != 2) return set_error(SRWN_E_UNSUPPORTED, "wgrad_layers: built for R=64, K=2 (got R=%d K=%d)", R, K);
+  if (nlayers < 0 || nlayers > 64 || rows < 0 || T < 1 || rows % T || nslabs < 1)
+    return set_error(SRWN_E_SHAPE, "wgrad_layers: nlayers=%d rows=%lld T=%d nslabs=%d", nlayers, (long long)rows, T, nslabs);
+  if (cond && (pool_stride < 1 || cond_row_stride < 64 || (int64_t)cond_frames * pool_stride < T))
+    return set_error(SRWN_E_SHAPE, "wgrad_layers: cond frames %d x pool %d < T %d", cond_frames, pool_stride, T);
+  WgLArgs a;
+  a.x = x; a.z = z; a.df = df; a.g = g; a.layer_stride = layer_stride;
+  a.cond = cond; a.cond_layer_stride = cond_layer_stride; a.cond_frames = cond_frames;
+  a.pool = pool_stride > 0 ? pool_stride : 1; a.cond_stride = cond_row_stride;
+  a.part_f = part_f; a.part_r = part_r; a.part_bf = part_bf; a.part_br = part_br;
+  a.rows = rows; a.Tlen = T; a.nslabs = nslabs;
+  int64_t rps = (rows + nslabs - 1) / nslabs;
+  rps = (rps + kRows - 1) / kRows * kRows;
+  a.rows_per_slab = (int)rps;
+  for (int i = 0; i < 64; ++i) a.dil[i] = (i < nlayers) ? dilations[i] : 1;
+  for (int i = 0; i < nlayers; ++i)
+    if (a.dil[i] < 1) return set_error(SRWN_E_SHAPE, "wgrad_layers: dilation %d", a.dil[i]);
+  dim3 grid((unsigned)nslabs, (unsigned)nlayers), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define SRWN_WL(TT, C)                                                                                         \
+  {                                                                                                            \
+    auto kfn = wgrad_layer_kernel<TT, C>;                                                                      \
+    const size_t sh = (size_t)2 * kRows * (kLA + kLD) * sizeof(TT);                                            \
+    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+    if (e != hipSuccess) return set_error((int)e, "wgrad_layers: LDS %zu: %s", sh, hipGetErrorString(e));      \
+    hipLaunchKernelGGL(kfn, grid, block, sh, st, a);                                                           \
+    return check_launch("wgrad_layers");                                                                       \
+  }
+  if (dtype == SRWN_BF16) {
+    if (cond) SRWN_WL(bf16_t, true) else SRWN_WL(bf16_t, false)
+  } else if (dtype == SRWN_F32) {
+    if (cond) SRWN_WL(float, true) else SRWN_WL(float, false)
+  }
+#undef SRWN_WL
+  return set_error(SRWN_E_DTYPE, "wgrad_layers: dtype %d", dtype);
+}

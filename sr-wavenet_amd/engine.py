@@ -328,6 +328,11 @@ class WaveNetEngine:
             self.tm_parts = z(B * int(_l.load().srwn_time_mean_slabs(T)) * S, dt=torch.float32)
         self.nslabs = K.wgrad_slabs(N)
         big = max(L * R * S, S * S, S * Cp, L * self.Kw * R * R)
+        self.use_wl = (R == 64 and self.Kw == 2)
+        if self.use_wl:
+            ns = self.nslabs
+            self.pl_f = z(L * ns * 2 * R * R, dt=torch.float32); self.pl_r = z(L * ns * R * R, dt=torch.float32)
+            self.pl_bf = z(L * ns * R, dt=torch.float32); self.pl_br = z(L * ns * R, dt=torch.float32)
         self.use_w256 = (S == 256 and R == 64)
         if self.use_w256:
             self.ns_skip = K.wgrad256_slabs(N, L)
@@ -463,7 +468,20 @@ class WaveNetEngine:
         # ---- weight gradients
         NR = N * R
         xs_p, zs_p, dfs_p, gs_p = self.xs.data_ptr(), self.zs.data_ptr(), self.dfs.data_ptr(), self.gs.data_ptr()
-        for k in range(Kw):                                                          # dilated conv taps
+        if self.use_wl:
+            # conv taps + 1x1 residual of every layer in one pass over x, z, df, G
+            ckw = {}
+            if self.E:
+                ckw = dict(cond_ptr=self.cond_all.data_ptr(), cond_layer_stride=R, cond_frames=self.frames,
+                           pool_stride=self.cfg.pool_stride, cond_row_stride=L * R)
+            with _Span(self, "wgrad_layers"):
+                K.wgrad_layers(self.xs.view(L + 1, N, R), self.zs.view(L, N, R), self.dfs.view(L, N, R),
+                               gs_p + NR * es, self.dil, self.pl_f, self.pl_r, self.pl_bf, self.pl_br, T, ns, **ckw)
+            K.reduce_partials(self.pl_f, ns, Kw * R * R, L, True, 1.0, gp + 4 * sec["WF"].offset, Kw * R * R)
+            K.reduce_partials(self.pl_bf, ns, R, L, True, 1.0, gp + 4 * sec["BF"].offset, R)
+            K.reduce_partials(self.pl_r, ns, R * R, L, True, SQRT_HALF, gp + 4 * sec["WR"].offset, R * R)
+            K.reduce_partials(self.pl_br, ns, R, L, True, SQRT_HALF, gp + 4 * sec["BR"].offset, R)
+        for k in range(0 if self.use_wl else Kw):                                    # dilated conv taps (legacy)
             shifts = [(Kw - 1 - k) * d for d in self.dil]
             last = k == Kw - 1
             ckw = {}
@@ -476,10 +494,11 @@ class WaveNetEngine:
                               Kw * R * R)
             if last:
                 K.reduce_partials(self.wg_bparts, ns, R, L, True, 1.0, gp + 4 * sec["BF"].offset, R)
-        K.wgrad(zs_p, NR, R, gs_p + NR * es, NR, R, None, L, self.wg_parts, self.wg_bparts, N, T, ns, dt,
-                pro=K.PRO_GATE)                                                       # 1x1 residual
-        K.reduce_partials(self.wg_parts, ns, R * R, L, True, SQRT_HALF, gp + 4 * sec["WR"].offset, R * R)
-        K.reduce_partials(self.wg_bparts, ns, R, L, True, SQRT_HALF, gp + 4 * sec["BR"].offset, R)
+        if not self.use_wl:
+            K.wgrad(zs_p, NR, R, gs_p + NR * es, NR, R, None, L, self.wg_parts, self.wg_bparts, N, T, ns, dt,
+                    pro=K.PRO_GATE)                                                   # 1x1 residual
+            K.reduce_partials(self.wg_parts, ns, R * R, L, True, SQRT_HALF, gp + 4 * sec["WR"].offset, R * R)
+            K.reduce_partials(self.wg_bparts, ns, R, L, True, SQRT_HALF, gp + 4 * sec["BR"].offset, R)
         if self.use_w256:
             # every skip 1x1 at once: out[L*R, S] = c_all^T . dtotal (dtotal re-read once per 4 layers)
             with _Span(self, "wgrad_skip"):

@@ -278,6 +278,32 @@ def wgrad(in_ptr: int, in_batch_stride: int, cin: int, dout_ptr: int, dout_batch
          int(nslabs), int(pro), abi_dtype(dtype), _stream())
 
 
+def wgrad_layers(x: torch.Tensor, z: torch.Tensor, df: torch.Tensor, g_ptr: int, dilations: List[int],
+                 part_f: torch.Tensor, part_r: torch.Tensor, part_bf: torch.Tensor, part_br: torch.Tensor, T: int,
+                 nslabs: int, cond_ptr: Optional[int] = None, cond_layer_stride: int = 0, cond_frames: int = 1,
+                 pool_stride: int = 1, cond_row_stride: int = 64):
+    """x, z, df: [L, rows, 64] stacks; g_ptr: pointer to the [L, rows, 64] stack of G_{l+1} (same strides)."""
+    import ctypes as C
+    L, rows, R = z.shape
+    for t, nm in ((x, "x"), (df, "df")):
+        _chk(t, nm, z.dtype)
+        if t.shape[-1] != R or t.shape[-2] != rows or t.shape[0] < L:
+            raise ValueError("wgrad_layers: %s shape %s" % (nm, tuple(t.shape)))
+    _chk(z, "z")
+    if len(dilations) != L:
+        raise ValueError("wgrad_layers: %d dilations for %d layers" % (len(dilations), L))
+    for t, n in ((part_f, L * nslabs * 2 * R * R), (part_r, L * nslabs * R * R), (part_bf, L * nslabs * R),
+                 (part_br, L * nslabs * R)):
+        _chk(t, "partials", torch.float32)
+        if t.numel() < n:
+            raise ValueError("wgrad_layers: partial buffer needs %d floats" % n)
+    dl = (C.c_int32 * L)(*[int(d) for d in dilations])
+    call("srwn_wgrad_layers", x.data_ptr(), z.data_ptr(), df.data_ptr(), g_ptr, rows * R, cond_ptr,
+         int(cond_layer_stride), int(cond_frames), int(pool_stride), int(cond_row_stride), dl, L, part_f.data_ptr(),
+         part_r.data_ptr(), part_bf.data_ptr(), part_br.data_ptr(), rows, int(T), int(nslabs), R, 2,
+         abi_dtype(z.dtype), _stream())
+
+
 def wgrad256_slabs(rows: int, m_chunks: int) -> int:
     return int(_lib.load().srwn_wgrad256_slabs(int(rows), int(m_chunks)))
 

@@ -77,6 +77,9 @@ def main():
                                              eng.ns_skip, pro=K.PRO_GATE), 2.0 * N * L * R * S, N * L * R * 2 + N * S * 2),
         "wgrad256_head": (lambda: K.wgrad256(eng.r0.data_ptr(), 64, S, S // 64, eng.da1, eng.wg_parts, eng.wg_bparts,
                                              N, eng.ns_head), 2.0 * N * S * S, N * S * 4),
+        "wgrad_layers(30)": (lambda: K.wgrad_layers(eng.xs.view(L + 1, N, R), eng.zs.view(L, N, R), eng.dfs.view(L, N, R),
+                                                    eng.gs.data_ptr() + NR * 2, eng.dil, eng.pl_f, eng.pl_r, eng.pl_bf,
+                                                    eng.pl_br, T, eng.nslabs), 2.0 * N * L * 3 * R * R, N * L * R * 2 * 4),
         "wgrad_conv_tap(30)": (lambda: K.wgrad(eng.xs.data_ptr(), NR, R, eng.dfs.data_ptr(), NR, R, list(eng.dil), L,
                                                eng.wg_parts, None, N, T, eng.nslabs, dt),
                                2.0 * N * L * R * R, N * L * R * 4),
