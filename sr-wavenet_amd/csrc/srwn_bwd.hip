@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void layer_bwd_kernel(LayerBwdArgs a) {
   if (UP) lds_dma_copy(a.wconvT, lds_conv, RT * K * KS * 64 * (int)sizeof(Frag<T>), wave, lane, 4);
   if (UP && DOWN) lds_dma_copy(a.wresT, lds_res, RT * KS * 64 * (int)sizeof(Frag<T>), wave, lane, 4);
   if (DOWN && !DCS) lds_dma_copy(a.wskipT, lds_skip, RT * KSS * 64 * (int)sizeof(Frag<T>), wave, lane, 4);
-  __syncthreads();
+  // (barrier after the first tile's loads are issued: one round trip for weights + first operands)
 
   const int col = lane & 31, half = lane >> 5;
   struct Tile {
@@ -199,6 +199,7 @@ __global__ __launch_bounds__(256) void layer_bwd_kernel(LayerBwdArgs a) {
   Tile ta, tb;
   int tile = blockIdx.x * 4 + wave;
   load_tile(tile, ta);
+  __syncthreads();
   while (tile < a.ntiles) {
     load_tile(tile + stride, tb);
     process(tile, ta);

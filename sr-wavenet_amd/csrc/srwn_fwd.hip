@@ -33,7 +33,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2) ? 2 : 1) void layer_fwd_kerne
   T* stage = reinterpret_cast<T*>(lds_res + NRES * 64) + wave * (32 * RowStage<T>::stride(R));   // wave-private
   lds_dma_copy(wconv, lds_conv, NCONV * 64 * (int)sizeof(Frag<T>), wave, lane, 4);
   lds_dma_copy(wres, lds_res, NRES * 64 * (int)sizeof(Frag<T>), wave, lane, 4);
-  __syncthreads();
+  // (the barrier that retires the LDS-DMA comes after the first tile's loads have been issued too, so
+  //  weights, biases and the first activations share one memory round trip)
 
   const int col = lane & 31, half = lane >> 5;
   float bf[RT][16], br[RT][16];
@@ -164,6 +165,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2) ? 2 : 1) void layer_fwd_kerne
   Frag<T> fa[K][KS], fb[K][KS];
   int tile = blockIdx.x * 4 + wave;
   load_tile(tile, fa);
+  __syncthreads();
   while (tile < ntiles) {
     load_tile(tile + stride, fb);   // (clamped to the last tile when past the end: harmless re-read)
     process(tile, fa);

@@ -199,7 +199,7 @@ extern "C" int srwn_causal_conv1d_fwd(const float* x, const float* w, const floa
 // stage 1: block p sums rows [p*ROWS, (p+1)*ROWS) of the flattened [B*T] axis -> partials[p][(K+1)*R]
 // stage 2: fixed-order sum over p.
 // ------------------------------------------------------------------------------------------
-constexpr int kIcRows = 512;
+constexpr int kIcRows = 2048;
 
 template <typename T>
 __global__ __launch_bounds__(256) void init_conv_wgrad_stage1(const float* __restrict__ audio,
