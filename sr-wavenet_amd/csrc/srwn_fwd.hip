@@ -10,13 +10,46 @@ using namespace srwn;
 // ------------------------------------------------------------------------------------------
 // fused residual layer forward (ops.py:23-46 + model.py:180-183)
 //   Persistent waves: grid = O(#CUs) workgroups of 4 waves; a wave walks 32-step time tiles
-//   (tile id = b * tiles_per_clip + t/32) with stride = total waves, and keeps the NEXT tile's
-//   activation fragments in flight (HBM -> VGPR) while it runs the MFMAs / gate / stores of the
-//   current one, so loads, math and stores of different tiles overlap instead of running as three
-//   chip-wide phases.  LDS holds only the layer's packed weights (A fragments), filled by LDS-DMA.
+//   (tile id = b * tiles_per_clip + t/32) with stride = total waves.
+//   Activations enter through LDS as WHOLE ROWS: each tap's 32-row window of x is one contiguous
+//   4 KiB block of the channels-last tensor, fetched by LDS-DMA (global_load_lds_dwordx4, 8 rows x
+//   128 B per instruction) into a wave-private, XOR-swizzled image (swizzle on the per-lane SOURCE
+//   address, LDS destination linear) and double-buffered, so tile n+1 streams in while tile n is in
+//   the MFMAs / gate / stores.  (Fragment-shaped global loads touch 32-64 cache lines per instruction
+//   and measured ~5 us of the 17 us kernel.)  Outputs leave as whole rows through a wave-private
+//   transposing LDS stage.  LDS also holds the layer's packed weights (A fragments), filled by LDS-DMA.
 // ------------------------------------------------------------------------------------------
-template <typename T, int RT, int K, bool COND>
-__global__ __launch_bounds__(256, (sizeof(T) == 2) ? 2 : 1) void layer_fwd_kernel(const T* __restrict__ x, const T* __restrict__ cond,
+template <typename T> struct XTile {
+  static constexpr int VEC = 16 / (int)sizeof(T);
+  // element offset of 16-byte chunk c of row r in a swizzled [32][R] image
+  template <int R> static __device__ __forceinline__ int off(int r, int c) {
+    constexpr int CPR = R / VEC;
+    return r * R + ((c ^ (r & (CPR - 1))) * VEC);
+  }
+};
+
+// B fragment (natural k order) of k-step ks for time row `r`, lane half h, from a swizzled x image
+template <int R> __device__ __forceinline__ Frag<bf16_t> xfrag(const bf16_t* img, int r, int ks, int h) {
+  Frag<bf16_t> f;
+  f.v = *reinterpret_cast<const bf16x8*>(img + XTile<bf16_t>::off<R>(r, 2 * ks + h));
+  return f;
+}
+template <int R> __device__ __forceinline__ Frag<float> xfrag(const float* img, int r, int ks, int h) {
+  Frag<float> f;
+  f.lo = *reinterpret_cast<const f32x4*>(img + XTile<float>::off<R>(r, 4 * ks + 2 * h));
+  f.hi = *reinterpret_cast<const f32x4*>(img + XTile<float>::off<R>(r, 4 * ks + 2 * h + 1));
+  return f;
+}
+// 4 consecutive channels (accumulator group) starting at channel ch0 (multiple of 4) of row r
+template <int R> __device__ __forceinline__ f32x4 xquad(const bf16_t* img, int r, int ch0) {
+  return load4(img + XTile<bf16_t>::off<R>(r, ch0 >> 3) + (ch0 & 7));
+}
+template <int R> __device__ __forceinline__ f32x4 xquad(const float* img, int r, int ch0) {
+  return load4(img + XTile<float>::off<R>(r, ch0 >> 2));
+}
+
+template <typename T, int RT, int K, bool COND, int NBUF>
+__global__ __launch_bounds__(256) void layer_fwd_kernel(const T* __restrict__ x, const T* __restrict__ cond,
                                                         const T* __restrict__ wconv, const T* __restrict__ wres,
                                                         const float* __restrict__ bias_f,
                                                         const float* __restrict__ bias_r, T* __restrict__ h_out,
@@ -26,15 +59,19 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2) ? 2 : 1) void layer_fwd_kerne
   constexpr int R = 32 * RT;
   constexpr int KS = R / 16;  // k-steps per tap
   constexpr int NCONV = RT * K * KS, NRES = RT * KS;
+  constexpr int VEC = 16 / (int)sizeof(T), CPR = R / VEC;       // 16-B chunks per row
+  constexpr int TILE_E = 32 * R;                                // elements of one tap image
+  constexpr int PIECES = TILE_E * (int)sizeof(T) / 1024;        // 1-KiB LDS-DMA pieces per tap image
+  constexpr int RPP = 32 / PIECES;                              // rows per piece
   extern __shared__ __attribute__((aligned(16))) char smem[];
   Frag<T>* lds_conv = reinterpret_cast<Frag<T>*>(smem);
   Frag<T>* lds_res = lds_conv + NCONV * 64;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   T* stage = reinterpret_cast<T*>(lds_res + NRES * 64) + wave * (32 * RowStage<T>::stride(R));   // wave-private
+  T* ximg = reinterpret_cast<T*>(lds_res + NRES * 64) + 4 * (32 * RowStage<T>::stride(R)) +
+            wave * (NBUF * K * TILE_E);                                                          // [NBUF][K][32][R]
   lds_dma_copy(wconv, lds_conv, NCONV * 64 * (int)sizeof(Frag<T>), wave, lane, 4);
   lds_dma_copy(wres, lds_res, NRES * 64 * (int)sizeof(Frag<T>), wave, lane, 4);
-  // (the barrier that retires the LDS-DMA comes after the first tile's loads have been issued too, so
-  //  weights, biases and the first activations share one memory round trip)
 
   const int col = lane & 31, half = lane >> 5;
   float bf[RT][16], br[RT][16];
@@ -46,59 +83,55 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2) ? 2 : 1) void layer_fwd_kerne
       br[mt][q] = bias_r[32 * mt + crow(q, half)];
     }
 
-  // B fragments of one tile: taps 0..K-2 natural k order, last tap (shift 0) permuted so that its
-  // registers are also the residual-add operand in accumulator layout.
-  // Loads are UNCONDITIONAL (clamped addresses, values zeroed afterwards by a select): a load under a
-  // branch makes the number of loads in flight path-dependent, and hipcc then waits vmcnt(0) before the
-  // first use of the previous tile's fragments, which would drain the prefetch it is supposed to overlap.
-  auto load_tile = [&](int tile_, Frag<T> (&bx)[K][KS]) {
+  // LDS-DMA of the K tap windows of one tile (rows clamped into the clip; out-of-range taps are
+  // zeroed at use).  Always exactly K*PIECES instructions, so the vmcnt bookkeeping below is exact.
+  auto fetch = [&](int tile_, int buf) {
     const int tile = tile_ < ntiles ? tile_ : ntiles - 1;
     const int b = tile / ntb;
-    const int tc = (tile - b * ntb) * 32 + col;
+    const int t0 = (tile - b * ntb) * 32;
     const T* xb = x + (size_t)b * Tlen * R;
-    const T* cb = COND ? cond + (size_t)b * cond_frames * cond_stride : nullptr;
+    const int rl0 = lane / CPR, slot = lane % CPR;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      const int tk = tc - (K - 1 - k) * dilation;
-      const int tkc = tk < 0 ? 0 : (tk < Tlen ? tk : Tlen - 1);
-      const T* row = xb + (size_t)tkc * R;
-      const T* crow_ = COND ? cb + (size_t)(tkc / pool) * cond_stride : nullptr;
+      T* img = ximg + (buf * K + k) * TILE_E;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        Frag<T> f;
-        if (k == K - 1) {
-          f = load_perm(row + 16 * ks + 4 * half);
-          if (COND) {
-            Frag<T> c = load_perm(crow_ + 16 * ks + 4 * half);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) f.set(j, f.get(j) + c.get(j));
-          }
-        } else {
-          f = load_nat(row + 16 * ks + 8 * half);
-          if (COND) {
-            Frag<T> c = load_nat(crow_ + 16 * ks + 8 * half);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) f.set(j, f.get(j) + c.get(j));
-          }
-        }
-        bx[k][ks] = f;   // raw; out-of-range taps are zeroed at use time (process)
+      for (int p = 0; p < PIECES; ++p) {
+        const int rl = p * RPP + rl0;                       // row within the tile image
+        int tr = t0 + rl - (K - 1 - k) * dilation;          // source time row
+        tr = tr < 0 ? 0 : (tr < Tlen ? tr : Tlen - 1);
+        const int c = slot ^ (rl & (CPR - 1));              // source chunk (swizzle on the source side)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xb + (size_t)tr * R + c * VEC),
+                                         (__attribute__((address_space(3))) void*)(img + p * (1024 / (int)sizeof(T))), 16, 0, 0);
       }
     }
   };
 
   // one tile: conv MFMAs -> tanh/gate -> residual MFMAs -> whole-row stores
-  auto process = [&](int tile, const Frag<T> (&raw)[K][KS]) {
+  auto process = [&](int tile, int buf) {
+    const int b = tile / ntb;
+    const int t0 = (tile - b * ntb) * 32;
+    const int tc = t0 + col;
+    const int rows_valid = Tlen - t0;   // >= 1; rows beyond it do not exist
+    const T* cb = COND ? cond + (size_t)b * cond_frames * cond_stride : nullptr;
     Frag<T> cur[K][KS];
-    {
-      const int b0 = tile / ntb;
-      const int tc0 = (tile - b0 * ntb) * 32 + col;
 #pragma unroll
-      for (int k = 0; k < K; ++k) {
-        const bool valid = (tc0 < Tlen) && (tc0 - (K - 1 - k) * dilation >= 0);
+    for (int k = 0; k < K; ++k) {
+      const int tk = tc - (K - 1 - k) * dilation;
+      const bool valid = (tc < Tlen) && (tk >= 0);
+      const T* img = ximg + (buf * K + k) * TILE_E;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) cur[k][ks] = valid ? raw[k][ks] : zero_frag<T>();
+      for (int ks = 0; ks < KS; ++ks) {
+        Frag<T> f = xfrag<R>(img, col, ks, half);
+        if (COND) {
+          const T* cr = cb + (size_t)((valid ? tk : 0) / pool) * cond_stride;
+          const Frag<T> c = load_nat(cr + 16 * ks + 8 * half);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f.set(j, f.get(j) + c.get(j));
+        }
+        cur[k][ks] = valid ? f : zero_frag<T>();
       }
     }
+
     // ---- dilated causal conv as one (K*R)-deep contraction; accumulators start at the bias
     f32x16 accF[RT];
 #pragma unroll
@@ -116,9 +149,6 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2) ? 2 : 1) void layer_fwd_kerne
         }
 
     // ---- tanh, gate, 1x1 residual from registers, scaled residual add
-    const int b = tile / ntb;
-    const int t0 = (tile - b * ntb) * 32;
-    const int rows_valid = Tlen - t0;   // >= 1; rows beyond it do not exist
     T* ztile = z_out + ((size_t)b * Tlen + t0) * R;
     T* htile = h_out + ((size_t)b * Tlen + t0) * R;
     Frag<T> cf[KS];
@@ -147,33 +177,58 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2) ? 2 : 1) void layer_fwd_kerne
         mma(accR[mt], a, cf[s]);
       }
     {
+      // residual operand x(+cond) in accumulator layout straight from the tap-(K-1) image
+      const T* img = ximg + (buf * K + (K - 1)) * TILE_E;
+      const bool ok = tc < Tlen;
       float hv[RT][16];
 #pragma unroll
       for (int mt = 0; mt < RT; ++mt)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const float xin = cur[K - 1][2 * mt + (q >> 3)].get(q & 7);
-          hv[mt][q] = (xin + accR[mt][q]) * kSqrtHalf;
+        for (int g = 0; g < 4; ++g) {
+          f32x4 xv = xquad<R>(img, col, 32 * mt + 8 * g + 4 * half);
+          if (COND) {
+            const f32x4 cv = load4(cb + (size_t)((ok ? tc : 0) / pool) * cond_stride + 32 * mt + 8 * g + 4 * half);
+            // match the fragment path: x + cond rounded to T before use
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xv[e] = (float)(T)(xv[e] + cv[e]);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) hv[mt][4 * g + e] = (xv[e] + accR[mt][4 * g + e]) * kSqrtHalf;
         }
       store_rows_via_lds<T, RT>(stage, htile, R, hv, rows_valid, lane);
     }
   };
 
-  // ping-pong fragment sets (no register copies, and the compiler's waitcnt bookkeeping stays exact):
-  // the loads of the NEXT tile are always in flight while the current tile is processed.
   const int stride = gridDim.x * 4;
-  Frag<T> fa[K][KS], fb[K][KS];
   int tile = blockIdx.x * 4 + wave;
-  load_tile(tile, fa);
-  __syncthreads();
-  while (tile < ntiles) {
-    load_tile(tile + stride, fb);   // (clamped to the last tile when past the end: harmless re-read)
-    process(tile, fa);
-    tile += stride;
-    if (tile >= ntiles) break;
-    load_tile(tile + stride, fa);
-    process(tile, fb);
-    tile += stride;
+  fetch(tile, 0);
+  __syncthreads();   // weights + first tile landed (vmcnt(0) + barrier)
+  if (NBUF == 2) {
+    int buf = 0;
+    bool prev_full = true;
+    while (tile < ntiles) {
+      fetch(tile + stride, buf ^ 1);                  // K*PIECES LDS-DMA ops for the next tile
+      // tile `tile` was fetched one iteration ago; younger ops: the previous tile's 2*32/RPI-row-store
+      // instructions (all issued only if that tile was full) and the K*PIECES ops just issued.
+      if (prev_full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K * PIECES + 2 * (32 * R * (int)sizeof(T) / 1024)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K * PIECES) : "memory");
+      process(tile, buf);
+      {
+        const int b = tile / ntb;
+        prev_full = (Tlen - (tile - b * ntb) * 32) >= 32;
+      }
+      tile += stride;
+      buf ^= 1;
+    }
+  } else {
+    while (tile < ntiles) {
+      process(tile, 0);
+      tile += stride;
+      if (tile < ntiles) {
+        fetch(tile, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    }
   }
 }
 
@@ -188,22 +243,23 @@ static int launch_layer_fwd(const void* x, const void* cond, const void* wconv, 
                             const float* bias_f, const float* bias_r, void* h_out, void* z_out, int B, int Tlen,
                             int dilation, int cond_frames, int pool, int cond_stride, hipStream_t st) {
   constexpr int R = 32 * RT, KS = R / 16;
+  constexpr int NBUF = (sizeof(T) == 2) ? 2 : 1;
   const size_t sh = (size_t)(RT * K * KS + RT * KS) * 64 * sizeof(Frag<T>) +
-                    (size_t)4 * 32 * RowStage<T>::stride(R) * sizeof(T);
+                    (size_t)4 * 32 * RowStage<T>::stride(R) * sizeof(T) + (size_t)4 * NBUF * K * 32 * R * sizeof(T);
   const int ntb = (Tlen + 31) / 32;
   const long long ntiles = (long long)B * ntb;
-  static const int bpc = layer_blocks_per_cu("SRWN_FWD_BPC", 2);
+  static const int bpc = layer_blocks_per_cu("SRWN_FWD_BPC", 1);
   long long blocks = (ntiles + 3) / 4;
   if (blocks > 256LL * bpc) blocks = 256LL * bpc;
   dim3 grid((unsigned)blocks), block(256);
   if (cond) {
-    auto kfn = layer_fwd_kernel<T, RT, K, true>;
-    if (sh > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    auto kfn = layer_fwd_kernel<T, RT, K, true, NBUF>;
+    if (sh > 32768) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     hipLaunchKernelGGL(kfn, grid, block, sh, st, (const T*)x, (const T*)cond, (const T*)wconv, (const T*)wres, bias_f,
                        bias_r, (T*)h_out, (T*)z_out, Tlen, dilation, cond_frames, pool, cond_stride, ntb, (int)ntiles);
   } else {
-    auto kfn = layer_fwd_kernel<T, RT, K, false>;
-    if (sh > 65536) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    auto kfn = layer_fwd_kernel<T, RT, K, false, NBUF>;
+    if (sh > 32768) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     hipLaunchKernelGGL(kfn, grid, block, sh, st, (const T*)x, (const T*)nullptr, (const T*)wconv, (const T*)wres,
                        bias_f, bias_r, (T*)h_out, (T*)z_out, Tlen, dilation, 1, 1, R, ntb, (int)ntiles);
   }

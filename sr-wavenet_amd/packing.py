@@ -8,11 +8,11 @@ from __future__ import annotations
 
 def pack_conv(pk, src_offset: int, K: int, R: int) -> int:
     """Dilated conv kernel [K,R,R] (ops.py:14) as one (K*R)-deep contraction: rows = out channel,
-    k = tap*R + in channel; the last tap (time shift 0) in permuted k order."""
+    k = tap*R + in channel, natural k order (the activation fragments come from LDS row images)."""
     mt, ks_total = R // 32, K * R // 16
     off = pk.reserve(mt, ks_total)
     pk.fill(off, src_offset=src_offset, rows_valid=R, k_valid=K * R, row_stride=1, k_stride=R, mt_count=mt,
-            ks_total=ks_total, perm_from_ks=(K - 1) * R // 16)
+            ks_total=ks_total)
     return off
 
 
