@@ -93,6 +93,9 @@ class WaveNetEngine:
         self.cfg = cfg
         self.timing = False
         self.spans: Dict[str, list] = {}
+        import os as _os
+        self.overlap = _os.environ.get("SRWN_OVERLAP", "1") != "0"
+        self.side = torch.cuda.Stream() if (torch.cuda.is_available() and self.overlap) else None
         self.B, self.T = int(batch), int(length)
         self.N = self.B * self.T
         self.L = len(cfg.dilations)
@@ -428,28 +431,26 @@ class WaveNetEngine:
     # backward
     # ------------------------------------------------------------------------------------------
     def backward(self):
-        B, T, N, L, R, S, Cp, Kw = self.B, self.T, self.N, self.L, self.R, self.S, self.Cp, self.Kw
-        g = self.grads
-        gp = g.data_ptr()
-        sec = self.sections
-        ns = self.nslabs
+        """Data gradients top-down on the current stream; weight gradients on a side stream as soon as their
+        operands exist (skip/head kernels right after the head data gradients, per-layer kernels in groups
+        behind the dgrad chain), so the bandwidth-bound wgrad passes fill the ramp/tail bubbles of the
+        short per-layer dgrad kernels.  Joined before the optimizer.  SRWN_OVERLAP=0 serialises everything."""
+        B, T, N, L, R, S, Kw = self.B, self.T, self.N, self.L, self.R, self.S, self.Kw
         dt = self.dt
-        es = self.xs.element_size()
-        # ---- head data gradients (relu masks against the saved activations)
-        with _Span(self, "bwd_head"):
-            if self.pooled:
-                from ._lib import call
-                call("srwn_bcast_mask", self.dmean.data_ptr(), self.r1.data_ptr(), self.da1.data_ptr(), B, T, S,
-                     1.0 / T, K.abi_dtype(dt), torch.cuda.current_stream().cuda_stream)
-            else:
-                K.pw_linear(self.dlogits.data_ptr(), Cp, 0, Cp, Cp, self.wptr(self.o_w2T), None, self.da1, S, S, N,
-                            aux=self.r1, epi=K.EPI_MASK)
-            K.pw_linear(self.da1.data_ptr(), S, 0, S, S, self.wptr(self.o_w1T), None, self.dtotal, S, S, N,
-                        aux=self.r0, epi=K.EPI_MASK)
+        main = torch.cuda.current_stream()
+        overlap = self.overlap and not self.timing
+        side = self.side if overlap else main
+        self._bwd_head()
+        if overlap:
+            side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self._wgrad_skip_and_head()
         if self.use_dcs:
             with _Span(self, "skip_dgrad_all"):
                 K.skip_dgrad_all(self.dtotal, self.wptr(self.o_skipT_all), self.dcs.view(L, N, R), R, S)
         # ---- residual stack, top down
+        groups = self._wl_groups() if self.use_wl else []
+        group_lo = {g[0]: g for g in groups}
         span = _Span(self, "bwd_layers").__enter__()
         for l in range(L - 1, -1, -1):
             has_up = l < L - 1
@@ -462,26 +463,67 @@ class WaveNetEngine:
                                  None if self.use_dcs else self.dtotal, self.zs[l], self.dfs[l], B, T, R, S, Kw,
                                  self.dil[l + 1] if has_up else 1, has_up, True, dt,
                                  dcs=self.dcs[l] if self.use_dcs else None)
+            if l in group_lo:   # df_l.. and G_{l+1}.. of this group are complete
+                if overlap:
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    self._wgrad_layers_group(*group_lo[l])
         K.residual_layer_bwd(self.gs[1] if L > 1 else None, self.dfs[0], self.wptr(self.o_convT[0]), self.gs[0],
                              None, None, None, None, None, B, T, R, S, Kw, self.dil[0], True, False, dt)
         span.__exit__()
-        # ---- weight gradients
+        with torch.cuda.stream(side):
+            self._wgrad_layers_finish()
+        self._wgrad_input_and_cond()
+        if overlap:
+            main.wait_stream(side)
+
+    def _wl_groups(self):
+        per = 6
+        return [(l0, min(l0 + per, self.L)) for l0 in range(0, self.L, per)]
+
+    def _bwd_head(self):
+        B, T, N, S, Cp = self.B, self.T, self.N, self.S, self.Cp
+        with _Span(self, "bwd_head"):   # relu masks against the saved activations
+            if self.pooled:
+                from ._lib import call
+                call("srwn_bcast_mask", self.dmean.data_ptr(), self.r1.data_ptr(), self.da1.data_ptr(), B, T, S,
+                     1.0 / T, K.abi_dtype(self.dt), torch.cuda.current_stream().cuda_stream)
+            else:
+                K.pw_linear(self.dlogits.data_ptr(), Cp, 0, Cp, Cp, self.wptr(self.o_w2T), None, self.da1, S, S, N,
+                            aux=self.r1, epi=K.EPI_MASK)
+            K.pw_linear(self.da1.data_ptr(), S, 0, S, S, self.wptr(self.o_w1T), None, self.dtotal, S, S, N,
+                        aux=self.r0, epi=K.EPI_MASK)
+
+    def _wgrad_layers_group(self, l0: int, l1: int):
+        """conv taps + 1x1 residual of layers [l0, l1) in one pass over x, z, df, G."""
+        N, L, R, T, ns = self.N, self.L, self.R, self.T, self.nslabs
+        es = self.xs.element_size()
+        NR = N * R
+        ckw = {}
+        if self.E:
+            ckw = dict(cond_ptr=self.cond_all.data_ptr() + l0 * R * es, cond_layer_stride=R,
+                       cond_frames=self.frames, pool_stride=self.cfg.pool_stride, cond_row_stride=L * R)
+        with _Span(self, "wgrad_layers"):
+            K.wgrad_layers(self.xs.view(L + 1, N, R)[l0:l1], self.zs.view(L, N, R)[l0:l1],
+                           self.dfs.view(L, N, R)[l0:l1], self.gs.data_ptr() + (l0 + 1) * NR * es, self.dil[l0:l1],
+                           self.pl_f[l0 * ns * 2 * R * R:], self.pl_r[l0 * ns * R * R:], self.pl_bf[l0 * ns * R:],
+                           self.pl_br[l0 * ns * R:], T, ns, **ckw)
+
+    def _wgrad_layers_finish(self):
+        L, R, S, Kw, N, T = self.L, self.R, self.S, self.Kw, self.N, self.T
+        gp, sec, ns, dt = self.grads.data_ptr(), self.sections, self.nslabs, self.dt
+        es = self.xs.element_size()
         NR = N * R
         xs_p, zs_p, dfs_p, gs_p = self.xs.data_ptr(), self.zs.data_ptr(), self.dfs.data_ptr(), self.gs.data_ptr()
         if self.use_wl:
-            # conv taps + 1x1 residual of every layer in one pass over x, z, df, G
-            ckw = {}
-            if self.E:
-                ckw = dict(cond_ptr=self.cond_all.data_ptr(), cond_layer_stride=R, cond_frames=self.frames,
-                           pool_stride=self.cfg.pool_stride, cond_row_stride=L * R)
-            with _Span(self, "wgrad_layers"):
-                K.wgrad_layers(self.xs.view(L + 1, N, R), self.zs.view(L, N, R), self.dfs.view(L, N, R),
-                               gs_p + NR * es, self.dil, self.pl_f, self.pl_r, self.pl_bf, self.pl_br, T, ns, **ckw)
             K.reduce_partials(self.pl_f, ns, Kw * R * R, L, True, 1.0, gp + 4 * sec["WF"].offset, Kw * R * R)
             K.reduce_partials(self.pl_bf, ns, R, L, True, 1.0, gp + 4 * sec["BF"].offset, R)
             K.reduce_partials(self.pl_r, ns, R * R, L, True, SQRT_HALF, gp + 4 * sec["WR"].offset, R * R)
             K.reduce_partials(self.pl_br, ns, R, L, True, SQRT_HALF, gp + 4 * sec["BR"].offset, R)
-        for k in range(0 if self.use_wl else Kw):                                    # dilated conv taps (legacy)
+            return
+        for k in range(Kw):                                                          # dilated conv taps (legacy)
             shifts = [(Kw - 1 - k) * d for d in self.dil]
             last = k == Kw - 1
             ckw = {}
@@ -494,11 +536,17 @@ class WaveNetEngine:
                               Kw * R * R)
             if last:
                 K.reduce_partials(self.wg_bparts, ns, R, L, True, 1.0, gp + 4 * sec["BF"].offset, R)
-        if not self.use_wl:
-            K.wgrad(zs_p, NR, R, gs_p + NR * es, NR, R, None, L, self.wg_parts, self.wg_bparts, N, T, ns, dt,
-                    pro=K.PRO_GATE)                                                   # 1x1 residual
-            K.reduce_partials(self.wg_parts, ns, R * R, L, True, SQRT_HALF, gp + 4 * sec["WR"].offset, R * R)
-            K.reduce_partials(self.wg_bparts, ns, R, L, True, SQRT_HALF, gp + 4 * sec["BR"].offset, R)
+        K.wgrad(zs_p, NR, R, gs_p + NR * es, NR, R, None, L, self.wg_parts, self.wg_bparts, N, T, ns, dt,
+                pro=K.PRO_GATE)                                                       # 1x1 residual
+        K.reduce_partials(self.wg_parts, ns, R * R, L, True, SQRT_HALF, gp + 4 * sec["WR"].offset, R * R)
+        K.reduce_partials(self.wg_bparts, ns, R, L, True, SQRT_HALF, gp + 4 * sec["BR"].offset, R)
+
+    def _wgrad_skip_and_head(self):
+        """Gradients of the skip 1x1s and the two head 1x1s: need only z, r0, r1, da1, dtotal, dlogits."""
+        N, T, L, R, S, Cp = self.N, self.T, self.L, self.R, self.S, self.Cp
+        gp, sec, ns, dt = self.grads.data_ptr(), self.sections, self.nslabs, self.dt
+        NR = N * R
+        zs_p = self.zs.data_ptr()
         if self.use_w256:
             # every skip 1x1 at once: out[L*R, S] = c_all^T . dtotal (dtotal re-read once per 4 layers)
             with _Span(self, "wgrad_skip"):
@@ -529,6 +577,11 @@ class WaveNetEngine:
                     N, T, ns, dt)                                                     # last 1x1 (S->C)
             K.reduce_partials(self.wg_parts, ns, S * Cp, 1, True, 1.0, gp + 4 * sec["head_w2"].offset, 0)
             K.reduce_partials(self.wg_bparts, ns, Cp, 1, True, 1.0, gp + 4 * sec["head_b2"].offset, 0)
+
+    def _wgrad_input_and_cond(self):
+        B, T, L, R, Kw = self.B, self.T, self.L, self.R, self.Kw
+        g = self.grads
+        gp, sec, dt = g.data_ptr(), self.sections, self.dt
         K.init_conv_wgrad(self.audio, self.gs[0], self.view("init_w", g).reshape(-1), self.view("init_b", g), Kw,
                           1 if self.cfg.shift_input else 0, self.ic_ws)
         if self.E:
