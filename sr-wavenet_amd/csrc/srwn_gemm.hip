@@ -9,6 +9,7 @@
 //    is being consumed; one barrier per chunk (guide: "minimum 2-phase" schedule);
 //  * activation fragments for chunk c+1 are fetched straight from HBM into registers while chunk c's
 //    MFMAs run.
+#include <cstdlib>
 #include "srwn_common.h"
 #include "srwn_host.h"
 #include "../../include/srwn.h"
@@ -30,20 +31,27 @@ template <typename T> __device__ __forceinline__ void glds16(const void* g, void
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-template <typename T, int MT, int KSC, int PRO, int EPI>
-__global__ __launch_bounds__(256, (EPI == SRWN_EPI_SOFTMAX_CE) ? 1 : 2) void rowgemm_kernel(RgArgs a) {
+template <typename T, int MT, int KSC, int PRO, int EPI, int NT>
+__global__ __launch_bounds__(256, (EPI == SRWN_EPI_SOFTMAX_CE || NT == 2) ? 1 : 2) void rowgemm_kernel(RgArgs a) {
+  static_assert(MT % 2 == 0, "outputs are emitted in 64-channel groups");
+  static_assert(EPI != SRWN_EPI_SOFTMAX_CE || NT == 1, "softmax epilogue holds one column tile");
   constexpr int FB = sizeof(Frag<T>) * 64;          // bytes of one fragment image (1 KiB bf16, 2 KiB f32)
   constexpr int CHUNK_B = MT * KSC * FB;            // bytes of one weight chunk in LDS
   constexpr int PIECES = CHUNK_B / 1024;            // 1-KiB glds pieces per chunk
   static_assert(PIECES % 4 == 0, "chunk must split evenly over 4 waves");
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][CHUNK_B]
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][CHUNK_B]; reused as row stages at the end
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int col = lane & 31, half = lane >> 5;
-  const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-  const int64_t row = tile * 32 + col;
-  const bool valid = row < a.rows;
+  const int64_t tile0 = ((int64_t)blockIdx.x * 4 + wave) * NT;   // first 32-row tile of this wave
+  int64_t rowv[NT];
+  bool valid[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    rowv[nt] = (tile0 + nt) * 32 + col;
+    valid[nt] = rowv[nt] < a.rows;
+  }
   const int nchunks = a.ks_total / KSC;
   const char* wbase = reinterpret_cast<const char*>(a.wpack);
 
@@ -58,42 +66,50 @@ __global__ __launch_bounds__(256, (EPI == SRWN_EPI_SOFTMAX_CE) ? 1 : 2) void row
       glds16<T>(g, l);
     }
   };
-  auto load_b = [&](int c, Frag<T>* dst) {
+  // unconditional (clamped) activation loads; rows beyond the end produce values that are never stored
+  auto load_b = [&](int c, Frag<T> (&dst)[NT][KSC]) {
 #pragma unroll
-    for (int ks = 0; ks < KSC; ++ks) {
-      const int kg = 16 * (c * KSC + ks);
-      const int chunk = kg / a.chunk_len, within = kg - chunk * a.chunk_len;
-      const T* p = reinterpret_cast<const T*>(a.x) + (int64_t)chunk * a.x_chunk_stride +
-                   (valid ? row : 0) * a.x_row_stride + within + 8 * half;
-      dst[ks] = valid ? load_nat(p) : zero_frag<T>();
-    }
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int ks = 0; ks < KSC; ++ks) {
+        const int kg = 16 * (c * KSC + ks);
+        const int chunk = kg / a.chunk_len, within = kg - chunk * a.chunk_len;
+        const T* p = reinterpret_cast<const T*>(a.x) + (int64_t)chunk * a.x_chunk_stride +
+                     (valid[nt] ? rowv[nt] : (a.rows - 1)) * a.x_row_stride + within + 8 * half;
+        dst[nt][ks] = load_nat(p);
+      }
   };
 
-  f32x16 acc[MT];
+  f32x16 acc[MT][NT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int n = 32 * mt + crow(q, half);
-      acc[mt][q] = (a.bias && n < a.cout_valid) ? a.bias[n] : 0.0f;
+      const float bv = (a.bias && n < a.cout_valid) ? a.bias[n] : 0.0f;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt][q] = bv;
     }
 
-  Frag<T> bcur[KSC], bnext[KSC];
+  Frag<T> bcur[NT][KSC], bnext[NT][KSC];
   stage(0, 0);
   load_b(0, bnext);
   __syncthreads();   // (drains the glds: vmcnt(0) + barrier)
   for (int c = 0; c < nchunks; ++c) {
 #pragma unroll
-    for (int ks = 0; ks < KSC; ++ks) {
-      bcur[ks] = bnext[ks];
-      if (PRO == SRWN_PRO_GATE) {
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) bcur[ks].set(j, gate_of_z<T>(bcur[ks].get(j)));
+      for (int ks = 0; ks < KSC; ++ks) {
+        bcur[nt][ks] = bnext[nt][ks];   // rows past the end are clamped re-reads: computed, never stored
+        if (PRO == SRWN_PRO_GATE) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bcur[nt][ks].set(j, gate_of_z<T>(bcur[nt][ks].get(j)));
+        }
       }
-    }
-    if (c + 1 < nchunks) {
-      stage(c + 1, (c + 1) & 1);
-      load_b(c + 1, bnext);
+    {
+      const int cn = (c + 1 < nchunks) ? c + 1 : c;   // (last iteration re-fetches chunk c: harmless, keeps counts fixed)
+      if (c + 1 < nchunks) stage(cn, (c + 1) & 1);
+      load_b(cn, bnext);
     }
     const Frag<T>* lw = reinterpret_cast<const Frag<T>*>(smem + (c & 1) * CHUNK_B) + lane;
 #pragma unroll
@@ -101,22 +117,27 @@ __global__ __launch_bounds__(256, (EPI == SRWN_EPI_SOFTMAX_CE) ? 1 : 2) void row
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const Frag<T> af = lw[(mt * KSC + ks) * 64];
-        mma(acc[mt], af, bcur[ks]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) mma(acc[mt][nt], af, bcur[nt][ks]);
       }
     __syncthreads();
   }
+  // the weight buffers are free now: each wave takes a private row stage ([32][64 + pad]) from them
+  T* rstage = reinterpret_cast<T*>(smem) + wave * (32 * RowStage<T>::stride(64));
 
   // ------------------------------------------------------------------------------------ epilogues
   if (EPI == SRWN_EPI_SOFTMAX_CE) {
-    const int tgt = valid ? a.targets[row] : -1;
+    const int64_t row = rowv[0];
+    const bool vld = valid[0];
+    const int tgt = vld ? a.targets[row] : -1;
     float m = -INFINITY, vt = 0.0f;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int n = 32 * mt + crow(q, half);
-        if (n < a.cout_valid) m = fmaxf(m, acc[mt][q]);
-        if (n == tgt) vt = acc[mt][q];
+        if (n < a.cout_valid) m = fmaxf(m, acc[mt][0][q]);
+        if (n == tgt) vt = acc[mt][0][q];
       }
     m = fmaxf(m, __shfl_xor(m, 32));
     vt += __shfl_xor(vt, 32);
@@ -126,68 +147,75 @@ __global__ __launch_bounds__(256, (EPI == SRWN_EPI_SOFTMAX_CE) ? 1 : 2) void row
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int n = 32 * mt + crow(q, half);
-        if (n < a.cout_valid) s += __expf(acc[mt][q] - m);
+        if (n < a.cout_valid) s += __expf(acc[mt][0][q] - m);
       }
     s += __shfl_xor(s, 32);
     const float lse = m + __logf(s);
-    float loss = (valid && half == 0) ? (lse - vt) : 0.0f;
+    float loss = (vld && half == 0) ? (lse - vt) : 0.0f;
 #pragma unroll
     for (int off = 16; off > 0; off >>= 1) loss += __shfl_xor(loss, off);
-    if (lane == 0 && tile * 32 < a.rows) a.loss_partials[tile] = loss;
-    if (!valid) return;
-    if (a.logits_out) {
+    if (lane == 0 && tile0 * 32 < a.rows) a.loss_partials[tile0] = loss;
+    if (a.logits_out && vld) {
       float* lr = a.logits_out + row * (int64_t)a.cout_valid;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           const int n = 32 * mt + crow(q, half);
-          if (n < a.cout_valid) lr[n] = acc[mt][q];
+          if (n < a.cout_valid) lr[n] = acc[mt][0][q];
         }
     }
     if (a.y) {
-      T* dr = reinterpret_cast<T*>(a.y) + row * a.y_row_stride;
+      const int64_t r0 = tile0 * 32;
+      const int rows_valid = (a.rows - r0) < 32 ? (int)(a.rows - r0) : 32;
+      T* ytile = reinterpret_cast<T*>(a.y) + (rows_valid > 0 ? r0 : 0) * a.y_row_stride;
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+      for (int j = 0; j < MT / 2; ++j) {
+        float v[2][16];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          float v[4];
+        for (int m2 = 0; m2 < 2; ++m2)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int n = 32 * mt + 8 * g + 4 * half + e;
-            const float p = (n < a.cout_valid) ? __expf(acc[mt][4 * g + e] - lse) : 0.0f;
-            v[e] = (p - (n == tgt ? 1.0f : 0.0f)) * a.grad_scale;
+          for (int q = 0; q < 16; ++q) {
+            const int n = 32 * (2 * j + m2) + crow(q, half);
+            const float p = (n < a.cout_valid) ? __expf(acc[2 * j + m2][0][q] - lse) : 0.0f;
+            v[m2][q] = (p - (n == tgt ? 1.0f : 0.0f)) * a.grad_scale;
           }
-          store4(dr + 32 * mt + 8 * g + 4 * half, v[0], v[1], v[2], v[3]);
-        }
+        store_rows_via_lds<T, 2>(rstage, ytile + 64 * j, a.y_row_stride, v, rows_valid, lane);
+      }
     }
     return;
   }
 
-  if (!valid) return;
-  T* yrow = reinterpret_cast<T*>(a.y) + row * a.y_row_stride;
-  const T* arow = (EPI == SRWN_EPI_MASK) ? reinterpret_cast<const T*>(a.aux) + row * a.aux_row_stride : nullptr;
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
+  for (int nt = 0; nt < NT; ++nt) {
+    const int64_t r0 = (tile0 + nt) * 32;
+    const int rows_valid = (a.rows - r0) < 32 ? (int)(a.rows - r0) : 32;   // <= 0 for idle tiles
+    T* ytile = reinterpret_cast<T*>(a.y) + (rows_valid > 0 ? r0 : 0) * a.y_row_stride;
+    const T* arow = (EPI == SRWN_EPI_MASK)
+                        ? reinterpret_cast<const T*>(a.aux) + (valid[nt] ? rowv[nt] : 0) * a.aux_row_stride
+                        : nullptr;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int n0 = 32 * mt + 8 * g + 4 * half;
-      if (n0 >= a.cout_valid) continue;
-      float v[4];
+    for (int j = 0; j < MT / 2; ++j) {
+      if (64 * j >= a.cout_valid) continue;   // cout_valid is a multiple of 64 on this path (host check)
+      float v[2][16];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = acc[mt][4 * g + e];
-      if (EPI == SRWN_EPI_RELU) {
+      for (int m2 = 0; m2 < 2; ++m2)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
-      } else if (EPI == SRWN_EPI_MASK) {
-        const f32x4 mk = load4(arow + n0);
+        for (int g = 0; g < 4; ++g) {
+          f32x4 mk = {1.f, 1.f, 1.f, 1.f};
+          if (EPI == SRWN_EPI_MASK) mk = load4(arow + 32 * (2 * j + m2) + 8 * g + 4 * half);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (mk[e] > 0.0f) ? v[e] : 0.0f;
-      }
-      store4(yrow + n0, v[0], v[1], v[2], v[3]);
+          for (int e = 0; e < 4; ++e) {
+            float x = acc[2 * j + m2][nt][4 * g + e];
+            if (EPI == SRWN_EPI_RELU) x = fmaxf(x, 0.0f);
+            if (EPI == SRWN_EPI_MASK) x = (mk[e] > 0.0f) ? x : 0.0f;
+            v[m2][4 * g + e] = x;
+          }
+        }
+      store_rows_via_lds<T, 2>(rstage, ytile + 64 * j, a.y_row_stride, v, rows_valid, lane);
     }
+  }
 }
-
 
 // ------------------------------------------------------------------------------------------
 // Output-streaming GEMM: the skip-path data gradient of EVERY layer in one launch
@@ -292,14 +320,16 @@ extern "C" int srwn_skip_dgrad_all(const void* dtotal, const void* wskipT_all, v
 
 namespace srwn {
 
-template <typename T, int MT, int KSC>
+template <typename T, int MT, int KSC, int NT>
 static int launch_rg(const RgArgs& a, int pro, int epi, hipStream_t st) {
   constexpr int CHUNK_B = MT * KSC * (int)sizeof(Frag<T>) * 64;
   const size_t sh = 2 * (size_t)CHUNK_B;
-  dim3 grid((unsigned)((a.rows + 127) / 128)), block(256);
+  constexpr int NTS = 1;   // softmax epilogue always one column tile per wave
+  const int rows_per_block = 128 * ((epi == SRWN_EPI_SOFTMAX_CE) ? NTS : NT);
+  dim3 grid((unsigned)((a.rows + rows_per_block - 1) / rows_per_block)), block(256);
 #define SRWN_RG(P, E)                                                                                        \
   if (pro == P && epi == E) {                                                                                \
-    auto kfn = rowgemm_kernel<T, MT, KSC, P, E>;                                                             \
+    auto kfn = rowgemm_kernel<T, MT, KSC, P, E, (E == SRWN_EPI_SOFTMAX_CE) ? 1 : NT>;                        \
     if (sh > 32768) {                                                                                        \
       hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
       if (e != hipSuccess) return set_error((int)e, "rowgemm: LDS %zu: %s", sh, hipGetErrorString(e));       \
@@ -324,10 +354,12 @@ int rowgemm_dispatch(const void* x, int64_t x_row_stride, int64_t x_chunk_stride
                      float* loss_partials, float* logits_out, float grad_scale, int pro, int epi, int dtype,
                      hipStream_t st, int* rc) {
   if (cout_pad != 256 || (Cin % 64) != 0 || rows < 1) return 0;
+  if (epi != SRWN_EPI_SOFTMAX_CE && (cout_valid % 64) != 0) return 0;
   RgArgs a{x, x_row_stride, x_chunk_stride, chunk_len, Cin / 16, wpack, bias, y, y_row_stride, cout_valid, rows,
            aux, aux_row_stride, targets, loss_partials, logits_out, grad_scale};
-  if (dtype == SRWN_BF16) *rc = launch_rg<bf16_t, 8, 4>(a, pro, epi, st);
-  else if (dtype == SRWN_F32) *rc = launch_rg<float, 8, 2>(a, pro, epi, st);
+  static const int nt_bf16 = [] { const char* e = getenv("SRWN_RG_NT"); return (e && atoi(e) == 2) ? 2 : 1; }();
+  if (dtype == SRWN_BF16) *rc = (nt_bf16 == 2) ? launch_rg<bf16_t, 8, 4, 2>(a, pro, epi, st) : launch_rg<bf16_t, 8, 4, 1>(a, pro, epi, st);
+  else if (dtype == SRWN_F32) *rc = launch_rg<float, 8, 2, 1>(a, pro, epi, st);
   else return 0;
   return 1;
 }
