@@ -90,20 +90,18 @@ def main():
     codes = KN.mu_law_encode(audio, C)
     eng.set_inputs(audio, codes)
 
-    use_graph = bool(args.graph) and world == 1
+    use_graph = bool(args.graph)
     step_fn = eng.train_step
-    graph = None
     for _ in range(max(args.warmup, 1 if use_graph else 0)):
         eng.train_step()
     if use_graph:
-        try:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                eng.train_step()
-            step_fn = graph.replay
+        try:   # {fwd,bwd} and {Adam,pack} as two hipGraphs; the RCCL all-reduce stays between them
+            eng.capture_graphs()
+            step_fn = eng.train_step_graphed
+            step_fn()
         except Exception as e:   # fall back to eager launches, and say so
             print("hipGraph capture failed (%s); running eager" % e, file=sys.stderr)
-            graph, use_graph, step_fn = None, False, eng.train_step
+            use_graph, step_fn = False, eng.train_step
         torch.cuda.synchronize()
 
     def sync():

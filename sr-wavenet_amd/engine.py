@@ -95,7 +95,11 @@ class WaveNetEngine:
         self.spans: Dict[str, list] = {}
         import os as _os
         self.overlap = _os.environ.get("SRWN_OVERLAP", "1") != "0"
-        self.side = torch.cuda.Stream() if (torch.cuda.is_available() and self.overlap) else None
+        self.side = None
+        if torch.cuda.is_available() and self.overlap:
+            # weight-gradient passes are throughput work: lowest priority, so the latency-critical dgrad
+            # chain on the main stream gets CU slots first
+            self.side = torch.cuda.Stream(priority=0)
         self.B, self.T = int(batch), int(length)
         self.N = self.B * self.T
         self.L = len(cfg.dilations)
@@ -619,4 +623,24 @@ class WaveNetEngine:
         self.backward()
         self.allreduce_grads()
         self.optimizer_step()
+        return self.loss
+
+    def capture_graphs(self):
+        """Captures the step as two hipGraphs -- {forward, backward} and {Adam, re-pack} -- with the
+        gradient all-reduce left between them as an ordinary RCCL call, so one and many GPUs replay the
+        same launch-free kernel sequence.  Call after at least one eager train_step (warm-up)."""
+        torch.cuda.synchronize()
+        self._g_fb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g_fb):
+            self.forward()
+            self.backward()
+        self._g_opt = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g_opt, pool=self._g_fb.pool()):
+            self.optimizer_step()
+        torch.cuda.synchronize()
+
+    def train_step_graphed(self) -> torch.Tensor:
+        self._g_fb.replay()
+        self.allreduce_grads()
+        self._g_opt.replay()
         return self.loss

@@ -209,3 +209,45 @@ def test_wgrad256(dt, mode, rows):
     K.reduce_partials(bparts, ns, 256, 1, True, 1.0, bout.data_ptr(), 0)
     assert rel_err(out.cpu().numpy(), ref) < TOL[dt]
     assert rel_err(bout.cpu().numpy(), d.double().cpu().numpy().sum(0)) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("with_cond", [False, True])
+def test_wgrad_layers_fused(dt, with_cond):
+    """conv taps + 1x1 residual gradients of several layers in one pass (srwn_wgrad_layers)."""
+    K = sub("kernels")
+    L, B, T, R, pool = 3, 2, 352, 64, 32
+    rows = B * T
+    dil = [1, 16, 300]
+    rng = np.random.default_rng(7)
+    x = dev(rng.standard_normal((L, rows, R)), dt); z = dev(np.tanh(rng.standard_normal((L, rows, R))), dt)
+    df = dev(rng.standard_normal((L, rows, R)), dt); g = dev(rng.standard_normal((L, rows, R)), dt)
+    cond = dev(rng.standard_normal((B * (T // pool), L * R)), dt) if with_cond else None
+    ns = K.wgrad_slabs(rows)
+    pf = torch.full((L * ns * 2 * R * R,), float("nan"), dtype=torch.float32, device=DEV)
+    pr = torch.full((L * ns * R * R,), float("nan"), dtype=torch.float32, device=DEV)
+    pbf = torch.full((L * ns * R,), float("nan"), dtype=torch.float32, device=DEV); pbr = torch.full_like(pbf, float("nan"))
+    ckw = dict(cond_ptr=cond.data_ptr(), cond_layer_stride=R, cond_frames=T // pool, pool_stride=pool,
+               cond_row_stride=L * R) if with_cond else {}
+    K.wgrad_layers(x, z, df, g.data_ptr(), dil, pf, pr, pbf, pbr, T, ns, **ckw)
+    of = torch.empty((L, 2, R, R), dtype=torch.float32, device=DEV); orr = torch.empty((L, R, R), dtype=torch.float32, device=DEV)
+    obf = torch.empty((L, R), dtype=torch.float32, device=DEV); obr = torch.empty((L, R), dtype=torch.float32, device=DEV)
+    K.reduce_partials(pf, ns, 2 * R * R, L, True, 1.0, of.data_ptr(), 2 * R * R)
+    K.reduce_partials(pr, ns, R * R, L, True, 1.0, orr.data_ptr(), R * R)
+    K.reduce_partials(pbf, ns, R, L, True, 1.0, obf.data_ptr(), R); K.reduce_partials(pbr, ns, R, L, True, 1.0, obr.data_ptr(), R)
+    q = lambda t: t.double().cpu().numpy()
+    for l in range(L):
+        xin = q(x[l]).reshape(B, T, R)
+        if with_cond:
+            cb = q(cond).reshape(B, T // pool, L, R)[:, :, l, :]
+            xin = xin + np.repeat(cb, pool, axis=1)
+            if dt == torch.bfloat16:
+                xin = dev(xin, dt).double().cpu().numpy()
+        dfl = q(df[l]).reshape(B, T, R); gl = q(g[l]).reshape(B, T, R)
+        zl = q(z[l]).reshape(B, T, R); c = zl / (1 + np.exp(-zl))
+        if dt == torch.bfloat16:
+            c = dev(c, dt).double().cpu().numpy()
+        _, dw = O._conv_backward(xin, np.zeros((2, R, R)), dil[l], dfl)
+        assert rel_err(of[l].cpu().numpy(), dw) < TOL[dt], l
+        assert rel_err(orr[l].cpu().numpy(), np.einsum("btn,btm->nm", c, gl)) < TOL[dt], l
+        assert rel_err(obf[l].cpu().numpy(), dfl.sum((0, 1))) < TOL[dt] and rel_err(obr[l].cpu().numpy(), gl.sum((0, 1))) < TOL[dt]
