@@ -199,7 +199,7 @@ extern "C" int srwn_causal_conv1d_fwd(const float* x, const float* w, const floa
 // stage 1: block p sums rows [p*ROWS, (p+1)*ROWS) of the flattened [B*T] axis -> partials[p][(K+1)*R]
 // stage 2: fixed-order sum over p.
 // ------------------------------------------------------------------------------------------
-constexpr int kIcRows = 2048;
+constexpr int kIcRows = 256;
 
 template <typename T>
 __global__ __launch_bounds__(256) void init_conv_wgrad_stage1(const float* __restrict__ audio,
@@ -257,13 +257,20 @@ __global__ __launch_bounds__(256) void init_conv_wgrad_stage1(const float* __res
   }
 }
 
-__global__ void init_conv_wgrad_stage2(const float* __restrict__ partials, int64_t nparts, float* __restrict__ gw,
-                                       float* __restrict__ gb, int R, int K) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per output element: lanes stride over the partials (fixed order), then a shuffle tree
+__global__ __launch_bounds__(256) void init_conv_wgrad_stage2(const float* __restrict__ partials, int64_t nparts,
+                                                              float* __restrict__ gw, float* __restrict__ gb, int R,
+                                                              int K) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= (K + 1) * R) return;
-  double s = 0.0;
-  for (int64_t p = 0; p < nparts; ++p) s += (double)partials[p * (K + 1) * R + i];
-  if (i < K * R) gw[i] = (float)s; else gb[i - K * R] = (float)s;
+  float s = 0.0f;
+  for (int64_t p = lane; p < nparts; p += 64) s += partials[p * (K + 1) * R + i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if (lane == 0) {
+    if (i < K * R) gw[i] = s; else gb[i - K * R] = s;
+  }
 }
 
 extern "C" int64_t srwn_init_conv_wgrad_partials(int32_t B, int32_t T, int32_t R, int32_t K) {
@@ -292,8 +299,8 @@ extern "C" int srwn_init_conv_wgrad(const float* audio, const void* g, float* pa
   int rc = check_launch("init_conv_wgrad_stage1");
   if (rc) return rc;
   int n = (K + 1) * R;
-  hipLaunchKernelGGL(init_conv_wgrad_stage2, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, partials,
-                     nparts, gw, gb, R, K);
+  hipLaunchKernelGGL(init_conv_wgrad_stage2, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, partials, nparts,
+                     gw, gb, R, K);
   return check_launch("init_conv_wgrad_stage2");
 }
 

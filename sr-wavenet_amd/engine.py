@@ -484,7 +484,8 @@ class WaveNetEngine:
             main.wait_stream(side)
 
     def _wl_groups(self):
-        per = 6
+        import os as _os
+        per = int(_os.environ.get("SRWN_WL_GROUP", "6"))
         return [(l0, min(l0 + per, self.L)) for l0 in range(0, self.L, per)]
 
     def _bwd_head(self):
