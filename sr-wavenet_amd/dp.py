@@ -36,7 +36,7 @@ def world_size(group=None) -> int:
 
 def allreduce_sum_(flat: torch.Tensor, group=None, async_op: bool = False):
     """In-place SUM of the flat gradient buffer over ranks (no-op for a single process)."""
-    if world_size(group) > 1:
+    if world_size(group) > 1 or (dist.is_available() and dist.is_initialized() and os.environ.get("SRWN_FORCE_DIST") == "1"):
         return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
     return None
 
