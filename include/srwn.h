@@ -204,6 +204,25 @@ int srwn_wgrad_layers(const void* x, const void* z, const void* df, const void* 
                       float* part_r, float* part_bf, float* part_br, int64_t rows, int32_t T, int32_t nslabs,
                       int32_t R, int32_t K, int32_t dtype, void* stream);
 
+/* ---- queue-cached incremental generation (BASELINE config 5; the reference only has the O(T^2 L) loop
+ * of teacher.py:140-171).  One persistent workgroup generates `nsteps` samples for up to 32 utterances
+ * with the arithmetic of the training graph (RightShift input conv model.py:172-173, layers ops.py:23-46,
+ * head model.py:50-56, softmax over C mu-law classes, decode ops.py:96-104), keeping per layer a ring of
+ * the last d_l+1 layer inputs (`ring`: srwn_generate_ring_elems elements of `dtype`, zero-initialised).
+ * wcr: per layer, back to back, [conv image R/32 x 2R/16 (tap 0 natural, tap 1 permuted k order) |
+ * residual image R/32 x R/16 (permuted)];  wskip: [S/32][L*R/16] in PERMUTED k order (its B operand is the
+ * gate tile in registers); w1/w2/biases as for the training kernels.
+ * mode 0 = argmax, 1 = categorical sample (counter-based RNG on seed, utterance, step).
+ * forced != NULL: teacher forcing -- step t consumes forced[u, t-1] instead of its own sample (parity test).
+ * audio_out/codes_out/forced are [B, Tout]; logits_out (may be NULL) [B, Tout, C] fp32. */
+int64_t srwn_generate_ring_elems(const int32_t* dilations, int32_t nlayers, int32_t R);
+int srwn_generate(const void* wcr, const void* wskip, const void* w1, const void* w2, const float* bias_f,
+                  const float* bias_r, const float* bs_sum, const float* b1, const float* b2, const float* init_w,
+                  const float* init_b, void* ring, float* audio_out, int32_t* codes_out, float* logits_out,
+                  const float* forced, const int32_t* dilations, int32_t nlayers, int32_t B, int32_t Tout,
+                  int32_t nsteps, int32_t R, int32_t S, int32_t C, int32_t K, int32_t mode, uint64_t seed,
+                  int32_t dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

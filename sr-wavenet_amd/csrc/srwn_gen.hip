@@ -1,0 +1,347 @@
+// Queue-cached incremental (autoregressive) generation for the mu-law softmax teacher.
+//
+// The reference has no fast generator: its only sampler re-runs the whole clip once per
+// generated sample (teacher.py:140-171, O(T^2 L)).  This kernel keeps, per layer, a ring of the last
+// d_l + 1 layer inputs and produces one sample per step with exactly the arithmetic of the training
+// graph (ops.py:23-46, model.py:158-196 with RightShift), so step t's logits equal the full forward's
+// logits[:, t] on the same prefix -- the property the parity test pins.
+//
+// One persistent workgroup (4 waves) serves up to 32 utterances: the 32 utterances are the 32 columns of
+// the MFMA tiles, so a step costs the same MFMAs for 1 or 32 voices.  Per layer every wave runs the tiny
+// conv -> gate -> residual chain redundantly in registers (no intra-layer exchange) and owns one quarter
+// (64 channels) of the skip / head products; conv+residual weights of layer l+1 stream into LDS by LDS-DMA
+// while layer l computes; skip/head weights are read straight from L2 (each wave uses distinct rows).
+#include <cstdlib>
+#include "srwn_common.h"
+#include "srwn_host.h"
+#include "../../include/srwn.h"
+
+using namespace srwn;
+
+constexpr int kGenMaxLayers = 64;
+
+struct GenArgs {
+  const void* wcr;      // per layer: [conv image RT x 2KS (tap0 natural, tap1 permuted) | res image RT x KS (permuted)]
+  const void* wskip;    // [S/32][L*R/16] permuted k order (B operand = gate tile in registers)
+  const void* w1;       // [S/32][S/16] natural
+  const void* w2;       // [Cp/32][S/16] natural
+  const float* bias_f; const float* bias_r;   // [L][R]
+  const float* bs_sum; const float* b1; const float* b2;   // [S], [S], [Cp]
+  const float* init_w; const float* init_b;   // [2][R], [R]
+  void* ring;           // layer input rings, element offsets ring_off[l], depth dil[l]+1 slots of [32][R]
+  float* audio_out; int32_t* codes_out; float* logits_out; const float* forced;
+  int B, Tout, nsteps, L, C, mode, Q;
+  unsigned long long seed;
+  int dil[kGenMaxLayers];
+  long long ring_off[kGenMaxLayers];
+};
+
+__device__ __forceinline__ float gen_mu_law_decode(int code, int Q) {   // ops.py:96-104, as srwn_mu_law_decode
+  const float mu = (float)(Q - 1);
+  const float signal = __fadd_rn(__fmul_rn(2.0f, __fdiv_rn((float)code, mu)), -1.0f);
+  const float p = (float)pow((double)Q, (double)fabsf(signal));
+  const float magnitude = __fmul_rn((float)(1.0 / (double)(Q - 1)), __fadd_rn(p, -1.0f));
+  const float sgn = (signal > 0.0f) ? 1.0f : ((signal < 0.0f) ? -1.0f : 0.0f);
+  return __fmul_rn(sgn, magnitude);
+}
+
+__device__ __forceinline__ float gen_uniform(unsigned long long seed, unsigned u, unsigned t) {
+  unsigned long long x = seed + 0x9E3779B97F4A7C15ull * ((unsigned long long)u * 0x100000001ull + t + 1);
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+  return (float)((x >> 40) + 0.5) * (1.0f / 16777216.0f);   // (0,1)
+}
+
+template <typename T, int NBUF>
+__global__ __launch_bounds__(256) void generate_kernel(GenArgs a) {
+  constexpr int RT = 2, R = 64, KS = 4, S = 256, SQ = 64;       // SQ: skip/head channels per wave
+  constexpr int FB = sizeof(Frag<T>) * 64;
+  constexpr int LAYER_FR = RT * 2 * KS + RT * KS;                // 24 fragment images per layer (conv + res)
+  constexpr int LAYER_B = LAYER_FR * FB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* wbuf = smem;                                             // [NBUF][LAYER_B]
+  T* xch = reinterpret_cast<T*>(smem + NBUF * LAYER_B);          // [32][S] activation exchange (r0 / r1)
+  float* lgl = reinterpret_cast<float*>(xch + 32 * S);           // [32][S] logits
+  float* prev = lgl + 32 * S;                                    // [2][32] last two samples
+
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int col = lane & 31, half = lane >> 5;
+  const int u0 = blockIdx.x * 32;                                // first utterance of this group
+  const int ug = u0 + col;                                       // this lane's utterance
+  const bool uok = ug < a.B;
+  const char* wcr = reinterpret_cast<const char*>(a.wcr);
+  const Frag<T>* wskip = reinterpret_cast<const Frag<T>*>(a.wskip);
+  const Frag<T>* w1 = reinterpret_cast<const Frag<T>*>(a.w1);
+  const Frag<T>* w2 = reinterpret_cast<const Frag<T>*>(a.w2);
+  const int ks_skip = a.L * KS;
+  T* ring = reinterpret_cast<T*>(a.ring);
+  int par = 0;   // which weight buffer holds the layer being computed (toggles every layer, across steps)
+
+  if (threadIdx.x < 64) prev[threadIdx.x] = 0.0f;
+  lds_dma_copy(wcr, wbuf, LAYER_B, wave, lane, 4);
+  __syncthreads();
+
+  for (int t = 0; t < a.nsteps; ++t) {
+    // ---- input conv with RightShift (model.py:172-173): h0[t] = w[0]*audio[t-2] + w[1]*audio[t-1] + b
+    float a1 = 0.0f, a2 = 0.0f;
+    if (uok) {
+      if (a.forced) {
+        if (t >= 1) a1 = a.forced[(size_t)ug * a.Tout + t - 1];
+        if (t >= 2) a2 = a.forced[(size_t)ug * a.Tout + t - 2];
+      } else {
+        a1 = prev[col];
+        a2 = prev[32 + col];
+      }
+    }
+    float h[RT][16];
+#pragma unroll
+    for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int n = 32 * mt + crow(q, half);
+        h[mt][q] = fmaf(a.init_w[n], a2, fmaf(a.init_w[R + n], a1, a.init_b[n]));
+      }
+    f32x16 accS[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) accS[m][q] = a.bs_sum[SQ * wave + 32 * m + crow(q, half)];
+
+    for (int l = 0; l < a.L; ++l) {
+      const int d = a.dil[l];
+      const int depth = d + 1;
+      const int buf = (NBUF == 2) ? par : 0;
+      if (NBUF == 2) {   // stream the next layer's (or next step's first layer's) conv+res weights
+        const int ln = (l + 1 < a.L) ? l + 1 : 0;
+        lds_dma_copy(wcr + (size_t)ln * LAYER_B, wbuf + (par ^ 1) * LAYER_B, LAYER_B, wave, lane, 4);
+        par ^= 1;
+      }
+      T* rl = ring + a.ring_off[l];
+      // tap 0: x_l[t-d] from the ring (zero before the clip starts)
+      Frag<T> xd[KS];
+      {
+        const int td = t - d;
+        const int slot = (td >= 0 ? td : 0) % depth;
+        const T* p = rl + ((size_t)slot * 32 + col) * R + 8 * half;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xd[ks] = load_nat(p + 16 * ks);
+        if (td < 0) {
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) xd[ks] = zero_frag<T>();
+        }
+      }
+      // x_l[t] -> ring (one writer), and as the permuted-order B fragments of tap 1
+      Frag<T> xc[KS];
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xc[s].set(j, h[s >> 1][8 * (s & 1) + j]);
+      if (wave == 0) {
+        T* wp = rl + ((size_t)(t % depth) * 32 + col) * R;
+#pragma unroll
+        for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            store4(wp + 32 * mt + 8 * g + 4 * half, h[mt][4 * g], h[mt][4 * g + 1], h[mt][4 * g + 2], h[mt][4 * g + 3]);
+      }
+      // in bf16 mode the residual operand is the rounded activation the training graph stored
+#pragma unroll
+      for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) h[mt][q] = xc[2 * mt + (q >> 3)].get(q & 7);
+
+      const Frag<T>* lw = reinterpret_cast<const Frag<T>*>(wbuf + buf * LAYER_B) + lane;
+      f32x16 accF[RT];
+#pragma unroll
+      for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) accF[mt][q] = a.bias_f[l * R + 32 * mt + crow(q, half)];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int mt = 0; mt < RT; ++mt) {
+          mma(accF[mt], lw[(mt * 2 * KS + ks) * 64], xd[ks]);
+          mma(accF[mt], lw[(mt * 2 * KS + KS + ks) * 64], xc[ks]);
+        }
+      Frag<T> cf[KS];
+#pragma unroll
+      for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          float z = Math<T>::tanh_(accF[mt][q]);
+          z = (float)(T)z;   // the training graph stores z in T and rebuilds the gate from it
+          cf[2 * mt + (q >> 3)].set(q & 7, gate_of_z<T>(z));
+        }
+      f32x16 accR[RT];
+#pragma unroll
+      for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) accR[mt][q] = a.bias_r[l * R + 32 * mt + crow(q, half)];
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int mt = 0; mt < RT; ++mt) mma(accR[mt], lw[(RT * 2 * KS + mt * KS + s) * 64], cf[s]);
+#pragma unroll
+      for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) h[mt][q] = (h[mt][q] + accR[mt][q]) * kSqrtHalf;
+      // this wave's quarter of the skip 1x1 (ops.py:44), accumulated over layers (model.py:50)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const Frag<T> af = wskip[((size_t)(2 * wave + m) * ks_skip + l * KS + ks) * 64 + lane];
+          mma(accS[m], af, cf[ks]);
+        }
+      __syncthreads();   // next layer's weights landed; ring write of this layer ordered before later reads
+      if (NBUF == 1) {
+        const int ln = (l + 1 < a.L) ? l + 1 : 0;
+        lds_dma_copy(wcr + (size_t)ln * LAYER_B, wbuf, LAYER_B, wave, lane, 4);
+        __syncthreads();
+      }
+    }
+
+    // ---- head: relu(sum skip) -> 1x1 + relu -> 1x1 (model.py:51-56); quarters exchanged through LDS
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        store4(xch + col * S + SQ * wave + 32 * m + 8 * g + 4 * half, fmaxf(accS[m][4 * g], 0.f),
+               fmaxf(accS[m][4 * g + 1], 0.f), fmaxf(accS[m][4 * g + 2], 0.f), fmaxf(accS[m][4 * g + 3], 0.f));
+    __syncthreads();
+    f32x16 acc1[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc1[m][q] = a.b1[SQ * wave + 32 * m + crow(q, half)];
+    for (int ks = 0; ks < S / 16; ++ks) {
+      const Frag<T> bf = load_nat(xch + col * S + 16 * ks + 8 * half);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) mma(acc1[m], w1[((size_t)(2 * wave + m) * (S / 16) + ks) * 64 + lane], bf);
+    }
+    __syncthreads();   // everyone has read r0
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        store4(xch + col * S + SQ * wave + 32 * m + 8 * g + 4 * half, fmaxf(acc1[m][4 * g], 0.f),
+               fmaxf(acc1[m][4 * g + 1], 0.f), fmaxf(acc1[m][4 * g + 2], 0.f), fmaxf(acc1[m][4 * g + 3], 0.f));
+    __syncthreads();
+    f32x16 acc2[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc2[m][q] = a.b2[SQ * wave + 32 * m + crow(q, half)];
+    for (int ks = 0; ks < S / 16; ++ks) {
+      const Frag<T> bf = load_nat(xch + col * S + 16 * ks + 8 * half);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) mma(acc2[m], w2[((size_t)(2 * wave + m) * (S / 16) + ks) * 64 + lane], bf);
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<f32x4*>(lgl + col * S + SQ * wave + 32 * m + 8 * g + 4 * half) =
+            f32x4{acc2[m][4 * g], acc2[m][4 * g + 1], acc2[m][4 * g + 2], acc2[m][4 * g + 3]};
+    __syncthreads();
+
+    // ---- softmax over the C classes of each utterance, pick a code, mu-law decode (wave 0)
+    if (wave == 0) {
+      const float* lr = lgl + col * S;
+      const int c0 = half * (S / 2), c1 = c0 + S / 2;
+      float m = -INFINITY; int am = 0;
+      for (int c = c0; c < c1; ++c)
+        if (c < a.C && lr[c] > m) { m = lr[c]; am = c; }
+      const float mo = __shfl_xor(m, 32); const int amo = __shfl_xor(am, 32);
+      if (mo > m || (mo == m && amo < am)) { m = mo; am = amo; }
+      int code = am;
+      if (a.mode == 1) {   // categorical sample from softmax(logits)
+        float sh = 0.0f;
+        for (int c = c0; c < c1; ++c)
+          if (c < a.C) sh += __expf(lr[c] - m);
+        const float so = __shfl_xor(sh, 32);
+        const float s_lo = half ? so : sh, s_hi = half ? sh : so;
+        const float target = gen_uniform(a.seed, (unsigned)ug, (unsigned)t) * (s_lo + s_hi);
+        const bool mine = half ? (target >= s_lo) : (target < s_lo);
+        float run = half ? s_lo : 0.0f;
+        int pick = -1;
+        for (int c = c0; c < c1; ++c) {
+          if (c >= a.C) break;
+          run += __expf(lr[c] - m);
+          if (pick < 0 && run > target) pick = c;
+        }
+        if (pick < 0) pick = (a.C - 1 < c1 - 1) ? a.C - 1 : c1 - 1;
+        const int other = __shfl_xor(pick, 32);
+        code = mine ? pick : other;
+      }
+      const float smp = gen_mu_law_decode(code, a.Q);
+      if (half == 0) {
+        if (uok) {
+          a.audio_out[(size_t)ug * a.Tout + t] = smp;
+          a.codes_out[(size_t)ug * a.Tout + t] = code;
+        }
+        prev[32 + col] = prev[col];
+        prev[col] = smp;
+      }
+      if (a.logits_out && uok) {
+        float* lo = a.logits_out + ((size_t)ug * a.Tout + t) * a.C;
+        for (int c = c0; c < c1; ++c)
+          if (c < a.C) lo[c] = lr[c];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int64_t srwn_generate_ring_elems(const int32_t* dilations, int32_t nlayers, int32_t R) {
+  int64_t n = 0;
+  for (int l = 0; l < nlayers; ++l) n += (int64_t)(dilations[l] + 1) * 32 * R;
+  return n;   // per group of 32 utterances
+}
+
+extern "C" int srwn_generate(const void* wcr, const void* wskip, const void* w1, const void* w2, const float* bias_f,
+                             const float* bias_r, const float* bs_sum, const float* b1, const float* b2,
+                             const float* init_w, const float* init_b, void* ring, float* audio_out,
+                             int32_t* codes_out, float* logits_out, const float* forced, const int32_t* dilations,
+                             int32_t nlayers, int32_t B, int32_t Tout, int32_t nsteps, int32_t R, int32_t S,
+                             int32_t C, int32_t K, int32_t mode, uint64_t seed, int32_t dtype, void* stream) {
+  if (B == 0 || nsteps == 0) return 0;
+  if (!wcr || !wskip || !w1 || !w2 || !bias_f || !bias_r || !bs_sum || !b1 || !b2 || !init_w || !init_b || !ring ||
+      !audio_out || !codes_out || !dilations)
+    return set_error(SRWN_E_NULL, "generate: null pointer");
+  if (R != 64 || S != 256 || K != 2 || C < 2 || C > 256)
+    return set_error(SRWN_E_UNSUPPORTED, "generate: built for R=64, S=256, K=2, C<=256 (got R=%d S=%d K=%d C=%d)", R, S, K, C);
+  if (B < 0 || nsteps < 0 || nsteps > Tout || nlayers < 1 || nlayers > kGenMaxLayers || (mode != 0 && mode != 1))
+    return set_error(SRWN_E_SHAPE, "generate: B=%d nsteps=%d Tout=%d layers=%d mode=%d", B, nsteps, Tout, nlayers, mode);
+  if (B > 32) return set_error(SRWN_E_UNSUPPORTED, "generate: one group of at most 32 utterances per call (got %d)", B);
+  GenArgs a;
+  a.wcr = wcr; a.wskip = wskip; a.w1 = w1; a.w2 = w2; a.bias_f = bias_f; a.bias_r = bias_r; a.bs_sum = bs_sum;
+  a.b1 = b1; a.b2 = b2; a.init_w = init_w; a.init_b = init_b; a.ring = ring; a.audio_out = audio_out;
+  a.codes_out = codes_out; a.logits_out = logits_out; a.forced = forced;
+  a.B = B; a.Tout = Tout; a.nsteps = nsteps; a.L = nlayers; a.C = C; a.mode = mode; a.Q = C; a.seed = seed;
+  long long off = 0;
+  for (int l = 0; l < kGenMaxLayers; ++l) {
+    a.dil[l] = (l < nlayers) ? dilations[l] : 1;
+    a.ring_off[l] = off;
+    if (l < nlayers) {
+      if (dilations[l] < 1) return set_error(SRWN_E_SHAPE, "generate: dilation %d", dilations[l]);
+      off += (long long)(dilations[l] + 1) * 32 * R;
+    }
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SRWN_BF16) {
+    auto kfn = generate_kernel<bf16_t, 2>;
+    const size_t sh = 2 * 24 * sizeof(Frag<bf16_t>) * 64 + 32 * 256 * sizeof(bf16_t) + 32 * 256 * 4 + 64 * 4;
+    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    if (e != hipSuccess) return set_error((int)e, "generate: LDS %zu: %s", sh, hipGetErrorString(e));
+    hipLaunchKernelGGL(kfn, dim3(1), dim3(256), sh, st, a);
+  } else if (dtype == SRWN_F32) {
+    auto kfn = generate_kernel<float, 1>;
+    const size_t sh = 1 * 24 * sizeof(Frag<float>) * 64 + 32 * 256 * sizeof(float) + 32 * 256 * 4 + 64 * 4;
+    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    if (e != hipSuccess) return set_error((int)e, "generate: LDS %zu: %s", sh, hipGetErrorString(e));
+    hipLaunchKernelGGL(kfn, dim3(1), dim3(256), sh, st, a);
+  } else {
+    return set_error(SRWN_E_DTYPE, "generate: dtype %d", dtype);
+  }
+  return check_launch("generate");
+}

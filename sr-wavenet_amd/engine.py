@@ -119,7 +119,7 @@ class WaveNetEngine:
             self._build_packing()
         else:   # another (batch, length) view of the same model: parameters, moments, images are shared
             for a in ("sections", "nparams", "params", "grads", "adam_m", "adam_v", "adam_step", "dead_gate",
-                      "packer", "packed", "o_conv", "o_res", "o_convT", "o_resT", "o_skipT", "o_skipT_all", "o_skip",
+                      "packer", "packed", "o_conv", "o_res", "o_convT", "o_resT", "o_skipT", "o_skipT_all", "o_skip", "o_gen", "o_skip_gen",
                       "o_w1", "o_w2",
                       "o_w1T", "o_w2T"):
                 setattr(self, a, getattr(share_from, a))
@@ -274,6 +274,19 @@ class WaveNetEngine:
             self.o_res.append(P.pack_res(pk, sec["WR"].offset + l * R * R, R))
             self.o_convT.append(P.pack_conv_T(pk, sec["WF"].offset + l * Kw * R * R, Kw, R))
             self.o_resT.append(P.pack_linear_T(pk, sec["WR"].offset + l * R * R, R, R, R, perm=True))
+        # generation images: per layer [conv (last tap permuted) | residual], back to back (srwn_generate)
+        self.o_gen = self.o_skip_gen = None
+        if R == 64 and S == 256 and Kw == 2:
+            for l in range(L):
+                o = P.pack_conv_gen(pk, sec["WF"].offset + l * Kw * R * R, Kw, R)
+                P.pack_res(pk, sec["WR"].offset + l * R * R, R)
+                if l == 0:
+                    self.o_gen = o
+            # skip kernels for generation: B operand is the gate tile in registers -> permuted k order
+            self.o_skip_gen = pk.reserve(S // 32, L * R // 16)
+            for l in range(L):
+                P.fill_linear(pk, self.o_skip_gen, sec["WS"].offset + l * R * S, R, S, S // 32, L * R // 16,
+                              ks_offset=l * R // 16, ks_count=R // 16, perm=True)
         # transposed skip kernels of all layers back to back (srwn_skip_dgrad_all streams them in order)
         per = (R // 32) * (S // 16) * 512
         self.o_skipT_all = pk.reserve(L * (R // 32), S // 16)
@@ -625,6 +638,38 @@ class WaveNetEngine:
         self.allreduce_grads()
         self.optimizer_step()
         return self.loss
+
+    def generate(self, nsteps: int, mode: str = "sample", seed: int = 0, forced: Optional[torch.Tensor] = None,
+                 want_logits: bool = False, batch: Optional[int] = None):
+        """Queue-cached autoregressive generation of `nsteps` samples for `batch` (<= 32) utterances.
+        Returns (audio [B,nsteps] f32, codes [B,nsteps] i32, logits [B,nsteps,C] f32 or None)."""
+        import ctypes as C
+        from . import _lib
+        if self.o_gen is None or self.E or self.pooled:
+            raise NotImplementedError("generate: built for the unconditioned per-time-step teacher with R=64, S=256, K=2")
+        B = int(batch or self.B)
+        dl = (C.c_int32 * self.L)(*self.dil)
+        relems = int(_lib.load().srwn_generate_ring_elems(dl, self.L, self.R))
+        ring = torch.zeros(relems, dtype=self.dt, device=self.dev)
+        audio = torch.zeros((B, nsteps), dtype=torch.float32, device=self.dev)
+        codes = torch.zeros((B, nsteps), dtype=torch.int32, device=self.dev)
+        logits = torch.zeros((B, nsteps, self.C), dtype=torch.float32, device=self.dev) if want_logits else None
+        fp = None
+        if forced is not None:
+            forced = forced.to(device=self.dev, dtype=torch.float32).contiguous()
+            if tuple(forced.shape) != (B, nsteps):
+                raise ValueError("forced must be [batch, nsteps]")
+            fp = forced.data_ptr()
+        v = self.view
+        K.reduce_partials(v("BS").reshape(-1), self.L, self.S, 1, True, 1.0, self.bs_sum.data_ptr(), 0)
+        _lib.call("srwn_generate", self.wptr(self.o_gen), self.wptr(self.o_skip_gen), self.wptr(self.o_w1),
+                  self.wptr(self.o_w2), v("BF").data_ptr(), v("BR").data_ptr(), self.bs_sum.data_ptr(),
+                  v("head_b1").data_ptr(), v("head_b2").data_ptr(), v("init_w").data_ptr(), v("init_b").data_ptr(),
+                  ring.data_ptr(), audio.data_ptr(), codes.data_ptr(), None if logits is None else logits.data_ptr(),
+                  fp, dl, self.L, B, nsteps, nsteps, self.R, self.S, self.C, self.Kw,
+                  {"argmax": 0, "sample": 1}[mode], int(seed), K.abi_dtype(self.dt),
+                  torch.cuda.current_stream().cuda_stream)
+        return audio, codes, logits
 
     def capture_graphs(self):
         """Captures the step as two hipGraphs -- {forward, backward} and {Adam, re-pack} -- with the

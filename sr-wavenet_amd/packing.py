@@ -65,3 +65,13 @@ def pack_conv_T(pk, src_offset: int, K: int, R: int) -> int:
         pk.fill(off, src_offset=src_offset + k * R * R, rows_valid=R, k_valid=R, row_stride=R, k_stride=1,
                 mt_count=mt, ks_total=ks_total, ks_offset=k * ks, ks_count=ks)
     return off
+
+
+def pack_conv_gen(pk, src_offset: int, K: int, R: int) -> int:
+    """Conv image for incremental generation: taps 0..K-2 natural, the last tap (whose B operand is the
+    previous layer's accumulator tile) in permuted k order."""
+    mt, ks_total = R // 32, K * R // 16
+    off = pk.reserve(mt, ks_total)
+    pk.fill(off, src_offset=src_offset, rows_valid=R, k_valid=K * R, row_stride=1, k_stride=R, mt_count=mt,
+            ks_total=ks_total, perm_from_ks=(K - 1) * R // 16)
+    return off

@@ -1,0 +1,17 @@
+#!/usr/bin/env python3
+"""Real-time factor of queue-cached generation, BASELINE config 5: 30-layer teacher, 16 kHz, 1 GPU."""
+import importlib, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import torch
+EG = importlib.import_module("sr-wavenet_amd.engine")
+dil = [1, 2, 4, 8, 16, 32, 64, 128, 256, 512] * 3
+for dt in (torch.bfloat16, torch.float32):
+    cfg = EG.StackConfig(dilations=dil, dilation_channels=64, skip_channels=256, output_channels=256, shift_input=True, dtype=dt)
+    eng = EG.WaveNetEngine(cfg, 1, 64, "cuda")
+    for B in (1, 32):
+        n = 4000
+        eng.generate(200, batch=B); torch.cuda.synchronize()
+        t0 = time.perf_counter(); a, c, _ = eng.generate(n, mode="sample", seed=1, batch=B); torch.cuda.synchronize()
+        dt_s = time.perf_counter() - t0
+        print("%s  B=%2d  %d steps in %.3f s -> %.1f us/step, RTF %.3f per stream (16 kHz), aggregate %.1fx real time"
+              % (str(dt).split(".")[-1], B, n, dt_s, dt_s / n * 1e6, dt_s / n * 16000, B * n / 16000 / dt_s), flush=True)
