@@ -205,10 +205,11 @@ int srwn_wgrad_layers(const void* x, const void* z, const void* df, const void* 
                       int32_t R, int32_t K, int32_t dtype, void* stream);
 
 /* ---- queue-cached incremental generation (BASELINE config 5; the reference only has the O(T^2 L) loop
- * of teacher.py:140-171).  One persistent workgroup generates `nsteps` samples for up to 32 utterances
+ * of teacher.py:140-171).  Persistent workgroups generate `nsteps` samples, 32 utterances per workgroup,
  * with the arithmetic of the training graph (RightShift input conv model.py:172-173, layers ops.py:23-46,
  * head model.py:50-56, softmax over C mu-law classes, decode ops.py:96-104), keeping per layer a ring of
- * the last d_l+1 layer inputs (`ring`: srwn_generate_ring_elems elements of `dtype`, zero-initialised).
+ * the last d_l+1 layer inputs (`ring`: ceil(B/32) * srwn_generate_ring_elems elements of `dtype`; one
+ * workgroup per group of 32 utterances).
  * wcr: per layer, back to back, [conv image R/32 x 2R/16 (tap 0 natural, tap 1 permuted k order) |
  * residual image R/32 x R/16 (permuted)];  wskip: [S/32][L*R/16] in PERMUTED k order (its B operand is the
  * gate tile in registers); w1/w2/biases as for the training kernels.

@@ -6,7 +6,7 @@
 // graph (ops.py:23-46, model.py:158-196 with RightShift), so step t's logits equal the full forward's
 // logits[:, t] on the same prefix -- the property the parity test pins.
 //
-// One persistent workgroup (4 waves) serves up to 32 utterances: the 32 utterances are the 32 columns of
+// One persistent workgroup (4 waves) serves a group of up to 32 utterances (grid = number of groups): the 32 utterances are the 32 columns of
 // the MFMA tiles, so a step costs the same MFMAs for 1 or 32 voices.  Per layer every wave runs the tiny
 // conv -> gate -> residual chain redundantly in registers (no intra-layer exchange) and owns one quarter
 // (64 channels) of the skip / head products; conv+residual weights of layer l+1 stream into LDS by LDS-DMA
@@ -31,6 +31,7 @@ struct GenArgs {
   void* ring;           // layer input rings, element offsets ring_off[l], depth dil[l]+1 slots of [32][R]
   float* audio_out; int32_t* codes_out; float* logits_out; const float* forced;
   int B, Tout, nsteps, L, C, mode, Q;
+  long long ring_group_elems;
   unsigned long long seed;
   int dil[kGenMaxLayers];
   long long ring_off[kGenMaxLayers];
@@ -62,10 +63,18 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a) {
   T* xch = reinterpret_cast<T*>(smem + NBUF * LAYER_B);          // [32][S] activation exchange (r0 / r1)
   float* lgl = reinterpret_cast<float*>(xch + 32 * S);           // [32][S] logits
   float* prev = lgl + 32 * S;                                    // [2][32] last two samples
+  float* cst = prev + 64;                                        // constants: biases of every layer + head + input conv
+  float* c_bf = cst;                 // [L][R]
+  float* c_br = c_bf + a.L * R;      // [L][R]
+  float* c_bs = c_br + a.L * R;      // [S]
+  float* c_b1 = c_bs + S;            // [S]
+  float* c_b2 = c_b1 + S;            // [S]
+  float* c_iw = c_b2 + S;            // [2][R]
+  float* c_ib = c_iw + 2 * R;        // [R]
 
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int col = lane & 31, half = lane >> 5;
-  const int u0 = blockIdx.x * 32;                                // first utterance of this group
+  const int u0 = blockIdx.x * 32;                                // first utterance of this workgroup's group
   const int ug = u0 + col;                                       // this lane's utterance
   const bool uok = ug < a.B;
   const char* wcr = reinterpret_cast<const char*>(a.wcr);
@@ -73,12 +82,34 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a) {
   const Frag<T>* w1 = reinterpret_cast<const Frag<T>*>(a.w1);
   const Frag<T>* w2 = reinterpret_cast<const Frag<T>*>(a.w2);
   const int ks_skip = a.L * KS;
-  T* ring = reinterpret_cast<T*>(a.ring);
+  T* ring = reinterpret_cast<T*>(a.ring) + (size_t)blockIdx.x * a.ring_group_elems;   // one ring set per group
   int par = 0;   // which weight buffer holds the layer being computed (toggles every layer, across steps)
 
+  for (int i = threadIdx.x; i < a.L * R; i += 256) { c_bf[i] = a.bias_f[i]; c_br[i] = a.bias_r[i]; }
+  for (int i = threadIdx.x; i < S; i += 256) { c_bs[i] = a.bs_sum[i]; c_b1[i] = a.b1[i]; c_b2[i] = a.b2[i]; }
+  if (threadIdx.x < 2 * R) c_iw[threadIdx.x] = a.init_w[threadIdx.x];
+  if (threadIdx.x < R) c_ib[threadIdx.x] = a.init_b[threadIdx.x];
   if (threadIdx.x < 64) prev[threadIdx.x] = 0.0f;
   lds_dma_copy(wcr, wbuf, LAYER_B, wave, lane, 4);
   __syncthreads();
+
+  // operands of one layer that do not depend on the current step's activations: the tap-0 window from
+  // the ring (written d >= 1 steps ago) and this wave's skip-weight fragments (from L2).  Loaded two
+  // layers ahead, unconditionally (clamped), so their latency hides behind the dependent MFMA chain.
+  struct Pre { Frag<T> xd[KS]; Frag<T> ws[2][KS]; };
+  auto preload = [&](int l_, int t, Pre& p) {
+    const int l = l_ < a.L ? l_ : a.L - 1;
+    const int d = a.dil[l], depth = d + 1;
+    const int td = t - d;
+    const int slot = (td >= 0 ? td : 0) % depth;
+    const T* rp = ring + a.ring_off[l] + ((size_t)slot * 32 + col) * R + 8 * half;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) p.xd[ks] = load_nat(rp + 16 * ks);
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) p.ws[m][ks] = wskip[((size_t)(2 * wave + m) * ks_skip + l * KS + ks) * 64 + lane];
+  };
 
   for (int t = 0; t < a.nsteps; ++t) {
     // ---- input conv with RightShift (model.py:172-173): h0[t] = w[0]*audio[t-2] + w[1]*audio[t-1] + b
@@ -98,15 +129,15 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int n = 32 * mt + crow(q, half);
-        h[mt][q] = fmaf(a.init_w[n], a2, fmaf(a.init_w[R + n], a1, a.init_b[n]));
+        h[mt][q] = fmaf(c_iw[n], a2, fmaf(c_iw[R + n], a1, c_ib[n]));
       }
     f32x16 accS[2];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) accS[m][q] = a.bs_sum[SQ * wave + 32 * m + crow(q, half)];
+      for (int q = 0; q < 16; ++q) accS[m][q] = c_bs[SQ * wave + 32 * m + crow(q, half)];
 
-    for (int l = 0; l < a.L; ++l) {
+    auto layer = [&](int l, const Pre& p, Pre& pfill, int lfill) {
       const int d = a.dil[l];
       const int depth = d + 1;
       const int buf = (NBUF == 2) ? par : 0;
@@ -115,28 +146,19 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a) {
         lds_dma_copy(wcr + (size_t)ln * LAYER_B, wbuf + (par ^ 1) * LAYER_B, LAYER_B, wave, lane, 4);
         par ^= 1;
       }
-      T* rl = ring + a.ring_off[l];
-      // tap 0: x_l[t-d] from the ring (zero before the clip starts)
+      preload(lfill, t, pfill);   // issued AFTER the LDS-DMA so the counted wait below leaves it in flight
       Frag<T> xd[KS];
-      {
-        const int td = t - d;
-        const int slot = (td >= 0 ? td : 0) % depth;
-        const T* p = rl + ((size_t)slot * 32 + col) * R + 8 * half;
+      const bool tap0 = (t - d) >= 0;   // zero before the clip starts
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) xd[ks] = load_nat(p + 16 * ks);
-        if (td < 0) {
-#pragma unroll
-          for (int ks = 0; ks < KS; ++ks) xd[ks] = zero_frag<T>();
-        }
-      }
+      for (int ks = 0; ks < KS; ++ks) xd[ks] = tap0 ? p.xd[ks] : zero_frag<T>();
       // x_l[t] -> ring (one writer), and as the permuted-order B fragments of tap 1
       Frag<T> xc[KS];
 #pragma unroll
       for (int s = 0; s < KS; ++s)
 #pragma unroll
         for (int j = 0; j < 8; ++j) xc[s].set(j, h[s >> 1][8 * (s & 1) + j]);
-      if (wave == 0) {
-        T* wp = rl + ((size_t)(t % depth) * 32 + col) * R;
+      if (wave == 0) {   // one writer per ring slot
+        T* wp = ring + a.ring_off[l] + ((size_t)(t % depth) * 32 + col) * R;
 #pragma unroll
         for (int mt = 0; mt < RT; ++mt)
 #pragma unroll
@@ -154,7 +176,7 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a) {
 #pragma unroll
       for (int mt = 0; mt < RT; ++mt)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) accF[mt][q] = a.bias_f[l * R + 32 * mt + crow(q, half)];
+        for (int q = 0; q < 16; ++q) accF[mt][q] = c_bf[l * R + 32 * mt + crow(q, half)];
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -175,7 +197,7 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a) {
 #pragma unroll
       for (int mt = 0; mt < RT; ++mt)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) accR[mt][q] = a.bias_r[l * R + 32 * mt + crow(q, half)];
+        for (int q = 0; q < 16; ++q) accR[mt][q] = c_br[l * R + 32 * mt + crow(q, half)];
 #pragma unroll
       for (int s = 0; s < KS; ++s)
 #pragma unroll
@@ -188,16 +210,25 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a) {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          const Frag<T> af = wskip[((size_t)(2 * wave + m) * ks_skip + l * KS + ks) * 64 + lane];
-          mma(accS[m], af, cf[ks]);
-        }
+        for (int m = 0; m < 2; ++m) mma(accS[m], p.ws[m][ks], cf[ks]);
       __syncthreads();   // next layer's weights landed; ring write of this layer ordered before later reads
       if (NBUF == 1) {
         const int ln = (l + 1 < a.L) ? l + 1 : 0;
         lds_dma_copy(wcr + (size_t)ln * LAYER_B, wbuf, LAYER_B, wave, lane, 4);
         __syncthreads();
       }
+    };
+
+    // three rotating operand sets: layer l computes while l+1 and l+2 are in flight
+    Pre p0, p1, p2;
+    preload(0, t, p0);
+    preload(1, t, p1);
+    for (int l = 0; l < a.L; l += 3) {
+      layer(l, p0, p2, l + 2);
+      if (l + 1 >= a.L) break;
+      layer(l + 1, p1, p0, l + 3);
+      if (l + 2 >= a.L) break;
+      layer(l + 2, p2, p1, l + 4);
     }
 
     // ---- head: relu(sum skip) -> 1x1 + relu -> 1x1 (model.py:51-56); quarters exchanged through LDS
@@ -212,7 +243,8 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a) {
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) acc1[m][q] = a.b1[SQ * wave + 32 * m + crow(q, half)];
+      for (int q = 0; q < 16; ++q) acc1[m][q] = c_b1[SQ * wave + 32 * m + crow(q, half)];
+#pragma unroll
     for (int ks = 0; ks < S / 16; ++ks) {
       const Frag<T> bf = load_nat(xch + col * S + 16 * ks + 8 * half);
 #pragma unroll
@@ -230,7 +262,8 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a) {
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) acc2[m][q] = a.b2[SQ * wave + 32 * m + crow(q, half)];
+      for (int q = 0; q < 16; ++q) acc2[m][q] = c_b2[SQ * wave + 32 * m + crow(q, half)];
+#pragma unroll
     for (int ks = 0; ks < S / 16; ++ks) {
       const Frag<T> bf = load_nat(xch + col * S + 16 * ks + 8 * half);
 #pragma unroll
@@ -244,48 +277,57 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a) {
             f32x4{acc2[m][4 * g], acc2[m][4 * g + 1], acc2[m][4 * g + 2], acc2[m][4 * g + 3]};
     __syncthreads();
 
-    // ---- softmax over the C classes of each utterance, pick a code, mu-law decode (wave 0)
-    if (wave == 0) {
-      const float* lr = lgl + col * S;
-      const int c0 = half * (S / 2), c1 = c0 + S / 2;
+    // ---- softmax over the C classes, pick a code, mu-law decode: wave w serves utterances 8w..8w+7 with
+    //      lanes = classes (4 per lane: conflict-free LDS rows, shuffle reductions instead of serial loops)
+    for (int i = 0; i < 8; ++i) {
+      const int ul = 8 * wave + i;                        // wave-uniform, local to the group
+      const int u = u0 + ul;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(lgl + ul * S + 4 * lane);
       float m = -INFINITY; int am = 0;
-      for (int c = c0; c < c1; ++c)
-        if (c < a.C && lr[c] > m) { m = lr[c]; am = c; }
-      const float mo = __shfl_xor(m, 32); const int amo = __shfl_xor(am, 32);
-      if (mo > m || (mo == m && amo < am)) { m = mo; am = amo; }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (4 * lane + e < a.C && v[e] > m) { m = v[e]; am = 4 * lane + e; }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const float mo = __shfl_xor(m, off); const int ao = __shfl_xor(am, off);
+        if (mo > m || (mo == m && ao < am)) { m = mo; am = ao; }
+      }
       int code = am;
-      if (a.mode == 1) {   // categorical sample from softmax(logits)
-        float sh = 0.0f;
-        for (int c = c0; c < c1; ++c)
-          if (c < a.C) sh += __expf(lr[c] - m);
-        const float so = __shfl_xor(sh, 32);
-        const float s_lo = half ? so : sh, s_hi = half ? sh : so;
-        const float target = gen_uniform(a.seed, (unsigned)ug, (unsigned)t) * (s_lo + s_hi);
-        const bool mine = half ? (target >= s_lo) : (target < s_lo);
-        float run = half ? s_lo : 0.0f;
-        int pick = -1;
-        for (int c = c0; c < c1; ++c) {
-          if (c >= a.C) break;
-          run += __expf(lr[c] - m);
-          if (pick < 0 && run > target) pick = c;
+      if (a.mode == 1) {   // categorical sample from softmax(logits): inclusive prefix sums over the lanes
+        float ev[4], loc = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ev[e] = (4 * lane + e < a.C) ? __expf(v[e] - m) : 0.0f; loc += ev[e]; }
+        float inc = loc;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const float o = __shfl_up(inc, off);
+          if (lane >= off) inc += o;
         }
-        if (pick < 0) pick = (a.C - 1 < c1 - 1) ? a.C - 1 : c1 - 1;
-        const int other = __shfl_xor(pick, 32);
-        code = mine ? pick : other;
+        const float total = __shfl(inc, 63);
+        const float target = gen_uniform(a.seed, (unsigned)u, (unsigned)t) * total;
+        const unsigned long long hit = __ballot(inc > target);
+        const int src = hit ? (__ffsll((long long)hit) - 1) : 63;
+        float run = inc - loc;
+        int pick = 4 * lane + 3;
+#pragma unroll
+        for (int e = 3; e >= 0; --e) { if (run + ev[0] + (e > 0 ? ev[1] : 0.f) + (e > 1 ? ev[2] : 0.f) + (e > 2 ? ev[3] : 0.f) > target) pick = 4 * lane + e; }
+        if (pick >= a.C) pick = a.C - 1;
+        code = __shfl(pick, src);
       }
-      const float smp = gen_mu_law_decode(code, a.Q);
-      if (half == 0) {
-        if (uok) {
-          a.audio_out[(size_t)ug * a.Tout + t] = smp;
-          a.codes_out[(size_t)ug * a.Tout + t] = code;
+      if (lane == 0) {
+        const float smp = gen_mu_law_decode(code, a.Q);
+        if (u < a.B) {
+          a.audio_out[(size_t)u * a.Tout + t] = smp;
+          a.codes_out[(size_t)u * a.Tout + t] = code;
         }
-        prev[32 + col] = prev[col];
-        prev[col] = smp;
+        prev[32 + ul] = prev[ul];
+        prev[ul] = smp;
       }
-      if (a.logits_out && uok) {
-        float* lo = a.logits_out + ((size_t)ug * a.Tout + t) * a.C;
-        for (int c = c0; c < c1; ++c)
-          if (c < a.C) lo[c] = lr[c];
+      if (a.logits_out && u < a.B && 4 * lane < a.C) {
+        float* lo = a.logits_out + ((size_t)u * a.Tout + t) * a.C + 4 * lane;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (4 * lane + e < a.C) lo[e] = v[e];
       }
     }
     __syncthreads();
@@ -312,7 +354,6 @@ extern "C" int srwn_generate(const void* wcr, const void* wskip, const void* w1,
     return set_error(SRWN_E_UNSUPPORTED, "generate: built for R=64, S=256, K=2, C<=256 (got R=%d S=%d K=%d C=%d)", R, S, K, C);
   if (B < 0 || nsteps < 0 || nsteps > Tout || nlayers < 1 || nlayers > kGenMaxLayers || (mode != 0 && mode != 1))
     return set_error(SRWN_E_SHAPE, "generate: B=%d nsteps=%d Tout=%d layers=%d mode=%d", B, nsteps, Tout, nlayers, mode);
-  if (B > 32) return set_error(SRWN_E_UNSUPPORTED, "generate: one group of at most 32 utterances per call (got %d)", B);
   GenArgs a;
   a.wcr = wcr; a.wskip = wskip; a.w1 = w1; a.w2 = w2; a.bias_f = bias_f; a.bias_r = bias_r; a.bs_sum = bs_sum;
   a.b1 = b1; a.b2 = b2; a.init_w = init_w; a.init_b = init_b; a.ring = ring; a.audio_out = audio_out;
@@ -327,19 +368,23 @@ extern "C" int srwn_generate(const void* wcr, const void* wskip, const void* w1,
       off += (long long)(dilations[l] + 1) * 32 * R;
     }
   }
+  a.ring_group_elems = off;
+  const unsigned groups = (unsigned)((B + 31) / 32);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == SRWN_BF16) {
     auto kfn = generate_kernel<bf16_t, 2>;
-    const size_t sh = 2 * 24 * sizeof(Frag<bf16_t>) * 64 + 32 * 256 * sizeof(bf16_t) + 32 * 256 * 4 + 64 * 4;
+    const size_t sh = 2 * 24 * sizeof(Frag<bf16_t>) * 64 + 32 * 256 * sizeof(bf16_t) + 32 * 256 * 4 + 64 * 4 +
+                      (size_t)(2 * nlayers * 64 + 3 * 256 + 3 * 64) * 4;
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     if (e != hipSuccess) return set_error((int)e, "generate: LDS %zu: %s", sh, hipGetErrorString(e));
-    hipLaunchKernelGGL(kfn, dim3(1), dim3(256), sh, st, a);
+    hipLaunchKernelGGL(kfn, dim3(groups), dim3(256), sh, st, a);
   } else if (dtype == SRWN_F32) {
     auto kfn = generate_kernel<float, 1>;
-    const size_t sh = 1 * 24 * sizeof(Frag<float>) * 64 + 32 * 256 * sizeof(float) + 32 * 256 * 4 + 64 * 4;
+    const size_t sh = 1 * 24 * sizeof(Frag<float>) * 64 + 32 * 256 * sizeof(float) + 32 * 256 * 4 + 64 * 4 +
+                      (size_t)(2 * nlayers * 64 + 3 * 256 + 3 * 64) * 4;
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     if (e != hipSuccess) return set_error((int)e, "generate: LDS %zu: %s", sh, hipGetErrorString(e));
-    hipLaunchKernelGGL(kfn, dim3(1), dim3(256), sh, st, a);
+    hipLaunchKernelGGL(kfn, dim3(groups), dim3(256), sh, st, a);
   } else {
     return set_error(SRWN_E_DTYPE, "generate: dtype %d", dtype);
   }

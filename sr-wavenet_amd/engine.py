@@ -641,7 +641,7 @@ class WaveNetEngine:
 
     def generate(self, nsteps: int, mode: str = "sample", seed: int = 0, forced: Optional[torch.Tensor] = None,
                  want_logits: bool = False, batch: Optional[int] = None):
-        """Queue-cached autoregressive generation of `nsteps` samples for `batch` (<= 32) utterances.
+        """Queue-cached autoregressive generation of `nsteps` samples for `batch` utterances.
         Returns (audio [B,nsteps] f32, codes [B,nsteps] i32, logits [B,nsteps,C] f32 or None)."""
         import ctypes as C
         from . import _lib
@@ -650,7 +650,7 @@ class WaveNetEngine:
         B = int(batch or self.B)
         dl = (C.c_int32 * self.L)(*self.dil)
         relems = int(_lib.load().srwn_generate_ring_elems(dl, self.L, self.R))
-        ring = torch.zeros(relems, dtype=self.dt, device=self.dev)
+        ring = torch.zeros(relems * ((B + 31) // 32), dtype=self.dt, device=self.dev)
         audio = torch.zeros((B, nsteps), dtype=torch.float32, device=self.dev)
         codes = torch.zeros((B, nsteps), dtype=torch.int32, device=self.dev)
         logits = torch.zeros((B, nsteps, self.C), dtype=torch.float32, device=self.dev) if want_logits else None

@@ -192,6 +192,20 @@ class WaveNetTeacher(_EngineOwner):
         eng.forward()
         return np.float32(eng.loss.item())
 
+    def generate(self, batch_size, num_samples, mode="sample", seed=0, forced=None, return_logits=False):
+        """Queue-cached autoregressive generation (the O(T L) replacement of the reference's O(T^2 L)
+        loop, teacher.py:140-171): returns audio [B, num_samples] float32 (mu-law decoded), or
+        (audio, codes, logits) when return_logits.  `forced` [B, num_samples] = teacher forcing."""
+        if self.use_encoding:
+            raise NotImplementedError("generation with encoding/conditions: next milestone")
+        eng = self._primary or self._engine(1, self._default_length)
+        f = None if forced is None else torch.as_tensor(np.asarray(forced, dtype=np.float32), device="cuda")
+        a, c, lg = eng.generate(int(num_samples), mode=mode, seed=seed, forced=f, want_logits=return_logits,
+                                batch=int(batch_size))
+        if return_logits:
+            return a.cpu().numpy(), c.cpu().numpy(), lg.cpu().numpy()
+        return a.cpu().numpy()
+
 
 class WaveNetAutoEncoder(object):
     """model.py:75-285.  Constructor signature kept; the encoder (ResidualDilationLayerNC), the

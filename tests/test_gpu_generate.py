@@ -24,7 +24,7 @@ def _engine(dt, dil, B, T, C=256, seed=4):
 
 
 @pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-3), (torch.bfloat16, 6e-2)])
-@pytest.mark.parametrize("B,T,C", [(3, 300, 256), (32, 70, 256), (1, 130, 100)])
+@pytest.mark.parametrize("B,T,C", [(3, 300, 256), (32, 70, 256), (1, 130, 100), (70, 40, 256)])
 def test_incremental_logits_equal_full_forward(dt, tol, B, T, C):
     dil = [1, 2, 4, 8, 16, 32, 64, 128, 1, 2, 5]
     eng, sp = _engine(dt, dil, B, T, C)
@@ -80,4 +80,18 @@ def test_generate_argument_errors():
     with pytest.raises(ValueError):
         eng.generate(10, forced=torch.zeros(2, 11))
     with pytest.raises(RuntimeError):
-        eng.generate(10, batch=33)
+        eng.generate(0 - 1)
+
+
+def test_teacher_generate_api():
+    M = sub("model")
+    dil = [1, 2, 4, 8, 16, 32]
+    m = M.WaveNetTeacher(512, 0, dil, dilation_channels=64, skip_channels=256, quantization_channels=256,
+                         learning_rate=1e-2)
+    x = O.synthetic_audio(4, 512, seed=3)
+    for _ in range(5):
+        m.train(x)
+    audio = m.generate(3, 300, mode="sample", seed=7)
+    assert audio.shape == (3, 300) and np.isfinite(audio).all() and np.abs(audio).max() <= 1.0
+    a2, codes, logits = m.generate(3, 300, mode="sample", seed=7, return_logits=True)
+    assert np.array_equal(audio, a2) and logits.shape == (3, 300, 256) and codes.dtype == np.int32

@@ -8,7 +8,7 @@ dil = [1, 2, 4, 8, 16, 32, 64, 128, 256, 512] * 3
 for dt in (torch.bfloat16, torch.float32):
     cfg = EG.StackConfig(dilations=dil, dilation_channels=64, skip_channels=256, output_channels=256, shift_input=True, dtype=dt)
     eng = EG.WaveNetEngine(cfg, 1, 64, "cuda")
-    for B in (1, 32):
+    for B in (1, 32, 2048):
         n = 4000
         eng.generate(200, batch=B); torch.cuda.synchronize()
         t0 = time.perf_counter(); a, c, _ = eng.generate(n, mode="sample", seed=1, batch=B); torch.cuda.synchronize()
