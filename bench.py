@@ -68,6 +68,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1)   # (rehearsal: several ranks may share one GPU with SRWN_DIST_BACKEND=gloo)
     torch.cuda.set_device(local)
     dist = None
     if world > 1 or os.environ.get("SRWN_FORCE_DIST") == "1":   # (FORCE_DIST: exercise the RCCL path with one rank)
@@ -75,7 +77,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        backend = os.environ.get("SRWN_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+        kw = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
 
     EG = importlib.import_module("sr-wavenet_amd.engine")
     KN = importlib.import_module("sr-wavenet_amd.kernels")
