@@ -238,17 +238,16 @@ static int layer_blocks_per_cu(const char* env, int dflt) {
   return v < 1 ? 1 : (v > 8 ? 8 : v);
 }
 
-template <typename T, int RT, int K>
-static int launch_layer_fwd(const void* x, const void* cond, const void* wconv, const void* wres,
-                            const float* bias_f, const float* bias_r, void* h_out, void* z_out, int B, int Tlen,
-                            int dilation, int cond_frames, int pool, int cond_stride, hipStream_t st) {
+template <typename T, int RT, int K, int NBUF>
+static int launch_layer_fwd_n(const void* x, const void* cond, const void* wconv, const void* wres,
+                              const float* bias_f, const float* bias_r, void* h_out, void* z_out, int B, int Tlen,
+                              int dilation, int cond_frames, int pool, int cond_stride, hipStream_t st) {
   constexpr int R = 32 * RT, KS = R / 16;
-  constexpr int NBUF = (sizeof(T) == 2) ? 2 : 1;
   const size_t sh = (size_t)(RT * K * KS + RT * KS) * 64 * sizeof(Frag<T>) +
                     (size_t)4 * 32 * RowStage<T>::stride(R) * sizeof(T) + (size_t)4 * NBUF * K * 32 * R * sizeof(T);
   const int ntb = (Tlen + 31) / 32;
   const long long ntiles = (long long)B * ntb;
-  static const int bpc = layer_blocks_per_cu("SRWN_FWD_BPC", 1);
+  static const int bpc = layer_blocks_per_cu("SRWN_FWD_BPC", 2);   // single-buffered images: 74 KB LDS -> 2 blocks/CU
   long long blocks = (ntiles + 3) / 4;
   if (blocks > 256LL * bpc) blocks = 256LL * bpc;
   dim3 grid((unsigned)blocks), block(256);
@@ -265,6 +264,38 @@ static int launch_layer_fwd(const void* x, const void* cond, const void* wconv, 
   }
   return check_launch("residual_layer_fwd");
 }
+
+template <typename T, int RT, int K>
+static int launch_layer_fwd(const void* x, const void* cond, const void* wconv, const void* wres,
+                            const float* bias_f, const float* bias_r, void* h_out, void* z_out, int B, int Tlen,
+                            int dilation, int cond_frames, int pool, int cond_stride, hipStream_t st) {
+  static const int nbuf_env = [] { const char* e = getenv("SRWN_FWD_NBUF"); return e ? atoi(e) : 1; }();
+  if (sizeof(T) == 2 && nbuf_env == 1) return launch_layer_fwd_n<T, RT, K, 1>(x, cond, wconv, wres, bias_f, bias_r, h_out, z_out, B, Tlen, dilation, cond_frames, pool, cond_stride, st);
+  return launch_layer_fwd_n<T, RT, K, (sizeof(T) == 2) ? 2 : 1>(x, cond, wconv, wres, bias_f, bias_r, h_out, z_out, B, Tlen, dilation, cond_frames, pool, cond_stride, st);
+}
+#if 0
+  const size_t sh = (size_t)(RT * K * KS + RT * KS) * 64 * sizeof(Frag<T>) +
+                    (size_t)4 * 32 * RowStage<T>::stride(R) * sizeof(T) + (size_t)4 * NBUF * K * 32 * R * sizeof(T);
+  const int ntb = (Tlen + 31) / 32;
+  const long long ntiles = (long long)B * ntb;
+  static const int bpc = layer_blocks_per_cu("SRWN_FWD_BPC", 2);   // single-buffered images: 74 KB LDS -> 2 blocks/CU
+  long long blocks = (ntiles + 3) / 4;
+  if (blocks > 256LL * bpc) blocks = 256LL * bpc;
+  dim3 grid((unsigned)blocks), block(256);
+  if (cond) {
+    auto kfn = layer_fwd_kernel<T, RT, K, true, NBUF>;
+    if (sh > 32768) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipLaunchKernelGGL(kfn, grid, block, sh, st, (const T*)x, (const T*)cond, (const T*)wconv, (const T*)wres, bias_f,
+                       bias_r, (T*)h_out, (T*)z_out, Tlen, dilation, cond_frames, pool, cond_stride, ntb, (int)ntiles);
+  } else {
+    auto kfn = layer_fwd_kernel<T, RT, K, false, NBUF>;
+    if (sh > 32768) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipLaunchKernelGGL(kfn, grid, block, sh, st, (const T*)x, (const T*)nullptr, (const T*)wconv, (const T*)wres,
+                       bias_f, bias_r, (T*)h_out, (T*)z_out, Tlen, dilation, 1, 1, R, ntb, (int)ntiles);
+  }
+  return 0;
+#endif
+
 
 extern "C" int srwn_residual_layer_fwd(const void* x, const void* cond, const void* wconv, const void* wres,
                                        const float* bias_f, const float* bias_r, void* h_out, void* z_out,
