@@ -41,6 +41,7 @@ extern "C" {
 #define SRWN_EPI_NONE 0
 #define SRWN_EPI_RELU 1
 #define SRWN_EPI_MASK 2 /* y *= (aux > 0): relu backward against the saved activation */
+#define SRWN_EPI_F32 4  /* y is fp32 regardless of dtype (mixture-of-logistics parameters need full precision) */
 
 int srwn_version(void);
 const char* srwn_last_error(void);
@@ -223,6 +224,16 @@ int srwn_generate(const void* wcr, const void* wskip, const void* w1, const void
                   const float* forced, const int32_t* dilations, int32_t nlayers, int32_t B, int32_t Tout,
                   int32_t nsteps, int32_t R, int32_t S, int32_t C, int32_t K, int32_t mode, uint64_t seed,
                   int32_t dtype, void* stream);
+
+/* ---- discretised mixture-of-logistics loss of the reference's live teacher:
+ * discretized_mix_logistic_loss (ops.py:124-175, sum_all=True) on logits [rows, ldl] fp32 whose first 4*M
+ * columns are (logit_probs, means, log_scales, coeffs) and targets x [rows] in [-1,1]:
+ *   loss = -sum_rows logsumexp_m( log p_m(x) + log_softmax(logit_probs)_m )   (bin half-width 1/255, log-scale
+ *   floor -7, the four tf.where branches of ops.py:169; the coeffs never reach the loss)
+ * loss_partials: one float per 256 rows (sum with srwn_reduce_loss);  dlogits [rows, ldd] in `dtype`,
+ * = d loss / d logits * grad_scale, columns >= 4*M written as 0. */
+int srwn_mol_loss(const float* logits, int64_t ldl, const float* x, int32_t M, float* loss_partials, void* dlogits,
+                  int64_t ldd, int64_t rows, float grad_scale, int32_t dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -483,3 +483,72 @@ def synthetic_audio(B: int, T: int, seed: int = 0, sample_rate: int = 16000) -> 
     f = 110.0 * (np.arange(B, dtype=np.float64)[:, None] % 16 + 1)
     x = 0.5 * np.sin(2 * np.pi * f * t / sample_rate) + 0.05 * rng.standard_normal((B, T))
     return np.clip(x, -1.0, 1.0).astype(np.float32)
+
+
+# --------------------------------------------------------------------------
+# discretised mixture-of-logistics head of the reference's live teacher (ops.py:124-175)
+# --------------------------------------------------------------------------
+def _softplus(v):
+    return np.logaddexp(0.0, v)
+
+
+def mol_log_probs(x: np.ndarray, l: np.ndarray):
+    """Per-mixture log-probabilities of ``discretized_mix_logistic_loss`` (ops.py:131-169).
+
+    x [B,T] in [-1,1]; l [B,T,4M] = (logit_probs, means, log_scales, coeffs); the coeffs (ops.py:138) are
+    computed by the reference but never used for single-channel audio.  Returns (log_probs [B,T,M], aux).
+    """
+    M = l.shape[-1] // 4
+    logit_probs = l[..., :M]
+    means = l[..., M:2 * M]
+    raw_ls = l[..., 2 * M:3 * M]
+    log_scales = np.maximum(raw_ls, -7.0)                      # ops.py:137
+    xx = x[..., None]
+    centered = xx - means                                       # ops.py:147
+    inv = np.exp(-log_scales)
+    plus_in = inv * (centered + 1.0 / 255.0)
+    min_in = inv * (centered - 1.0 / 255.0)
+    cdf_plus = sigmoid(plus_in); cdf_min = sigmoid(min_in)
+    log_cdf_plus = plus_in - _softplus(plus_in)                 # ops.py:153
+    log_one_minus_cdf_min = -_softplus(min_in)                  # ops.py:154
+    cdf_delta = cdf_plus - cdf_min
+    mid_in = inv * centered
+    log_pdf_mid = mid_in - log_scales - 2.0 * _softplus(mid_in)  # ops.py:157
+    case = np.where(xx < -0.999, 0, np.where(xx > 0.999, 1, np.where(cdf_delta > 1e-5, 2, 3)))   # ops.py:169
+    comp = np.where(case == 0, log_cdf_plus,
+                    np.where(case == 1, log_one_minus_cdf_min,
+                             np.where(case == 2, np.log(np.maximum(cdf_delta, 1e-12)), log_pdf_mid - np.log(127.5))))
+    lp = comp + log_prob_from_logits(logit_probs)               # ops.py:171
+    return lp, dict(case=case, inv=inv, plus_in=plus_in, min_in=min_in, mid_in=mid_in, cdf_plus=cdf_plus,
+                    cdf_min=cdf_min, cdf_delta=cdf_delta, clamp=(raw_ls > -7.0), logit_probs=logit_probs)
+
+
+def mol_loss(x: np.ndarray, l: np.ndarray) -> float:
+    """``discretized_mix_logistic_loss(x, l, sum_all=True)`` (ops.py:173-174): -sum over B,T of logsumexp."""
+    lp, _ = mol_log_probs(x, l)
+    return float(-log_sum_exp(lp).sum())
+
+
+def mol_dlogits(x: np.ndarray, l: np.ndarray) -> np.ndarray:
+    """Hand-derived d(mol_loss)/dl [B,T,4M] (tf.where routes the gradient to the selected branch only)."""
+    M = l.shape[-1] // 4
+    lp, a = mol_log_probs(x, l)
+    w = softmax(lp)                                             # d(-LSE)/d lp_m = -w_m
+    sm = softmax(a["logit_probs"])
+    g = np.zeros_like(l)
+    g[..., :M] = -(w - sm)
+    sp, smn, smd = sigmoid(a["plus_in"]), sigmoid(a["min_in"]), sigmoid(a["mid_in"])
+    inv, case = a["inv"], a["case"]
+    # d comp / d mean and d comp / d log_scale per branch
+    dm0 = (1 - sp) * (-inv);            ds0 = (1 - sp) * (-a["plus_in"])
+    dm1 = (-smn) * (-inv);              ds1 = (-smn) * (-a["min_in"])
+    num_m = sp * (1 - sp) * (-inv) - smn * (1 - smn) * (-inv)
+    num_s = sp * (1 - sp) * (-a["plus_in"]) - smn * (1 - smn) * (-a["min_in"])
+    den = np.maximum(a["cdf_delta"], 1e-12)
+    dm2 = num_m / den;                  ds2 = num_s / den
+    dm3 = (1 - 2 * smd) * (-inv);       ds3 = (1 - 2 * smd) * (-a["mid_in"]) - 1.0
+    dm = np.select([case == 0, case == 1, case == 2], [dm0, dm1, dm2], dm3)
+    ds = np.select([case == 0, case == 1, case == 2], [ds0, ds1, ds2], ds3)
+    g[..., M:2 * M] = -w * dm
+    g[..., 2 * M:3 * M] = -w * ds * a["clamp"]
+    return g

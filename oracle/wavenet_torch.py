@@ -154,3 +154,28 @@ def cpu_train_steps(sp, audio_np: np.ndarray, codes_np: np.ndarray, steps: int, 
         last = one()
     dt = time.perf_counter() - t0
     return dict(samples_per_s=steps * B * T / dt, seconds=dt, loss=last, steps=steps, B=B, T=T)
+
+
+def mol_loss(x: torch.Tensor, l: torch.Tensor) -> torch.Tensor:
+    """ops.py:124-175 in torch (autograd gives the reference gradient, incl. tf.where routing)."""
+    M = l.shape[-1] // 4
+    logit_probs = l[..., :M]
+    means = l[..., M:2 * M]
+    log_scales = torch.clamp(l[..., 2 * M:3 * M], min=-7.0)
+    xx = x[..., None].expand_as(means)
+    centered = xx - means
+    inv = torch.exp(-log_scales)
+    plus_in = inv * (centered + 1.0 / 255.0)
+    min_in = inv * (centered - 1.0 / 255.0)
+    cdf_plus = torch.sigmoid(plus_in); cdf_min = torch.sigmoid(min_in)
+    log_cdf_plus = plus_in - F.softplus(plus_in)
+    log_one_minus_cdf_min = -F.softplus(min_in)
+    cdf_delta = cdf_plus - cdf_min
+    mid_in = inv * centered
+    log_pdf_mid = mid_in - log_scales - 2.0 * F.softplus(mid_in)
+    comp = torch.where(xx < -0.999, log_cdf_plus,
+                       torch.where(xx > 0.999, log_one_minus_cdf_min,
+                                   torch.where(cdf_delta > 1e-5, torch.log(torch.clamp(cdf_delta, min=1e-12)),
+                                               log_pdf_mid - math.log(127.5))))
+    lp = comp + torch.log_softmax(logit_probs, dim=-1)
+    return -torch.logsumexp(lp, dim=-1).sum()

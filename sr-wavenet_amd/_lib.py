@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(HERE, "libsrwn.so")
 
 F32, BF16 = 0, 1
 PRO_NONE, PRO_GATE = 0, 1
-EPI_NONE, EPI_RELU, EPI_MASK = 0, 1, 2
+EPI_NONE, EPI_RELU, EPI_MASK, EPI_F32 = 0, 1, 2, 4
 
 _p, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -53,6 +53,7 @@ SIGNATURES = {
     "srwn_generate_ring_elems": (_i64, [_p, _i32, _i32]),
     "srwn_generate": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32,
                                 _i32, _i32, _i32, _i32, _i32, _i32, C.c_uint64, _i32, _p]),
+    "srwn_mol_loss": (C.c_int, [_p, _i64, _p, _i32, _p, _p, _i64, _i64, _f32, _i32, _p]),
     "srwn_wgrad256_slabs": (_i32, [_i64, _i32]),
     "srwn_wgrad256": (C.c_int, [_p, _i64, _i64, _i32, _p, _i64, _p, _p, _i64, _i32, _i32, _i32, _p]),
 }

@@ -414,7 +414,8 @@ __global__ __launch_bounds__(256) void pw_linear_kernel(PwArgs a) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = (m[e] > 0.0f) ? v[e] : 0.0f;
         }
-        store4(yrow + n0, v[0], v[1], v[2], v[3]);
+        if (EPI == SRWN_EPI_F32) store4(reinterpret_cast<float*>(a.y) + rowc[nt] * a.y_row_stride + n0, v[0], v[1], v[2], v[3]);
+        else store4(yrow + n0, v[0], v[1], v[2], v[3]);
       }
     }
   }
@@ -433,6 +434,7 @@ static int launch_pw(const PwArgs& a, int cout_pad, int pro, int epi, hipStream_
   SRWN_PW(SRWN_PRO_NONE, SRWN_EPI_MASK)
   SRWN_PW(SRWN_PRO_GATE, SRWN_EPI_NONE)
   SRWN_PW(SRWN_PRO_GATE, SRWN_EPI_RELU)
+  SRWN_PW(SRWN_PRO_NONE, SRWN_EPI_F32)
 #undef SRWN_PW
   return set_error(SRWN_E_UNSUPPORTED, "pw_linear: pro %d / epi %d combination not built", pro, epi);
 }
@@ -449,7 +451,7 @@ extern "C" int srwn_pw_linear(const void* x, int64_t x_row_stride, int64_t x_chu
     return set_error(SRWN_E_SHAPE, "pw_linear: rows=%lld Cin=%d chunk=%d cout_pad=%d cout_valid=%d", (long long)rows,
                      Cin, chunk_len, cout_pad, cout_valid);
   hipStream_t st = (hipStream_t)stream;
-  {
+  if (epi != SRWN_EPI_F32) {
     int rc = 0;
     if (rowgemm_dispatch(x, x_row_stride, x_chunk_stride, chunk_len, Cin, wpack, bias, y, y_row_stride, cout_pad,
                          cout_valid, rows, aux, aux_row_stride, nullptr, nullptr, nullptr, 0.0f, pro, epi, dtype, st,

@@ -185,3 +185,102 @@ extern "C" int srwn_bcast_mask(const float* dmean, const void* r1, void* out, in
     return set_error(SRWN_E_DTYPE, "bcast_mask: dtype %d", dtype);
   return check_launch("bcast_mask");
 }
+
+// ------------------------------------------------------------------------------------------
+// discretised mixture-of-logistics NLL + gradient (ops.py:124-175), one thread per time step.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float mol_softplus(float v) { return (v > 20.0f) ? v : log1pf(expf(v)); }
+__device__ __forceinline__ float mol_sigmoid(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void mol_loss_kernel(const float* __restrict__ logits, int64_t ldl,
+                                                       const float* __restrict__ x, int M,
+                                                       float* __restrict__ loss_partials, T* __restrict__ dlogits,
+                                                       int64_t ldd, int64_t rows, float grad_scale) {
+  __shared__ float red[256];
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float loss = 0.0f;
+  if (row < rows) {
+    const float* l = logits + row * ldl;
+    const float xv = x[row];
+    float lp[16], dmean[16], dls[16], lg[16];
+    float mx = -INFINITY;
+    for (int m = 0; m < M; ++m) { lg[m] = l[m]; mx = fmaxf(mx, lg[m]); }
+    float se = 0.0f;
+    for (int m = 0; m < M; ++m) se += expf(lg[m] - mx);
+    const float lse_logit = mx + logf(se);
+    float mlp = -INFINITY;
+    for (int m = 0; m < M; ++m) {
+      const float mean = l[M + m];
+      const float raw = l[2 * M + m];
+      const float ls = fmaxf(raw, -7.0f);                                  // ops.py:137
+      const float inv = expf(-ls);
+      const float cen = xv - mean;
+      const float plus_in = inv * (cen + (1.0f / 255.0f));
+      const float min_in = inv * (cen - (1.0f / 255.0f));
+      const float mid_in = inv * cen;
+      const float sp = mol_sigmoid(plus_in), sm = mol_sigmoid(min_in), sd = mol_sigmoid(mid_in);
+      const float cdf_delta = sp - sm;
+      float comp, dm, ds;
+      if (xv < -0.999f) {                                                   // ops.py:169, branch by branch
+        comp = plus_in - mol_softplus(plus_in);
+        dm = (1.0f - sp) * (-inv); ds = (1.0f - sp) * (-plus_in);
+      } else if (xv > 0.999f) {
+        comp = -mol_softplus(min_in);
+        dm = sm * inv; ds = sm * min_in;
+      } else if (cdf_delta > 1e-5f) {
+        const float den = fmaxf(cdf_delta, 1e-12f);
+        comp = logf(den);
+        const float a = sp * (1.0f - sp), b = sm * (1.0f - sm);
+        dm = (-(a - b) * inv) / den;
+        ds = (-(a * plus_in - b * min_in)) / den;
+      } else {
+        comp = mid_in - ls - 2.0f * mol_softplus(mid_in) - 4.848116f;       // log(127.5)
+        dm = (1.0f - 2.0f * sd) * (-inv); ds = (1.0f - 2.0f * sd) * (-mid_in) - 1.0f;
+      }
+      lp[m] = comp + (lg[m] - lse_logit);                                   // ops.py:171
+      dmean[m] = dm;
+      dls[m] = (raw > -7.0f) ? ds : 0.0f;
+      mlp = fmaxf(mlp, lp[m]);
+    }
+    float sw = 0.0f;
+    for (int m = 0; m < M; ++m) sw += expf(lp[m] - mlp);
+    const float lse = mlp + logf(sw);
+    loss = -lse;                                                            // ops.py:174
+    T* dr = dlogits + row * ldd;
+    for (int m = 0; m < M; ++m) {
+      const float w = expf(lp[m] - lse);
+      const float smx = expf(lg[m] - lse_logit);
+      dr[m] = (T)(-(w - smx) * grad_scale);
+      dr[M + m] = (T)(-w * dmean[m] * grad_scale);
+      dr[2 * M + m] = (T)(-w * dls[m] * grad_scale);
+      dr[3 * M + m] = (T)0.0f;                                              // coeffs never reach the loss
+    }
+    for (int64_t c = 4 * M; c < ldd; ++c) dr[c] = (T)0.0f;
+  }
+  red[threadIdx.x] = loss;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss_partials[blockIdx.x] = red[0];
+}
+
+extern "C" int srwn_mol_loss(const float* logits, int64_t ldl, const float* x, int32_t M, float* loss_partials,
+                             void* dlogits, int64_t ldd, int64_t rows, float grad_scale, int32_t dtype,
+                             void* stream) {
+  if (rows == 0) return 0;
+  if (!logits || !x || !loss_partials || !dlogits) return set_error(SRWN_E_NULL, "mol_loss: null pointer");
+  if (rows < 0 || M < 1 || M > 16 || ldl < 4 * M || ldd < 4 * M)
+    return set_error(SRWN_E_SHAPE, "mol_loss: rows=%lld M=%d ldl=%lld ldd=%lld", (long long)rows, M, (long long)ldl, (long long)ldd);
+  dim3 grid((unsigned)((rows + 255) / 256)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SRWN_F32)
+    hipLaunchKernelGGL(mol_loss_kernel<float>, grid, block, 0, st, logits, ldl, x, M, loss_partials, (float*)dlogits, ldd, rows, grad_scale);
+  else if (dtype == SRWN_BF16)
+    hipLaunchKernelGGL(mol_loss_kernel<bf16_t>, grid, block, 0, st, logits, ldl, x, M, loss_partials, (bf16_t*)dlogits, ldd, rows, grad_scale);
+  else
+    return set_error(SRWN_E_DTYPE, "mol_loss: dtype %d", dtype);
+  return check_launch("mol_loss");
+}

@@ -42,7 +42,10 @@ class StackConfig:
     pool_stride: int = 1
     shift_input: bool = False     # RightShift(truth) teacher forcing (model.py:172)
     head_mode: str = "per_timestep"  # "per_timestep": mu-law softmax CE per sample (model.py:100-112);
-    #                                  "pooled": class WaveNet's clip-level softmax (model.py:56-60, 24-29)
+    #                                  "pooled": class WaveNet's clip-level softmax (model.py:56-60, 24-29);
+    #                                  "mol": discretised mixture of logistics, the live teacher's loss
+    #                                         (model.py:114,196; ops.py:124-175): output_channels = 4*mixtures,
+    #                                         loss SUMMED over batch and time
     dtype: torch.dtype = torch.bfloat16
     learning_rate: float = 1e-3
 
@@ -86,7 +89,9 @@ class WaveNetEngine:
             raise NotImplementedError("skip_channels must be a multiple of 32")
         if cfg.output_channels < 1 or cfg.output_channels > 256:
             raise NotImplementedError("output_channels must be in [1, 256]")
-        if cfg.head_mode not in ("per_timestep", "pooled"):
+        if cfg.head_mode == "mol" and (cfg.output_channels % 4 or not 4 <= cfg.output_channels <= 64):
+            raise ValueError("mol head: output_channels = 4 * num_mixtures (<= 16 mixtures)")
+        if cfg.head_mode not in ("per_timestep", "pooled", "mol"):
             raise ValueError("head_mode %r" % cfg.head_mode)
         if cfg.cond_channels and (length % cfg.pool_stride):
             raise ValueError("length %d is not a multiple of pool_stride %d" % (length, cfg.pool_stride))
@@ -339,6 +344,9 @@ class WaveNetEngine:
         self.loss_parts = z((N + 31) // 32, dt=torch.float32)
         self.loss = z(1, dt=torch.float32)
         self.pooled = self.cfg.head_mode == "pooled"
+        self.mol = self.cfg.head_mode == "mol"
+        if self.mol:
+            self.logits32 = z(N, Cp, dt=torch.float32)
         if self.pooled:
             from . import _lib as _l
             self.labels = z(B, self.C, dt=torch.float32)
@@ -412,6 +420,16 @@ class WaveNetEngine:
                         epi=K.EPI_RELU)                                               # model.py:53-54
         if self.pooled:
             return self._forward_pooled_head(with_loss)
+        if self.mol:
+            # last 1x1 in fp32 (the mixture parameters need it), then the mixture-of-logistics NLL on the
+            # UNshifted clip (labels = inputs, model.py:103,114) and its gradient
+            with _Span(self, "head_mol"):
+                K.pw_linear(self.r1.data_ptr(), S, 0, S, S, self.wptr(self.o_w2), v("head_b2"), self.logits32,
+                            self.Cp, self.C, N, epi=K.EPI_F32, compute_dtype=self.dt)
+                K.mol_loss(self.logits32, self.audio.view(N), self.C // 4, self.loss_parts, self.dlogits, 1.0)
+            if with_loss:
+                K.reduce_loss(self.loss_parts, (N + 255) // 256, 1.0, self.loss)
+            return self.logits32[:, :self.C].reshape(B, T, self.C).clone() if want_logits else None
         logits = None
         if want_logits:
             logits = torch.empty((N, self.C), dtype=torch.float32, device=self.dev)
@@ -627,8 +645,10 @@ class WaveNetEngine:
         dp.allreduce_sum_(self.grads, self.pg)
 
     def optimizer_step(self):
+        # mean losses: mean of shard gradients; the mixture-of-logistics loss is a SUM over batch and time
+        # (ops.py:173-174), so shard gradients simply add
         K.adam_step(self.params, self.grads, self.adam_m, self.adam_v, self.adam_step, self.cfg.learning_rate,
-                    grad_scale=1.0 / self.world)
+                    grad_scale=1.0 if self.mol else 1.0 / self.world)
         self.repack()
 
     def train_step(self) -> torch.Tensor:

@@ -11,7 +11,7 @@ from typing import List, Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import BF16, EPI_MASK, EPI_NONE, EPI_RELU, F32, PRO_GATE, PRO_NONE, call
+from ._lib import BF16, EPI_F32, EPI_MASK, EPI_NONE, EPI_RELU, F32, PRO_GATE, PRO_NONE, call
 
 _TORCH2ABI = {torch.float32: F32, torch.bfloat16: BF16}
 
@@ -174,9 +174,10 @@ def residual_layer_fwd(x: torch.Tensor, cond: Optional[torch.Tensor], wconv_ptr:
 # ----------------------------------------------------------------------------------------------
 def pw_linear(x_ptr: int, x_row_stride: int, x_chunk_stride: int, chunk_len: int, Cin: int, wpack_ptr: int,
               bias: Optional[torch.Tensor], y: torch.Tensor, cout_pad: int, cout_valid: int, rows: int,
-              aux: Optional[torch.Tensor] = None, pro: int = PRO_NONE, epi: int = EPI_NONE):
+              aux: Optional[torch.Tensor] = None, pro: int = PRO_NONE, epi: int = EPI_NONE,
+              compute_dtype: Optional[torch.dtype] = None):
     """Raw-pointer input (the skip sum reads a [L,rows,R] stack through chunk strides); y is [rows, >=cout_valid]."""
-    py = _chk(y, "y")
+    py = _chk(y, "y", torch.float32 if epi == EPI_F32 else None)
     if y.shape[0] != rows or y.shape[-1] < cout_valid:
         raise ValueError("pw_linear: y shape %s vs rows=%d cout_valid=%d" % (tuple(y.shape), rows, cout_valid))
     pa, astride = None, 0
@@ -189,7 +190,26 @@ def pw_linear(x_ptr: int, x_row_stride: int, x_chunk_stride: int, chunk_len: int
     if bias is not None and bias.numel() < cout_valid:
         raise ValueError("pw_linear: bias too short")
     call("srwn_pw_linear", x_ptr, int(x_row_stride), int(x_chunk_stride), int(chunk_len), int(Cin), wpack_ptr, pb, py,
-         y.shape[-1], int(cout_pad), int(cout_valid), int(rows), pa, astride, pro, epi, abi_dtype(y.dtype), _stream())
+         y.shape[-1], int(cout_pad), int(cout_valid), int(rows), pa, astride, pro, epi,
+         abi_dtype(compute_dtype if epi == EPI_F32 else y.dtype), _stream())
+
+
+def mol_loss(logits: torch.Tensor, x: torch.Tensor, M: int, loss_partials: torch.Tensor, dlogits: torch.Tensor,
+             grad_scale: float = 1.0):
+    """Mixture-of-logistics NLL (ops.py:124-175) + gradient: logits [rows, >=4M] fp32, x [rows] fp32."""
+    rows = logits.shape[0]
+    _chk(logits, "logits", torch.float32)
+    if logits.shape[-1] < 4 * M or not (1 <= M <= 16):
+        raise ValueError("mol_loss: logits %s for M=%d" % (tuple(logits.shape), M))
+    _chk(x, "x", torch.float32, (rows,))
+    _chk(loss_partials, "loss_partials", torch.float32)
+    if loss_partials.numel() < (rows + 255) // 256:
+        raise ValueError("mol_loss: loss_partials needs %d floats" % ((rows + 255) // 256))
+    _chk(dlogits, "dlogits")
+    if dlogits.shape[0] != rows or dlogits.shape[-1] < 4 * M:
+        raise ValueError("mol_loss: dlogits shape %s" % (tuple(dlogits.shape),))
+    call("srwn_mol_loss", logits.data_ptr(), logits.shape[-1], x.data_ptr(), int(M), loss_partials.data_ptr(),
+         dlogits.data_ptr(), dlogits.shape[-1], rows, float(grad_scale), abi_dtype(dlogits.dtype), _stream())
 
 
 def head_softmax_ce(x: torch.Tensor, wpack_ptr: int, bias: torch.Tensor, targets: torch.Tensor,

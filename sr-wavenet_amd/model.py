@@ -144,7 +144,8 @@ class WaveNetTeacher(_EngineOwner):
 
     def __init__(self, input_size, condition_size, dilations, filter_width=2, dilation_channels=32,
                  skip_channels=256, quantization_channels=256, latent_channels=16, pool_stride=512,
-                 name="WaveNetTeacher", learning_rate=0.001, use_encoding=False, dtype=None, seed=0):
+                 name="WaveNetTeacher", learning_rate=0.001, use_encoding=False, dtype=None, seed=0,
+                 head="softmax", num_mixtures=5):
         self.input_size = input_size
         self.condition_size = condition_size
         self.dilations = dilations
@@ -152,13 +153,18 @@ class WaveNetTeacher(_EngineOwner):
         self.latent_channels = latent_channels
         self.pool_stride = pool_stride
         self.use_encoding = bool(use_encoding)
+        self.head = head
+        self.num_mixtures = num_mixtures
+        if head not in ("softmax", "mol"):
+            raise ValueError("head must be 'softmax' (mu-law classes) or 'mol' (mixture of logistics, model.py:114)")
         cond_ch = (latent_channels + condition_size) if self.use_encoding else 0
         self._scope, self._decoder_names, self._default_length = name, bool(cond_ch), int(input_size)
         self._setup(StackConfig(dilations=list(dilations), filter_width=filter_width,
                                 dilation_channels=dilation_channels, skip_channels=skip_channels,
-                                output_channels=quantization_channels, cond_channels=cond_ch,
-                                pool_stride=pool_stride if cond_ch else 1, shift_input=True,
-                                head_mode="per_timestep", dtype=dtype or _default_dtype(),
+                                output_channels=quantization_channels if head == "softmax" else 4 * num_mixtures,
+                                cond_channels=cond_ch, pool_stride=pool_stride if cond_ch else 1, shift_input=True,
+                                head_mode="per_timestep" if head == "softmax" else "mol",
+                                dtype=dtype or _default_dtype(),
                                 learning_rate=learning_rate), seed)
 
     def _stage(self, inputs, encoding=None, conditions=None):
@@ -174,7 +180,9 @@ class WaveNetTeacher(_EngineOwner):
                 c = torch.as_tensor(np.asarray(conditions, dtype=np.float32), device="cuda")
                 e = torch.cat([e, c[:, None, :].expand(-1, e.shape[1], -1)], dim=2)   # model.py:162-165
             cond = e.contiguous()
-        codes = K.mu_law_encode(x.contiguous(), self.quantization_channels)            # ops.py:82-93
+        codes = None
+        if self.head == "softmax":
+            codes = K.mu_law_encode(x.contiguous(), self.quantization_channels)        # ops.py:82-93
         eng.set_inputs(x, codes, cond)
         return eng
 
@@ -196,8 +204,8 @@ class WaveNetTeacher(_EngineOwner):
         """Queue-cached autoregressive generation (the O(T L) replacement of the reference's O(T^2 L)
         loop, teacher.py:140-171): returns audio [B, num_samples] float32 (mu-law decoded), or
         (audio, codes, logits) when return_logits.  `forced` [B, num_samples] = teacher forcing."""
-        if self.use_encoding:
-            raise NotImplementedError("generation with encoding/conditions: next milestone")
+        if self.use_encoding or self.head != "softmax":
+            raise NotImplementedError("generation: built for the unconditioned mu-law softmax teacher")
         eng = self._primary or self._engine(1, self._default_length)
         f = None if forced is None else torch.as_tensor(np.asarray(forced, dtype=np.float32), device="cuda")
         a, c, lg = eng.generate(int(num_samples), mode=mode, seed=seed, forced=f, want_logits=return_logits,

@@ -197,3 +197,59 @@ def test_deterministic_and_tf_names():
     assert names["WaveNet/conv1d_3/kernel"].shape == (1, 64, 64)
     assert names["WaveNet/dilated_conv_2_gate/dilated_conv_2_Kernel"].shape == (2, 64, 64)
     assert names["WaveNet/conv1d_7/kernel"].shape == (1, 64, 32)
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-3), (torch.bfloat16, 5e-2)])
+@pytest.mark.parametrize("M", [5, 10])
+def test_mixture_of_logistics_teacher(dt, tol, M):
+    """The reference's live teacher loss (model.py:114; ops.py:124-175) on the decoder stack: loss (a SUM over
+    batch and time), the gradient wrt the head parameters, and every stack gradient vs the oracle."""
+    EG = sub("engine")
+    K = sub("kernels")
+    dil = [1, 2, 4, 8, 16, 1, 2]
+    R, S, B, T = 64, 256, 2, 200
+    C = 4 * M
+    sp = O.init_stack_params(31, dil, 2, R, S, C, bias_scale=0.05)
+    audio = O.synthetic_audio(B, T, seed=8).astype(np.float64)
+    audio[0, :3] = [-1.0, 1.0, 0.9995]                         # the edge branches of ops.py:169
+    logits, cache = O.stack_forward(sp, audio, shift_input=True)
+    loss = O.mol_loss(audio, logits)
+    grads, _ = O.stack_backward(sp, cache, O.mol_dlogits(audio, logits))
+    cfg = EG.StackConfig(dilations=dil, dilation_channels=R, skip_channels=S, output_channels=C, shift_input=True,
+                         dtype=dt, head_mode="mol", learning_rate=1e-4)
+    eng = EG.WaveNetEngine(cfg, B, T, DEV); eng.load_oracle_params(sp)
+    eng.set_inputs(dev(audio))
+    lg = eng.forward(want_logits=True)
+    assert rel_err(lg.cpu().numpy(), logits) < tol
+    assert abs(float(eng.loss.item()) - loss) < tol * abs(loss)
+    eng.backward()
+    if dt == torch.float32:
+        _check_grads(eng, grads, tol)
+    else:
+        # bf16: judge the backward on the engine's own forward (see _bwd_oracle_on_engine_forward)
+        f = lambda t: t.double().cpu().numpy()
+        g = O.mol_dlogits(audio, f(eng.logits32)[:, :C].reshape(B, T, C))
+        assert rel_err(f(eng.dlogits)[:, :C].reshape(B, T, C), g) < tol
+    l0 = float(eng.loss.item())
+    for _ in range(5):
+        eng.train_step()
+    assert float(eng.loss.item()) < l0
+
+
+def test_mol_kernel_branches():
+    """All four tf.where branches + the -7 clamp through srwn_mol_loss, vs the oracle."""
+    K = sub("kernels")
+    rng = np.random.default_rng(3)
+    N, M = 3000, 5
+    x = rng.uniform(-1, 1, N); x[:5] = [-1.0, -0.9995, 0.9995, 1.0, 0.0]
+    l = rng.standard_normal((N, 4 * M)); l[:, 2 * M:3 * M] = rng.uniform(-9, 1, (N, M)); l[100:160, M:2 * M] += 30.0
+    _, aux = O.mol_log_probs(x[None], l[None])
+    assert set(np.unique(aux["case"])) == {0, 1, 2, 3}
+    lg = torch.zeros((N, 32), dtype=torch.float32, device=DEV); lg[:, :4 * M] = dev(l)
+    parts = torch.zeros((N + 255) // 256, dtype=torch.float32, device=DEV)
+    dl = torch.full((N, 32), float("nan"), dtype=torch.float32, device=DEV)
+    K.mol_loss(lg, dev(x), M, parts, dl, 1.0)
+    assert abs(float(parts.sum().item()) - O.mol_loss(x[None], l[None])) < 1e-3 * abs(O.mol_loss(x[None], l[None]))
+    ref = O.mol_dlogits(x[None], l[None])[0]
+    assert rel_err(dl[:, :4 * M].cpu().numpy(), ref) < 1e-3
+    assert torch.all(dl[:, 3 * M:] == 0)

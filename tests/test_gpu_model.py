@@ -122,3 +122,19 @@ def test_dropin_shims_import():
     finally:
         sys.path.remove(d)
         sys.modules.pop("model", None); sys.modules.pop("ops", None)
+
+
+def test_teacher_mixture_of_logistics_head():
+    """WaveNetTeacher(head='mol'): the reference teacher's loss (model.py:114) on the decoder stack."""
+    M = sub("model")
+    dil = [1, 2, 4, 8, 16]
+    m = M.WaveNetTeacher(256, 0, dil, dilation_channels=64, skip_channels=128, head="mol", num_mixtures=5,
+                         learning_rate=1e-3, dtype=torch.float32)
+    x = O.synthetic_audio(2, 256, seed=5)
+    ls = [float(m.train(x)) for _ in range(8)]
+    assert ls[-1] < ls[0]
+    lg = m.get_logits(x)
+    assert lg.shape == (2, 256, 20)
+    assert abs(float(m.loss(x)) - O.mol_loss(x.astype(np.float64), lg.astype(np.float64))) < 1e-3 * abs(float(m.loss(x)))
+    with pytest.raises(NotImplementedError):
+        m.generate(1, 10)

@@ -177,3 +177,22 @@ def test_tf_variable_names():
         assert k in names, k
     assert names["WaveNet/conv1d/kernel"].shape == (1, 8, 8)
     assert names["WaveNet/causal_conv_Bias"].shape == (1, 1, 8)
+
+
+def test_mol_loss_np_vs_torch_autograd():
+    """Mixture-of-logistics head (ops.py:124-175): hand-derived gradient == autograd, all four tf.where branches."""
+    rng = np.random.default_rng(3)
+    B, T, M = 3, 200, 5
+    x = rng.uniform(-1, 1, (B, T))
+    x[0, :5] = [-1.0, -0.9995, 0.9995, 1.0, 0.0]              # edge branches (ops.py:169)
+    l = rng.standard_normal((B, T, 4 * M))
+    l[..., 2 * M:3 * M] = rng.uniform(-9, 1, (B, T, M))       # log-scales across the -7 clamp
+    l[1, :20, M:2 * M] += 30.0                                 # far means: the cdf_delta <= 1e-5 branch
+    lp, aux = O.mol_log_probs(x, l)
+    assert set(np.unique(aux["case"])) == {0, 1, 2, 3}
+    lt = torch.tensor(l, requires_grad=True)
+    loss_t = OT.mol_loss(torch.tensor(x), lt)
+    assert abs(float(loss_t.detach()) - O.mol_loss(x, l)) < 1e-8 * abs(O.mol_loss(x, l))
+    loss_t.backward()
+    assert np.allclose(O.mol_dlogits(x, l), lt.grad.numpy(), rtol=1e-8, atol=1e-10)
+    assert np.all(O.mol_dlogits(x, l)[..., 3 * M:] == 0)       # coeffs never reach the loss
