@@ -125,7 +125,9 @@ int srwn_reduce_loss(const float* loss_partials, int64_t n, float scale, float* 
  *   has_down: dc = Wr_l . (G_{l+1} sqrt(.5)) + Ws_l . dtotal;  df_l = dc * d(z sigmoid z)/df      -> df_out
  *             (wresT packed permuted [R/32][R/16]; z = z_l; the skip term Ws_l . dtotal is either `dcs`
  *             = layer l's slice from srwn_skip_dgrad_all, or computed here from wskipT [R/32][S/16] + dtotal)
- * Layer L-1: has_up=0 (its dense output is unused, model.py:45-50).  Below layer 0: has_down=0. */
+ * Layer L-1: has_up=0 (its dense output is unused, model.py:45-50).  Below layer 0: has_down=0.
+ * Flow stacks of ParallelWaveNet (model.py:415-453) have no skip path: pass S=0 (dc = Wr_l . G sqrt(.5) only);
+ * their layer L-1 runs with has_up=2: G_L (the flow head's gradient, srwn_flow_affine_bwd) is READ from g_out. */
 int srwn_residual_layer_bwd(const void* g_in, const void* df_up, const void* wconvT_up, void* g_out,
                             const void* wresT, const void* wskipT, const void* dtotal, const void* dcs,
                             const void* z, void* df_out, int32_t B, int32_t T, int32_t R, int32_t S, int32_t K,
@@ -234,6 +236,68 @@ int srwn_generate(const void* wcr, const void* wskip, const void* w1, const void
  * = d loss / d logits * grad_scale, columns >= 4*M written as 0. */
 int srwn_mol_loss(const float* logits, int64_t ldl, const float* x, int32_t M, float* loss_partials, void* dlogits,
                   int64_t ldd, int64_t rows, float grad_scale, int32_t dtype, void* stream);
+
+/* Same loss on the student's output (model.py:374): the teacher logits are constants (stop_gradient,
+ * model.py:334), the gradient wanted is dx[row] = d loss / d x[row] * grad_scale (fp32). */
+int srwn_mol_loss_dx(const float* logits, int64_t ldl, const float* x, int32_t M, float* loss_partials, float* dx,
+                     int64_t rows, float grad_scale, void* stream);
+
+/* ---- Parallel-WaveNet student (class ParallelWaveNet, model.py:290-537).
+ * A flow (createPartialFlow/createFlow, model.py:415-487) is the conditioned residual stack above WITHOUT the skip
+ * path, then  prm = relu(h_L) @ W2[R,2] + b2;  scale = exp(prm0), mean = prm1;  x_out = x_in*scale + mean.
+ *   srwn_flow_affine_fwd: prm [rows,2] and x_out [rows] (fp32); ent_partials[srwn_flow_partials(rows)] = block sums
+ *                         of prm0 = log scale (entropy = sum over flows + 2*rows, model.py:356)
+ *   srwn_flow_affine_bwd: dprm0 = dx_out*x_in*scale + ent_grad, dprm1 = dx_out;  dx_in = dx_out*scale;
+ *                         g [rows,R] (dtype) = (h_L > 0) * (dprm @ W2^T) = G_L for srwn_residual_layer_bwd(has_up=2);
+ *                         w_partials[block][2R+2] = (relu(h_L)^T dprm | column sums of dprm): srwn_reduce_partials
+ * ent_grad carries d(-alpha*entropy/B)/d prm0 = -alpha/B (model.py:376-379). */
+int64_t srwn_flow_partials(int64_t rows);
+int srwn_flow_affine_fwd(const void* h, const float* w2, const float* b2, const float* x_in, float* prm, float* x_out,
+                         float* ent_partials, int64_t rows, int32_t R, int32_t dtype, void* stream);
+int srwn_flow_affine_bwd(const void* h, const float* w2, const float* prm, const float* x_in, const float* dx_out,
+                         float ent_grad, void* g, float* dx_in, float* w_partials, int64_t rows, int32_t R,
+                         int32_t dtype, void* stream);
+
+/* ---- out = tf.minimum(tf.maximum(x, lo), hi) (model.py:535) and its gradient dx = dy where lo <= x <= hi, else 0
+ * (dx may alias dy). */
+int srwn_clamp(const float* x, float* y, int64_t n, float lo, float hi, void* stream);
+int srwn_clamp_bwd(const float* x, const float* dy, float* dx, int64_t n, float lo, float hi, void* stream);
+
+/* ---- data gradient of _DilatedCausalConv1d (ops.py:6-10) wrt a narrow input (the 1-channel flow input,
+ * model.py:423-424); `shift` is the adjoint of RightShift (ops.py:78-80):
+ *   dx[b,u,i] (+)= scale * sum_k sum_o w[k,i,o] * dy[b, u + shift + (K-1-k)*dilation, o]   (0 beyond the clip)
+ * dy [B,T,Cout] in `dtype`, w [K,Cin,Cout] fp32, dx [B,T,Cin] fp32 (accumulate != 0 adds into it). */
+int srwn_causal_conv1d_dgrad(const void* dy, const float* w, float* dx, int32_t B, int32_t T, int32_t Cin,
+                             int32_t Cout, int32_t K, int32_t dilation, int32_t shift, int32_t accumulate, float scale,
+                             int32_t dtype, void* stream);
+
+/* ---- STFT power loss (model.py:360-371): tf.contrib.signal.stft(x, 512, 256) -> frames without end padding
+ * (srwn_stft_frames(T) = 1 + (T-512)/256), periodic Hann window, 512-point real DFT (257 bins);
+ *   srwn_stft_power    : power[b,f] = mean_frames |X[b,n,f]|^2;  spec [B,frames,257,2] keeps (Re,Im) for the
+ *                        backward (may be NULL); frame_power [B,frames,257] is scratch
+ *   srwn_power_loss    : loss = gamma * sum (power_truth - power_out)^2 (tf.norm(.)**2);  dpower (may be NULL)
+ *                        = d(loss*grad_scale)/d power_out
+ *   srwn_stft_power_bwd: dx[b,t] (+)= sum_f dpower[b,f] * d power[b,f] / d x[b,t] */
+int32_t srwn_stft_frames(int32_t T);
+int srwn_stft_power(const float* x, float* spec, float* frame_power, float* power, int32_t B, int32_t T, void* stream);
+int srwn_power_loss(const float* power_truth, const float* power_out, int64_t n, float gamma, float grad_scale,
+                    float* dpower, float* loss, void* stream);
+int srwn_stft_power_bwd(const float* spec, const float* dpower, float* dx, int32_t B, int32_t T, int32_t accumulate,
+                        void* stream);
+
+/* ---- tf.clip_by_global_norm(grads, clip_norm) (model.py:385) + the Adam update with the clip factor on device:
+ *   srwn_sumsq      : partials[srwn_sumsq_partials(n)] = chunk sums of g^2 (call once per gradient buffer, into
+ *                     consecutive slices of one partials array)
+ *   srwn_clip_scale : norm = pre_scale*sqrt(sum partials); out[0] = pre_scale*clip_norm/max(norm, clip_norm);
+ *                     out[1] = norm   (pre_scale = 1/world when the buffers hold an all-reduced SUM)
+ *   srwn_adam_step_scaled: srwn_adam_step with grad_scale read from device memory; tick=0 shares one step
+ *                     counter between several parameter buffers (tick it on the first call of a step only) */
+int64_t srwn_sumsq_partials(int64_t n);
+int srwn_sumsq(const float* g, int64_t n, float* partials, void* stream);
+int srwn_clip_scale(const float* partials, int64_t n, float clip_norm, float pre_scale, float* out, void* stream);
+int srwn_adam_step_scaled(float* params, const float* grads, float* m, float* v, int64_t n, int64_t* step, float lr,
+                          float beta1, float beta2, float eps, const float* grad_scale_dev, int32_t tick,
+                          void* stream);
 
 #ifdef __cplusplus
 }

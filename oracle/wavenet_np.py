@@ -552,3 +552,93 @@ def mol_dlogits(x: np.ndarray, l: np.ndarray) -> np.ndarray:
     g[..., M:2 * M] = -w * dm
     g[..., 2 * M:3 * M] = -w * ds * a["clamp"]
     return g
+
+
+def mol_dx(x: np.ndarray, l: np.ndarray) -> np.ndarray:
+    """d(mol_loss)/dx [B,T]: x enters only through ``centered = x - means`` (ops.py:147), so it is minus the
+    sum over mixtures of the gradient wrt the means (the tf.where conditions on x carry no gradient)."""
+    M = l.shape[-1] // 4
+    return -mol_dlogits(x, l)[..., M:2 * M].sum(-1)
+
+
+# --------------------------------------------------------------------------
+# Parallel-WaveNet student (model.py:290-537): inverse-autoregressive flows distilled against a frozen teacher
+# --------------------------------------------------------------------------
+def init_flow_params(seed: int, dilations: Sequence[int], K: int, R: int, S: int, cond_channels: int,
+                     bias_scale: float = 0.0) -> StackParams:
+    """One flow of ``createPartialFlow`` (model.py:415-453): a conditioned decoder-style stack whose skip 1x1s
+    exist as variables but are unused (model.py:440-449 commented out), with head relu -> 1x1 R->2
+    (model.py:451-452) stored as ``head_w2``/``head_b2`` (``head_w1`` is unused)."""
+    p = init_stack_params(seed, dilations, K, R, S, 2, cond_channels=cond_channels, bias_scale=bias_scale)
+    rng = np.random.default_rng(seed + 7919)
+    p.head_w1 = None; p.head_b1 = None
+    p.head_w2 = xavier_uniform(rng, (1, R, 2))[0]
+    p.head_b2 = rng.normal(0, bias_scale, size=(2,)) if bias_scale else np.zeros((2,))
+    return p
+
+
+def flow_forward(p: StackParams, x_in: np.ndarray, cond: np.ndarray, pool_stride: int):
+    """``createFlow`` (model.py:456-487): params = partial flow(x_in); scale = exp(params[...,0]),
+    mean = params[...,1]; out = x_in*scale + mean.  x_in [B,T]; cond [B,E,Cc]."""
+    h = dilated_causal_conv1d_bias(right_shift(x_in[:, :, None]), p.init_w, p.init_b, 1)   # model.py:423-424
+    for l, d in zip(p.layers, p.dilations):
+        cb = cond @ l.wc + l.bc                                                            # model.py:431
+        h = h + resize_embedding_nearest_neighbor(cb, pool_stride * cb.shape[1])           # model.py:432-435
+        h, _skip, _ = residual_dilation_layer(h, l, d, "reference")                        # model.py:438-440
+    prm = np.maximum(h, 0) @ p.head_w2 + p.head_b2                                         # model.py:451-452
+    scale = np.exp(prm[..., 0]); mean = prm[..., 1]                                        # model.py:479-480
+    return scale, mean, x_in * scale + mean, prm
+
+
+def student_forward(flows: Sequence[StackParams], noise: np.ndarray, cond: np.ndarray, pool_stride: int):
+    """``ParallelWaveNet.createNetwork`` (model.py:490-535).  Returns out [B,T] (clipped), s_tot, mu_tot and the
+    per-flow scales/means."""
+    x = noise
+    scales, means = [], []
+    for p in flows:
+        s, m, x, _ = flow_forward(p, x, cond, pool_stride)
+        scales.append(s); means.append(m)
+    s_tot = np.ones_like(noise); mu_tot = np.zeros_like(noise)
+    for i in range(len(flows)):                                                            # model.py:517-533
+        s_tot = s_tot * scales[i]
+        mu = means[i]
+        for j in range(i + 1, len(flows)):
+            mu = mu * scales[j]
+        mu_tot = mu_tot + mu
+    out = np.minimum(np.maximum(noise * s_tot + mu_tot, -1.0), 1.0)                        # model.py:535
+    return dict(out=out, s_tot=s_tot, mu_tot=mu_tot, scales=scales, means=means, x_last=x)
+
+
+def hann_periodic(n: int) -> np.ndarray:
+    """tf.contrib.signal.hann_window(n, periodic=True), the default window of tf.contrib.signal.stft."""
+    return 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n) / n)
+
+
+def stft_power(x: np.ndarray, frame_length: int = 512, frame_step: int = 256) -> np.ndarray:
+    """``reduce_mean(abs(stft(x, 512, 256))**2, 1)`` (model.py:360-368): frames without end padding
+    (1 + (T-512)//256 of them), periodic Hann window, fft_length = 512 -> [B, 257]."""
+    B, T = x.shape
+    nf = 1 + (T - frame_length) // frame_step
+    if T < frame_length or nf < 1:
+        raise ValueError("stft_power: clip shorter than one frame")
+    frames = np.stack([x[:, i * frame_step:i * frame_step + frame_length] for i in range(nf)], 1)
+    X = np.fft.rfft(frames * hann_periodic(frame_length), n=frame_length, axis=-1)
+    return (np.abs(X) ** 2).mean(1)
+
+
+def student_loss(fw, teacher_logits: np.ndarray, truth: np.ndarray, alpha=1.0, beta=1.0, gamma=1.0):
+    """model.py:356-379: entropy = sum(log s_tot + 2); power = gamma*||phi(truth) - phi(out)||_F^2;
+    loss = (beta*MoL_NLL(out | teacher) - alpha*entropy + power) / B."""
+    B = truth.shape[0]
+    entropy = float((np.log(fw["s_tot"]) + 2.0).sum())
+    diff = stft_power(truth) - stft_power(fw["out"])
+    power = float((diff ** 2).sum()) * gamma
+    ce = mol_loss(np.clip(fw["out"], -1, 1), teacher_logits) * beta
+    return dict(loss=(ce - alpha * entropy + power) / B, power_loss=power, entropy=entropy, cross_entropy=ce)
+
+
+def clip_by_global_norm(grads: Sequence[np.ndarray], clip_norm: float = 1.0):
+    """tf.clip_by_global_norm (model.py:385): g * clip_norm / max(global_norm, clip_norm)."""
+    gn = math.sqrt(sum(float((g.astype(np.float64) ** 2).sum()) for g in grads))
+    s = clip_norm / max(gn, clip_norm)
+    return [g * s for g in grads], gn

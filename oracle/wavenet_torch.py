@@ -179,3 +179,73 @@ def mol_loss(x: torch.Tensor, l: torch.Tensor) -> torch.Tensor:
                                                log_pdf_mid - math.log(127.5))))
     lp = comp + torch.log_softmax(logit_probs, dim=-1)
     return -torch.logsumexp(lp, dim=-1).sum()
+
+
+def mol_loss_sum(x: torch.Tensor, l: torch.Tensor) -> torch.Tensor:
+    return mol_loss(x, l)
+
+
+# --------------------------------------------------------------------------
+# Parallel-WaveNet student (model.py:290-537) with autograd
+# --------------------------------------------------------------------------
+def flow_forward(st: TorchStack, x_in: torch.Tensor, cond: torch.Tensor, pool_stride: int):
+    """model.py:415-487 on a TorchStack whose head_w2/head_b2 are the R->2 1x1 (oracle/wavenet_np.init_flow_params)."""
+    x0 = F.pad(x_in[:, None, :], (1, 0))[:, :, :-1]
+    h = causal_conv(x0, st.init_w, 1) + st.init_b[None, :, None]
+    for l, d in zip(st.layers, st.dilations):
+        cb = cond @ l["wc"] + l["bc"]
+        h = h + cb.repeat_interleave(pool_stride, dim=1).transpose(1, 2)
+        z = torch.tanh(causal_conv(h, l["wf"], d) + l["bf"][None, :, None])
+        c = z * torch.sigmoid(z)
+        h = (h + torch.einsum("bnt,nm->bmt", c, l["wr"]) + l["br"][None, :, None]) * SQRT_HALF
+    prm = torch.einsum("brt,rc->btc", torch.relu(h), st.head_w2) + st.head_b2
+    scale = torch.exp(prm[..., 0]); mean = prm[..., 1]
+    return scale, mean, x_in * scale + mean, prm
+
+
+def stft_power(x: torch.Tensor, frame_length: int = 512, frame_step: int = 256) -> torch.Tensor:
+    """DFT-matrix restatement of model.py:360-368 (independent of np.fft in oracle (i))."""
+    B, T = x.shape
+    nf = 1 + (T - frame_length) // frame_step
+    n = torch.arange(frame_length, dtype=x.dtype)
+    win = 0.5 - 0.5 * torch.cos(2 * math.pi * n / frame_length)
+    k = torch.arange(frame_length // 2 + 1, dtype=x.dtype)
+    ang = 2 * math.pi * torch.outer(n, k) / frame_length
+    frames = x.unfold(1, frame_length, frame_step)[:, :nf] * win
+    re = frames @ torch.cos(ang); im = -(frames @ torch.sin(ang))
+    return (re * re + im * im).mean(1)
+
+
+def student_loss(flows: List[TorchStack], noise: torch.Tensor, cond: torch.Tensor, pool_stride: int,
+                 teacher_logits: torch.Tensor, truth: torch.Tensor, alpha=1.0, beta=1.0, gamma=1.0):
+    """model.py:490-535 + 356-379; teacher_logits are constants (stop_gradient, model.py:334)."""
+    x = noise
+    scales, means = [], []
+    for st in flows:
+        s, m, x, _ = flow_forward(st, x, cond, pool_stride)
+        scales.append(s); means.append(m)
+    s_tot = torch.ones_like(noise); mu_tot = torch.zeros_like(noise)
+    for i in range(len(flows)):
+        s_tot = s_tot * scales[i]
+        mu = means[i]
+        for j in range(i + 1, len(flows)):
+            mu = mu * scales[j]
+        mu_tot = mu_tot + mu
+    out = torch.minimum(torch.maximum(noise * s_tot + mu_tot, torch.tensor(-1.0, dtype=noise.dtype)),
+                        torch.tensor(1.0, dtype=noise.dtype))
+    entropy = (torch.log(s_tot) + 2.0).sum()
+    diff = stft_power(truth) - stft_power(out)
+    power = (diff ** 2).sum() * gamma
+    ce = mol_loss(torch.clamp(out, -1, 1), teacher_logits) * beta
+    loss = (ce - alpha * entropy + power) / noise.shape[0]
+    return dict(loss=loss, power_loss=power, entropy=entropy, cross_entropy=ce, out=out, s_tot=s_tot, mu_tot=mu_tot)
+
+
+def flow_named(st: TorchStack):
+    """Trained variables of one flow (the skip 1x1s get no gradient: model.py:440-449)."""
+    out = [("init_w", st.init_w), ("init_b", st.init_b)]
+    for i, l in enumerate(st.layers):
+        out += [(f"l{i}.wf", l["wf"]), (f"l{i}.bf", l["bf"]), (f"l{i}.wr", l["wr"]), (f"l{i}.br", l["br"]),
+                (f"l{i}.wc", l["wc"]), (f"l{i}.bc", l["bc"])]
+    out += [("head_w2", st.head_w2), ("head_b2", st.head_b2)]
+    return out

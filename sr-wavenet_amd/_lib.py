@@ -56,6 +56,21 @@ SIGNATURES = {
     "srwn_mol_loss": (C.c_int, [_p, _i64, _p, _i32, _p, _p, _i64, _i64, _f32, _i32, _p]),
     "srwn_wgrad256_slabs": (_i32, [_i64, _i32]),
     "srwn_wgrad256": (C.c_int, [_p, _i64, _i64, _i32, _p, _i64, _p, _p, _i64, _i32, _i32, _i32, _p]),
+    "srwn_mol_loss_dx": (C.c_int, [_p, _i64, _p, _i32, _p, _p, _i64, _f32, _p]),
+    "srwn_clamp": (C.c_int, [_p, _p, _i64, _f32, _f32, _p]),
+    "srwn_clamp_bwd": (C.c_int, [_p, _p, _p, _i64, _f32, _f32, _p]),
+    "srwn_flow_partials": (_i64, [_i64]),
+    "srwn_flow_affine_fwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
+    "srwn_flow_affine_bwd": (C.c_int, [_p, _p, _p, _p, _p, _f32, _p, _p, _p, _i64, _i32, _i32, _p]),
+    "srwn_causal_conv1d_dgrad": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _p]),
+    "srwn_stft_frames": (_i32, [_i32]),
+    "srwn_stft_power": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _p]),
+    "srwn_power_loss": (C.c_int, [_p, _p, _i64, _f32, _f32, _p, _p, _p]),
+    "srwn_stft_power_bwd": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _p]),
+    "srwn_sumsq_partials": (_i64, [_i64]),
+    "srwn_sumsq": (C.c_int, [_p, _i64, _p, _p]),
+    "srwn_clip_scale": (C.c_int, [_p, _i64, _f32, _f32, _p, _p]),
+    "srwn_adam_step_scaled": (C.c_int, [_p, _p, _p, _p, _i64, _p, _f32, _f32, _f32, _f32, _p, _i32, _p]),
 }
 
 _lib = None

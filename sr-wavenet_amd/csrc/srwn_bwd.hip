@@ -17,6 +17,8 @@ using namespace srwn;
 //   The UP accumulator tile is the B operand of the Wr product (no LDS / HBM round trip).
 //   Flags: layer L-1 runs DOWN only (G_L = 0: the last dense output is unused, model.py:45-50);
 //          the call below layer 0 runs UP only (gradient wrt the input conv output).
+//          Flow stacks (model.py:415-453) have no skip path (SK = 2: dc = Wr . G sqrt(.5) only) and DO use the
+//          last dense output: their layer L-1 runs with UPM = 2, reading G_L from g_out instead of building it.
 //   Same execution shape as the forward kernel: persistent waves over 32-step tiles, the next tile's
 //   operands in flight (ping-pong register sets, unconditional clamped loads), whole-row stores via LDS.
 // ------------------------------------------------------------------------------------------
@@ -46,21 +48,22 @@ template <> struct Raw4<float> {
   static __device__ __forceinline__ float get(const type& v, int e) { return v[e]; }
 };
 
-template <typename T, int RT, int K, bool UP, bool GIN, bool DOWN, bool DCS>
+template <typename T, int RT, int K, int UPM, bool GIN, bool DOWN, int SK>
 __global__ __launch_bounds__(256) void layer_bwd_kernel(LayerBwdArgs a) {
   constexpr int R = 32 * RT, KS = R / 16;
+  constexpr bool UP = UPM == 1, HAVEG = UPM != 0, DCS = SK == 1, LEGACY = SK == 0;
   typedef typename Raw4<T>::type raw4;
   const int KSS = a.S / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   Frag<T>* lds_conv = reinterpret_cast<Frag<T>*>(smem);                    // [RT*K*KS][64]   (UP)
-  Frag<T>* lds_res = lds_conv + (UP ? RT * K * KS * 64 : 0);               // [RT*KS][64]     (UP && DOWN)
-  Frag<T>* lds_skip = lds_res + ((UP && DOWN) ? RT * KS * 64 : 0);         // [RT*KSS][64]    (DOWN && !DCS)
+  Frag<T>* lds_res = lds_conv + (UP ? RT * K * KS * 64 : 0);               // [RT*KS][64]     (HAVEG && DOWN)
+  Frag<T>* lds_skip = lds_res + ((HAVEG && DOWN) ? RT * KS * 64 : 0);      // [RT*KSS][64]    (DOWN && LEGACY)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  T* stage = reinterpret_cast<T*>(lds_skip + ((DOWN && !DCS) ? RT * KSS * 64 : 0)) +
+  T* stage = reinterpret_cast<T*>(lds_skip + ((DOWN && LEGACY) ? RT * KSS * 64 : 0)) +
              wave * (32 * RowStage<T>::stride(R));
   if (UP) lds_dma_copy(a.wconvT, lds_conv, RT * K * KS * 64 * (int)sizeof(Frag<T>), wave, lane, 4);
-  if (UP && DOWN) lds_dma_copy(a.wresT, lds_res, RT * KS * 64 * (int)sizeof(Frag<T>), wave, lane, 4);
-  if (DOWN && !DCS) lds_dma_copy(a.wskipT, lds_skip, RT * KSS * 64 * (int)sizeof(Frag<T>), wave, lane, 4);
+  if (HAVEG && DOWN) lds_dma_copy(a.wresT, lds_res, RT * KS * 64 * (int)sizeof(Frag<T>), wave, lane, 4);
+  if (DOWN && LEGACY) lds_dma_copy(a.wskipT, lds_skip, RT * KSS * 64 * (int)sizeof(Frag<T>), wave, lane, 4);
   // (barrier after the first tile's loads are issued: one round trip for weights + first operands)
 
   const int col = lane & 31, half = lane >> 5;
@@ -78,6 +81,13 @@ __global__ __launch_bounds__(256) void layer_bwd_kernel(LayerBwdArgs a) {
     const int tcc = tc < a.Tlen ? tc : a.Tlen - 1;
     const size_t boff = (size_t)b * a.Tlen;
     const size_t rowi = boff + tcc;
+    if (UPM == 2) {   // G_{l+1} already lies in g_out (flow head gradient)
+      const T* gin = reinterpret_cast<const T*>(a.g_out) + rowi * R;
+#pragma unroll
+      for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) t.gin[mt][g] = Raw4<T>::load(gin + 32 * mt + 8 * g + 4 * half);
+    }
     if (UP) {
       if (GIN) {
         const T* gin = reinterpret_cast<const T*>(a.g_in) + rowi * R;
@@ -120,6 +130,14 @@ __global__ __launch_bounds__(256) void layer_bwd_kernel(LayerBwdArgs a) {
     const int rows_valid = a.Tlen - t0;
     const size_t boff = (size_t)b * a.Tlen;
     f32x16 accG[RT];
+    if (UPM == 2) {
+#pragma unroll
+      for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) accG[mt][4 * g + e] = ok ? Raw4<T>::get(t.gin[mt][g], e) : 0.0f;
+    }
     if (UP) {
       // residual path: G_{l+2} * sqrt(.5) in accumulator layout
 #pragma unroll
@@ -158,7 +176,7 @@ __global__ __launch_bounds__(256) void layer_bwd_kernel(LayerBwdArgs a) {
         for (int g = 0; g < 4; ++g)
 #pragma unroll
           for (int e = 0; e < 4; ++e) accC[mt][4 * g + e] = (DCS && ok) ? Raw4<T>::get(t.dcs[mt][g], e) : 0.0f;
-      if (UP) {
+      if (HAVEG) {
         // dres = G_{l+1} * sqrt(.5): the accumulator tile is the B operand (permuted k order)
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -172,7 +190,7 @@ __global__ __launch_bounds__(256) void layer_bwd_kernel(LayerBwdArgs a) {
           }
         }
       }
-      if (!DCS) {
+      if (LEGACY) {
         const T* dt = reinterpret_cast<const T*>(a.dtotal) + (boff + (ok ? tc : 0)) * a.S + 8 * half;
         for (int ks = 0; ks < KSS; ++ks) {
           const Frag<T> bf = ok ? load_nat(dt + 16 * ks) : zero_frag<T>();
@@ -221,12 +239,12 @@ static int bwd_blocks_per_cu() {
 }
 
 template <typename T, int RT>
-static int launch_layer_bwd(LayerBwdArgs a, int B, bool up, bool gin, bool down, bool dcs, hipStream_t st) {
+static int launch_layer_bwd(LayerBwdArgs a, int B, int up, bool gin, bool down, int sk, hipStream_t st) {
   constexpr int K = 2, R = 32 * RT, KS = R / 16;
   size_t frags = 0;
-  if (up) frags += RT * K * KS;
+  if (up == 1) frags += RT * K * KS;
   if (up && down) frags += RT * KS;
-  if (down && !dcs) frags += (size_t)RT * (a.S / 16);
+  if (down && sk == 0) frags += (size_t)RT * (a.S / 16);
   const size_t sh = frags * 64 * sizeof(Frag<T>) + (size_t)4 * 32 * RowStage<T>::stride(R) * sizeof(T);
   a.ntb = (a.Tlen + 31) / 32;
   const long long ntiles = (long long)B * a.ntb;
@@ -235,7 +253,7 @@ static int launch_layer_bwd(LayerBwdArgs a, int B, bool up, bool gin, bool down,
   if (blocks > 256LL * bwd_blocks_per_cu()) blocks = 256LL * bwd_blocks_per_cu();
   dim3 grid((unsigned)blocks), block(256);
 #define SRWN_LB(U, G, D, C)                                                                                    \
-  if (up == U && gin == G && down == D && dcs == C) {                                                          \
+  if (up == U && gin == G && down == D && sk == C) {                                                          \
     auto kfn = layer_bwd_kernel<T, RT, K, U, G, D, C>;                                                         \
     if (sh > 32768) {                                                                                          \
       hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
@@ -244,14 +262,17 @@ static int launch_layer_bwd(LayerBwdArgs a, int B, bool up, bool gin, bool down,
     hipLaunchKernelGGL(kfn, grid, block, sh, st, a);                                                           \
     return check_launch("residual_layer_bwd");                                                                 \
   }
-  SRWN_LB(true, true, true, true)
-  SRWN_LB(true, false, true, true)
-  SRWN_LB(false, false, true, true)
-  SRWN_LB(true, true, true, false)
-  SRWN_LB(true, false, true, false)
-  SRWN_LB(false, false, true, false)
-  SRWN_LB(true, true, false, false)
-  SRWN_LB(true, false, false, false)
+  SRWN_LB(1, true, true, 1)
+  SRWN_LB(1, false, true, 1)
+  SRWN_LB(0, false, true, 1)
+  SRWN_LB(1, true, true, 0)
+  SRWN_LB(1, false, true, 0)
+  SRWN_LB(0, false, true, 0)
+  SRWN_LB(1, true, false, 2)
+  SRWN_LB(1, false, false, 2)
+  SRWN_LB(1, true, true, 2)
+  SRWN_LB(1, false, true, 2)
+  SRWN_LB(2, false, true, 2)
 #undef SRWN_LB
   return set_error(SRWN_E_UNSUPPORTED, "residual_layer_bwd: flag combination not built");
 }
@@ -263,17 +284,23 @@ extern "C" int srwn_residual_layer_bwd(const void* g_in, const void* df_up, cons
                                        int32_t dtype, void* stream) {
   if (B == 0 || T == 0) return 0;
   if (!has_up && !has_down) return set_error(SRWN_E_SHAPE, "residual_layer_bwd: neither UP nor DOWN");
-  if (has_up && (!df_up || !wconvT_up || !g_out)) return set_error(SRWN_E_NULL, "residual_layer_bwd: UP needs df_up, wconvT_up, g_out");
+  if (has_up == 1 && (!df_up || !wconvT_up || !g_out)) return set_error(SRWN_E_NULL, "residual_layer_bwd: UP needs df_up, wconvT_up, g_out");
+  if (has_up == 2 && (!g_out || !has_down || S != 0)) return set_error(SRWN_E_NULL, "residual_layer_bwd: has_up=2 reads G from g_out, needs DOWN and S=0");
+  if (has_up < 0 || has_up > 2) return set_error(SRWN_E_SHAPE, "residual_layer_bwd: has_up=%d", has_up);
   if (has_down && (!z || !df_out)) return set_error(SRWN_E_NULL, "residual_layer_bwd: DOWN needs z, df_out");
-  if (has_down && !dcs && (!wskipT || !dtotal)) return set_error(SRWN_E_NULL, "residual_layer_bwd: DOWN needs dcs, or wskipT + dtotal");
+  if (has_down && S != 0 && !dcs && (!wskipT || !dtotal)) return set_error(SRWN_E_NULL, "residual_layer_bwd: DOWN needs dcs, or wskipT + dtotal");
+  if (has_down && S == 0 && !has_up) return set_error(SRWN_E_SHAPE, "residual_layer_bwd: no skip path (S=0) and no G: df would be zero");
   if (has_up && has_down && !wresT) return set_error(SRWN_E_NULL, "residual_layer_bwd: UP+DOWN needs wresT");
   if (K != 2) return set_error(SRWN_E_UNSUPPORTED, "residual_layer_bwd: filter_width %d (only 2 is built)", K);
-  if (B < 0 || T < 0 || S < 16 || S % 16 || (has_up && dilation_up < 1))
+  if (B < 0 || T < 0 || (S != 0 && S < 16) || S % 16 || (has_up == 1 && dilation_up < 1))
     return set_error(SRWN_E_SHAPE, "residual_layer_bwd: B=%d T=%d S=%d d=%d", B, T, S, dilation_up);
   if ((long long)B * ((T + 31) / 32) > 0x7fffffffLL) return set_error(SRWN_E_SHAPE, "residual_layer_bwd: too many tiles");
   LayerBwdArgs a{g_in, df_up, wconvT_up, g_out, wresT, wskipT, dtotal, dcs, z, df_out, T, dilation_up, S, 0, 0};
   hipStream_t st = (hipStream_t)stream;
-  const bool up = has_up != 0, down = has_down != 0, gin = up && g_in != nullptr, use_dcs = down && dcs != nullptr;
+  const int up = has_up;
+  const bool down = has_down != 0, gin = up == 1 && g_in != nullptr;
+  // skip-path mode: 1 = dcs given, 0 = computed here from dtotal, 2 = none (S = 0, or UP-only call)
+  const int use_dcs = !down ? 2 : (S == 0 ? 2 : (dcs != nullptr ? 1 : 0));
   if (dtype == SRWN_BF16) {
     if (R == 32) return launch_layer_bwd<bf16_t, 1>(a, B, up, gin, down, use_dcs, st);
     if (R == 64) return launch_layer_bwd<bf16_t, 2>(a, B, up, gin, down, use_dcs, st);

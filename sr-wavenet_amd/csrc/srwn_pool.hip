@@ -196,7 +196,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void mol_loss_kernel(const float* __restrict__ logits, int64_t ldl,
                                                        const float* __restrict__ x, int M,
                                                        float* __restrict__ loss_partials, T* __restrict__ dlogits,
-                                                       int64_t ldd, int64_t rows, float grad_scale) {
+                                                       int64_t ldd, int64_t rows, float grad_scale,
+                                                       float* __restrict__ dx) {
   __shared__ float red[256];
   const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
   float loss = 0.0f;
@@ -247,16 +248,23 @@ __global__ __launch_bounds__(256) void mol_loss_kernel(const float* __restrict__
     for (int m = 0; m < M; ++m) sw += expf(lp[m] - mlp);
     const float lse = mlp + logf(sw);
     loss = -lse;                                                            // ops.py:174
-    T* dr = dlogits + row * ldd;
-    for (int m = 0; m < M; ++m) {
-      const float w = expf(lp[m] - lse);
-      const float smx = expf(lg[m] - lse_logit);
-      dr[m] = (T)(-(w - smx) * grad_scale);
-      dr[M + m] = (T)(-w * dmean[m] * grad_scale);
-      dr[2 * M + m] = (T)(-w * dls[m] * grad_scale);
-      dr[3 * M + m] = (T)0.0f;                                              // coeffs never reach the loss
+    if (dlogits) {
+      T* dr = dlogits + row * ldd;
+      for (int m = 0; m < M; ++m) {
+        const float w = expf(lp[m] - lse);
+        const float smx = expf(lg[m] - lse_logit);
+        dr[m] = (T)(-(w - smx) * grad_scale);
+        dr[M + m] = (T)(-w * dmean[m] * grad_scale);
+        dr[2 * M + m] = (T)(-w * dls[m] * grad_scale);
+        dr[3 * M + m] = (T)0.0f;                                            // coeffs never reach the loss
+      }
+      for (int64_t c = 4 * M; c < ldd; ++c) dr[c] = (T)0.0f;
     }
-    for (int64_t c = 4 * M; c < ldd; ++c) dr[c] = (T)0.0f;
+    if (dx) {   // x enters through centered = x - mean only (ops.py:147): d/dx = -sum_m d/dmean_m
+      float g = 0.0f;
+      for (int m = 0; m < M; ++m) g += expf(lp[m] - lse) * dmean[m];
+      dx[row] = g * grad_scale;
+    }
   }
   red[threadIdx.x] = loss;
   __syncthreads();
@@ -277,10 +285,22 @@ extern "C" int srwn_mol_loss(const float* logits, int64_t ldl, const float* x, i
   dim3 grid((unsigned)((rows + 255) / 256)), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == SRWN_F32)
-    hipLaunchKernelGGL(mol_loss_kernel<float>, grid, block, 0, st, logits, ldl, x, M, loss_partials, (float*)dlogits, ldd, rows, grad_scale);
+    hipLaunchKernelGGL(mol_loss_kernel<float>, grid, block, 0, st, logits, ldl, x, M, loss_partials, (float*)dlogits, ldd, rows, grad_scale, (float*)nullptr);
   else if (dtype == SRWN_BF16)
-    hipLaunchKernelGGL(mol_loss_kernel<bf16_t>, grid, block, 0, st, logits, ldl, x, M, loss_partials, (bf16_t*)dlogits, ldd, rows, grad_scale);
+    hipLaunchKernelGGL(mol_loss_kernel<bf16_t>, grid, block, 0, st, logits, ldl, x, M, loss_partials, (bf16_t*)dlogits, ldd, rows, grad_scale, (float*)nullptr);
   else
     return set_error(SRWN_E_DTYPE, "mol_loss: dtype %d", dtype);
   return check_launch("mol_loss");
+}
+
+extern "C" int srwn_mol_loss_dx(const float* logits, int64_t ldl, const float* x, int32_t M, float* loss_partials,
+                                float* dx, int64_t rows, float grad_scale, void* stream) {
+  if (rows == 0) return 0;
+  if (!logits || !x || !loss_partials || !dx) return set_error(SRWN_E_NULL, "mol_loss_dx: null pointer");
+  if (rows < 0 || M < 1 || M > 16 || ldl < 4 * M)
+    return set_error(SRWN_E_SHAPE, "mol_loss_dx: rows=%lld M=%d ldl=%lld", (long long)rows, M, (long long)ldl);
+  dim3 grid((unsigned)((rows + 255) / 256)), block(256);
+  hipLaunchKernelGGL(mol_loss_kernel<float>, grid, block, 0, (hipStream_t)stream, logits, ldl, x, M, loss_partials,
+                     (float*)nullptr, (int64_t)0, rows, grad_scale, dx);
+  return check_launch("mol_loss_dx");
 }

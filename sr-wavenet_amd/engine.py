@@ -46,6 +46,8 @@ class StackConfig:
     #                                  "mol": discretised mixture of logistics, the live teacher's loss
     #                                         (model.py:114,196; ops.py:124-175): output_channels = 4*mixtures,
     #                                         loss SUMMED over batch and time
+    #                                  "flow": no skip path, head relu -> 1x1 R->2 + affine transform: one flow of
+    #                                         ParallelWaveNet (model.py:415-487), see student.FlowStack
     dtype: torch.dtype = torch.bfloat16
     learning_rate: float = 1e-3
 
@@ -91,7 +93,7 @@ class WaveNetEngine:
             raise NotImplementedError("output_channels must be in [1, 256]")
         if cfg.head_mode == "mol" and (cfg.output_channels % 4 or not 4 <= cfg.output_channels <= 64):
             raise ValueError("mol head: output_channels = 4 * num_mixtures (<= 16 mixtures)")
-        if cfg.head_mode not in ("per_timestep", "pooled", "mol"):
+        if cfg.head_mode not in ("per_timestep", "pooled", "mol", "flow"):
             raise ValueError("head_mode %r" % cfg.head_mode)
         if cfg.cond_channels and (length % cfg.pool_stride):
             raise ValueError("length %d is not a multiple of pool_stride %d" % (length, cfg.pool_stride))
@@ -273,12 +275,33 @@ class WaveNetEngine:
         L, R, S, Kw, Cp, E, Ep = self.L, self.R, self.S, self.Kw, self.Cp, self.E, self.Ep
         sec = self.sections
         pk = K.Packer(self.dev)
-        self.o_conv, self.o_res, self.o_convT, self.o_resT, self.o_skipT = [], [], [], [], []
+        self._pack_stack(pk)
+        self._pack_head(pk)
+        pk.finalize()
+        self.packer = pk
+        self.packed = torch.zeros(max(pk.total, 1), dtype=self.dt, device=self.dev)
+
+    def _pack_stack(self, pk):
+        """Per-layer images of the residual stack: conv, 1x1 residual, their transposes, conditioning 1x1s."""
+        L, R, Kw, E, Ep = self.L, self.R, self.Kw, self.E, self.Ep
+        sec = self.sections
+        self.o_conv, self.o_res, self.o_convT, self.o_resT = [], [], [], []
         for l in range(L):
             self.o_conv.append(P.pack_conv(pk, sec["WF"].offset + l * Kw * R * R, Kw, R))
             self.o_res.append(P.pack_res(pk, sec["WR"].offset + l * R * R, R))
             self.o_convT.append(P.pack_conv_T(pk, sec["WF"].offset + l * Kw * R * R, Kw, R))
             self.o_resT.append(P.pack_linear_T(pk, sec["WR"].offset + l * R * R, R, R, R, perm=True))
+        if E:
+            # conditioning 1x1 of every layer as one [Ep] -> [L*R] product (model.py:180)
+            self.o_wc = pk.reserve(L * R // 32, Ep // 16)
+            for l in range(L):
+                P.fill_linear(pk, self.o_wc + l * (R // 32) * (Ep // 16) * 512, sec["WC"].offset + l * E * R, E, R,
+                              R // 32, Ep // 16)
+
+    def _pack_head(self, pk):
+        L, R, S, Kw, Cp = self.L, self.R, self.S, self.Kw, self.Cp
+        sec = self.sections
+        self.o_skipT = []
         # generation images: per layer [conv (last tap permuted) | residual], back to back (srwn_generate)
         self.o_gen = self.o_skip_gen = None
         if R == 64 and S == 256 and Kw == 2:
@@ -307,15 +330,6 @@ class WaveNetEngine:
         self.o_w2 = P.pack_linear(pk, sec["head_w2"].offset, S, Cp, Cp)
         self.o_w1T = P.pack_linear_T(pk, sec["head_w1"].offset, S, S, S)
         self.o_w2T = P.pack_linear_T(pk, sec["head_w2"].offset, S, Cp, S)
-        if E:
-            # conditioning 1x1 of every layer as one [Ep] -> [L*R] product (model.py:180)
-            self.o_wc = pk.reserve(L * R // 32, Ep // 16)
-            for l in range(L):
-                P.fill_linear(pk, self.o_wc + l * (R // 32) * (Ep // 16) * 512, sec["WC"].offset + l * E * R, E, R,
-                              R // 32, Ep // 16)
-        pk.finalize()
-        self.packer = pk
-        self.packed = torch.zeros(max(pk.total, 1), dtype=self.dt, device=self.dev)
 
     def wptr(self, off: int) -> int:
         return self.packed.data_ptr() + off * self.packed.element_size()
@@ -327,14 +341,39 @@ class WaveNetEngine:
     # buffers
     # ------------------------------------------------------------------------------------------
     def _alloc_buffers(self):
-        B, T, N, L, R, S, Cp = self.B, self.T, self.N, self.L, self.R, self.S, self.Cp
+        self._alloc_stack_buffers()
+        self._alloc_head_buffers()
+
+    def _alloc_stack_buffers(self):
+        """Saved activations / gradients of the residual stack and its weight-gradient scratch."""
+        B, T, N, L, R = self.B, self.T, self.N, self.L, self.R
         z = lambda *s, dt=self.dt: torch.zeros(s, dtype=dt, device=self.dev)
         self.audio = z(B, T, dt=torch.float32)
-        self.targets = torch.zeros(N, dtype=torch.int32, device=self.dev)
         self.xs = z(L + 1, B, T, R)
         self.zs = z(L, B, T, R)
         self.dfs = z(L, B, T, R)
-        self.gs = z(L + 1, B, T, R)   # gs[L] is never written: the last dense output is unused
+        self.gs = z(L + 1, B, T, R)   # gs[L] is never written by the teacher: its last dense output is unused
+        self.nslabs = K.wgrad_slabs(N)
+        self.use_wl = (R == 64 and self.Kw == 2)
+        if self.use_wl:
+            ns = self.nslabs
+            self.pl_f = z(L * ns * 2 * R * R, dt=torch.float32); self.pl_r = z(L * ns * R * R, dt=torch.float32)
+            self.pl_bf = z(L * ns * R, dt=torch.float32); self.pl_br = z(L * ns * R, dt=torch.float32)
+        from . import _lib
+        self.ic_ws = z(int(_lib.load().srwn_init_conv_wgrad_partials(B, T, R, self.Kw)), dt=torch.float32)
+        if self.E:
+            self.cond_in = z(B * self.frames, self.Ep)
+            self.cond_all = z(B * self.frames, L * R)      # cb of every layer, [B*frames, L*R]
+            self.dcb = z(L, B * self.frames, R)
+            self.nslabs_c = K.wgrad_slabs(B * self.frames)
+            self.wgc_parts = z(self.nslabs_c * L * self.Ep * R, dt=torch.float32)
+            self.wgc_bparts = z(self.nslabs_c * L * R, dt=torch.float32)
+            self.wc_grad_pad = z(L, self.Ep, R, dt=torch.float32)
+
+    def _alloc_head_buffers(self):
+        B, T, N, L, R, S, Cp = self.B, self.T, self.N, self.L, self.R, self.S, self.Cp
+        z = lambda *s, dt=self.dt: torch.zeros(s, dtype=dt, device=self.dev)
+        self.targets = torch.zeros(N, dtype=torch.int32, device=self.dev)
         self.use_dcs = (R, S) in ((64, 256), (32, 128))
         if self.use_dcs:
             self.dcs = z(L, B, T, R)  # Ws_l . dtotal of every layer (one output-streaming GEMM)
@@ -354,13 +393,7 @@ class WaveNetEngine:
             self.mean_r1 = z(B, S, dt=torch.float32)
             self.dmean = z(B, S, dt=torch.float32)
             self.tm_parts = z(B * int(_l.load().srwn_time_mean_slabs(T)) * S, dt=torch.float32)
-        self.nslabs = K.wgrad_slabs(N)
         big = max(L * R * S, S * S, S * Cp, L * self.Kw * R * R)
-        self.use_wl = (R == 64 and self.Kw == 2)
-        if self.use_wl:
-            ns = self.nslabs
-            self.pl_f = z(L * ns * 2 * R * R, dt=torch.float32); self.pl_r = z(L * ns * R * R, dt=torch.float32)
-            self.pl_bf = z(L * ns * R, dt=torch.float32); self.pl_br = z(L * ns * R, dt=torch.float32)
         self.use_w256 = (S == 256 and R == 64)
         if self.use_w256:
             self.ns_skip = K.wgrad256_slabs(N, L)
@@ -368,16 +401,6 @@ class WaveNetEngine:
             big = max(big, -(-max(self.ns_skip * L * R * S, self.ns_head * S * 256) // self.nslabs))
         self.wg_parts = z(self.nslabs * big, dt=torch.float32)
         self.wg_bparts = z(max(self.nslabs * max(L * S, Cp), 256 * 256), dt=torch.float32)
-        from . import _lib
-        self.ic_ws = z(int(_lib.load().srwn_init_conv_wgrad_partials(B, T, R, self.Kw)), dt=torch.float32)
-        if self.E:
-            self.cond_in = z(B * self.frames, self.Ep)
-            self.cond_all = z(B * self.frames, L * R)      # cb of every layer, [B*frames, L*R]
-            self.dcb = z(L, B * self.frames, R)
-            self.nslabs_c = K.wgrad_slabs(B * self.frames)
-            self.wgc_parts = z(self.nslabs_c * L * self.Ep * R, dt=torch.float32)
-            self.wgc_bparts = z(self.nslabs_c * L * R, dt=torch.float32)
-            self.wc_grad_pad = z(L, self.Ep, R, dt=torch.float32)
 
     # ------------------------------------------------------------------------------------------
     # forward

@@ -369,3 +369,112 @@ def adam_step(params: torch.Tensor, grads: torch.Tensor, m: torch.Tensor, v: tor
     _chk(step, "step", torch.int64, (1,))
     call("srwn_adam_step", params.data_ptr(), grads.data_ptr(), m.data_ptr(), v.data_ptr(), n, step.data_ptr(),
          float(lr), float(beta1), float(beta2), float(eps), float(grad_scale), _stream())
+
+
+# ----------------------------------------------------------------------------------------------
+# Parallel-WaveNet student kernels (model.py:290-537)
+# ----------------------------------------------------------------------------------------------
+def flow_partials(rows: int) -> int:
+    return int(_lib.load().srwn_flow_partials(int(rows)))
+
+
+def flow_affine_fwd(h: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, x_in: torch.Tensor, prm: torch.Tensor,
+                    x_out: torch.Tensor, ent_partials: torch.Tensor):
+    """prm = relu(h) @ w2 + b2; x_out = x_in*exp(prm0) + prm1 (model.py:451-452, 479-483)."""
+    rows, R = h.shape
+    _chk(w2, "w2", torch.float32, (R, 2)); _chk(b2, "b2", torch.float32, (2,))
+    _chk(x_in, "x_in", torch.float32, (rows,)); _chk(prm, "prm", torch.float32, (rows, 2))
+    _chk(x_out, "x_out", torch.float32, (rows,))
+    _chk(ent_partials, "ent_partials", torch.float32, (flow_partials(rows),))
+    call("srwn_flow_affine_fwd", _chk(h, "h"), w2.data_ptr(), b2.data_ptr(), x_in.data_ptr(), prm.data_ptr(),
+         x_out.data_ptr(), ent_partials.data_ptr(), rows, R, abi_dtype(h.dtype), _stream())
+
+
+def flow_affine_bwd(h: torch.Tensor, w2: torch.Tensor, prm: torch.Tensor, x_in: torch.Tensor, dx_out: torch.Tensor,
+                    ent_grad: float, g: torch.Tensor, dx_in: torch.Tensor, w_partials: torch.Tensor):
+    rows, R = h.shape
+    _chk(w2, "w2", torch.float32, (R, 2)); _chk(prm, "prm", torch.float32, (rows, 2))
+    _chk(x_in, "x_in", torch.float32, (rows,)); _chk(dx_out, "dx_out", torch.float32, (rows,))
+    _chk(g, "g", h.dtype, (rows, R)); _chk(dx_in, "dx_in", torch.float32, (rows,))
+    _chk(w_partials, "w_partials", torch.float32, (flow_partials(rows), 2 * R + 2))
+    call("srwn_flow_affine_bwd", _chk(h, "h"), w2.data_ptr(), prm.data_ptr(), x_in.data_ptr(), dx_out.data_ptr(),
+         float(ent_grad), g.data_ptr(), dx_in.data_ptr(), w_partials.data_ptr(), rows, R, abi_dtype(h.dtype), _stream())
+
+
+def causal_conv1d_dgrad(dy: torch.Tensor, w: torch.Tensor, dx: torch.Tensor, dilation: int = 1, shift: int = 0,
+                        accumulate: bool = False, scale: float = 1.0):
+    """dx[b,u,i] (+)= scale * sum_{k,o} w[k,i,o] * dy[b, u+shift+(K-1-k)*d, o] (adjoint of ops.py:6-10 + RightShift)."""
+    B, T, Cout = dy.shape
+    K, Cin, Co2 = w.shape
+    if Co2 != Cout:
+        raise ValueError("causal_conv1d_dgrad: w %s vs dy %s" % (tuple(w.shape), tuple(dy.shape)))
+    _chk(w, "w", torch.float32); _chk(dx, "dx", torch.float32, (B, T, Cin))
+    call("srwn_causal_conv1d_dgrad", _chk(dy, "dy"), w.data_ptr(), dx.data_ptr(), B, T, Cin, Cout, K, int(dilation),
+         int(shift), int(bool(accumulate)), float(scale), abi_dtype(dy.dtype), _stream())
+
+
+def mol_loss_dx(logits: torch.Tensor, x: torch.Tensor, M: int, loss_partials: torch.Tensor, dx: torch.Tensor,
+                grad_scale: float = 1.0):
+    rows = x.numel()
+    _chk(logits, "logits", torch.float32); _chk(x, "x", torch.float32); _chk(dx, "dx", torch.float32)
+    if logits.shape[0] != rows or dx.numel() != rows or loss_partials.numel() < (rows + 255) // 256:
+        raise ValueError("mol_loss_dx: shapes")
+    call("srwn_mol_loss_dx", logits.data_ptr(), logits.stride(0), x.data_ptr(), int(M),
+         _chk(loss_partials, "loss_partials", torch.float32), dx.data_ptr(), rows, float(grad_scale), _stream())
+
+
+def stft_frames(T: int) -> int:
+    return int(_lib.load().srwn_stft_frames(int(T)))
+
+
+def stft_power(x: torch.Tensor, spec: Optional[torch.Tensor], frame_power: torch.Tensor, power: torch.Tensor):
+    B, T = x.shape
+    nf = stft_frames(T)
+    _chk(x, "x", torch.float32); _chk(frame_power, "frame_power", torch.float32, (B, nf, 257))
+    _chk(power, "power", torch.float32, (B, 257))
+    ps = _opt(spec, "spec", torch.float32, (B, nf, 257, 2))
+    call("srwn_stft_power", x.data_ptr(), ps, frame_power.data_ptr(), power.data_ptr(), B, T, _stream())
+
+
+def power_loss(power_truth: torch.Tensor, power_out: torch.Tensor, gamma: float, grad_scale: float,
+               dpower: Optional[torch.Tensor], loss: torch.Tensor):
+    n = power_truth.numel()
+    _chk(power_truth, "power_truth", torch.float32); _chk(power_out, "power_out", torch.float32, power_truth.shape)
+    call("srwn_power_loss", power_truth.data_ptr(), power_out.data_ptr(), n, float(gamma), float(grad_scale),
+         _opt(dpower, "dpower", torch.float32, power_truth.shape), _chk(loss, "loss", torch.float32), _stream())
+
+
+def stft_power_bwd(spec: torch.Tensor, dpower: torch.Tensor, dx: torch.Tensor, accumulate: bool = False):
+    B, T = dx.shape
+    nf = stft_frames(T)
+    _chk(spec, "spec", torch.float32, (B, nf, 257, 2)); _chk(dpower, "dpower", torch.float32, (B, 257))
+    call("srwn_stft_power_bwd", spec.data_ptr(), dpower.data_ptr(), _chk(dx, "dx", torch.float32), B, T,
+         int(bool(accumulate)), _stream())
+
+
+def sumsq_partials(n: int) -> int:
+    return int(_lib.load().srwn_sumsq_partials(int(n)))
+
+
+def sumsq(g: torch.Tensor, partials: torch.Tensor):
+    _chk(g, "g", torch.float32)
+    if partials.numel() < sumsq_partials(g.numel()):
+        raise ValueError("sumsq: partials too small")
+    call("srwn_sumsq", g.data_ptr(), g.numel(), _chk(partials, "partials", torch.float32), _stream())
+
+
+def clip_scale(partials: torch.Tensor, clip_norm: float, pre_scale: float, out: torch.Tensor):
+    _chk(out, "out", torch.float32, (2,))
+    call("srwn_clip_scale", _chk(partials, "partials", torch.float32), partials.numel(), float(clip_norm),
+         float(pre_scale), out.data_ptr(), _stream())
+
+
+def adam_step_scaled(params: torch.Tensor, grads: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: torch.Tensor,
+                     lr: float, scale_dev: torch.Tensor, tick: bool, beta1: float = 0.9, beta2: float = 0.999,
+                     eps: float = 1e-8):
+    n = params.numel()
+    for t, nm in ((params, "params"), (grads, "grads"), (m, "m"), (v, "v")):
+        _chk(t, nm, torch.float32, (n,))
+    _chk(step, "step", torch.int64, (1,)); _chk(scale_dev, "scale_dev", torch.float32)
+    call("srwn_adam_step_scaled", params.data_ptr(), grads.data_ptr(), m.data_ptr(), v.data_ptr(), n, step.data_ptr(),
+         float(lr), float(beta1), float(beta2), float(eps), scale_dev.data_ptr(), int(bool(tick)), _stream())

@@ -1,6 +1,7 @@
 """CPU tests: the oracle against the reference's fixed self-check inputs, the
 closed-form mu-law values, the committed goldens, and oracle (i) vs oracle (ii)."""
 import json
+import math
 import os
 
 import numpy as np
@@ -196,3 +197,95 @@ def test_mol_loss_np_vs_torch_autograd():
     loss_t.backward()
     assert np.allclose(O.mol_dlogits(x, l), lt.grad.numpy(), rtol=1e-8, atol=1e-10)
     assert np.all(O.mol_dlogits(x, l)[..., 3 * M:] == 0)       # coeffs never reach the loss
+
+
+# --------------------------------------------------------------------------
+# Parallel-WaveNet student (model.py:290-537): oracle (i) == oracle (ii), closed forms, finite differences
+# --------------------------------------------------------------------------
+def _student_case(seed=0, B=2, T=1024, R=8, S=16, E=5, pool=64, F=3, M=4):
+    rng = np.random.default_rng(seed)
+    dil = [1, 2, 4]
+    flows = [O.init_flow_params(10 + i, dil, 2, R, S, E, bias_scale=0.1) for i in range(F)]
+    for p in flows:
+        p.head_w2 = p.head_w2 * 0.3
+    noise = rng.logistic(0, 1, (B, T)) * 0.15
+    cond = rng.standard_normal((B, T // pool, E))
+    truth = O.synthetic_audio(B, T, seed=seed + 1).astype(np.float64)
+    tl = rng.standard_normal((B, T, 4 * M)) * 0.5
+    return flows, noise, cond, truth, tl, pool
+
+
+def test_stft_power_closed_form_and_both_oracles():
+    """A pure tone at bin k has its power at bin k (Hann leaks into k-1, k+1 only); np.fft == DFT matrices."""
+    T = 2048
+    t = np.arange(T)
+    x = np.cos(2 * np.pi * 32 * t / 512)[None]
+    p = O.stft_power(x)
+    assert p.shape == (1, 257)
+    assert p[0].argmax() == 32 and p[0, 32] == pytest.approx((512 / 4) ** 2, rel=1e-9)
+    assert p[0, 31] == pytest.approx((512 / 8) ** 2, rel=1e-9) and p[0, 34:].max() < 1e-12
+    y = O.synthetic_audio(3, 1500, seed=2).astype(np.float64)
+    assert np.allclose(O.stft_power(y), OT.stft_power(torch.tensor(y)).numpy(), rtol=1e-9, atol=1e-12)
+    assert O.hann_periodic(512)[0] == 0 and O.hann_periodic(512)[256] == 1.0
+    with pytest.raises(ValueError):
+        O.stft_power(y[:, :500])
+
+
+def test_student_forward_np_vs_torch_and_chain_identity():
+    flows, noise, cond, truth, tl, pool = _student_case()
+    fw = O.student_forward(flows, noise, cond, pool)
+    # out = clip(z*s_tot + mu_tot) (model.py:535) is the clipped output of the flow chain
+    assert np.allclose(fw["out"], np.clip(fw["x_last"], -1, 1), rtol=1e-12, atol=1e-12)
+    ln = O.student_loss(fw, tl, truth, 0.7, 1.3, 0.01)
+    ts = [OT.TorchStack(p) for p in flows]
+    lt = OT.student_loss(ts, torch.tensor(noise), torch.tensor(cond), pool, torch.tensor(tl), torch.tensor(truth),
+                         0.7, 1.3, 0.01)
+    assert np.allclose(fw["out"], lt["out"].detach().numpy(), rtol=1e-10, atol=1e-12)
+    for k in ("loss", "power_loss", "entropy", "cross_entropy"):
+        assert float(lt[k].detach()) == pytest.approx(ln[k], rel=1e-7), k
+    # entropy = sum over flows of the log-scales + 2 per sample (model.py:356)
+    logs = sum(np.log(s).sum() for s in fw["scales"])
+    assert ln["entropy"] == pytest.approx(logs + 2.0 * noise.size, rel=1e-10)
+
+
+def test_student_autograd_vs_finite_differences():
+    flows, noise, cond, truth, tl, pool = _student_case(seed=3, T=768, F=2)
+    args = (0.9, 1.1, 0.02)
+
+    def loss_of(fl):
+        return O.student_loss(O.student_forward(fl, noise, cond, pool), tl, truth, *args)["loss"]
+
+    ts = [OT.TorchStack(p) for p in flows]
+    OT.student_loss(ts, torch.tensor(noise), torch.tensor(cond), pool, torch.tensor(tl), torch.tensor(truth),
+                    *args)["loss"].backward()
+    rng = np.random.default_rng(0)
+    for fi, attr, li in ((0, "init_w", None), (0, "wf", 1), (1, "wr", 0), (1, "wc", 2), (0, "head_w2", None),
+                         (1, "head_b2", None), (0, "bc", 0)):
+        holder = flows[fi] if li is None else flows[fi].layers[li]
+        arr = getattr(holder, attr)
+        idx = tuple(rng.integers(0, s) for s in arr.shape)
+        g = (getattr(ts[fi], attr) if li is None else ts[fi].layers[li][attr]).grad.numpy()[idx]
+        old = arr[idx]
+        h = 1e-5
+        arr[idx] = old + h; lp = loss_of(flows)
+        arr[idx] = old - h; lm = loss_of(flows)
+        arr[idx] = old
+        fd = (lp - lm) / (2 * h)
+        assert fd == pytest.approx(g, rel=2e-4, abs=1e-6), (fi, attr, li, fd, g)
+    # the skip 1x1s of a flow receive no gradient (model.py:440-449)
+    assert all(l["ws"].grad is None for st in ts for l in st.layers)
+
+
+def test_mol_dx_and_global_norm_clip():
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-1, 1, (2, 100)); l = rng.standard_normal((2, 100, 12))
+    xt = torch.tensor(x, requires_grad=True)
+    OT.mol_loss(xt, torch.tensor(l)).backward()
+    assert np.allclose(O.mol_dx(x, l), xt.grad.numpy(), rtol=1e-9, atol=1e-12)
+    gs = [rng.standard_normal((3, 4)), rng.standard_normal(7)]
+    c, gn = O.clip_by_global_norm(gs, 1.0)
+    assert gn == pytest.approx(math.sqrt(sum((g ** 2).sum() for g in gs)))
+    assert math.sqrt(sum((g ** 2).sum() for g in c)) == pytest.approx(1.0)
+    small = [g * 1e-3 for g in gs]
+    c2, _ = O.clip_by_global_norm(small, 1.0)
+    assert all(np.array_equal(a, b) for a, b in zip(c2, small))
