@@ -7,8 +7,10 @@ wrappers, but no TensorFlow: the graph body is the fixed kernel sequence of ``en
 * ``WaveNetTeacher``     -- the 30-layer mu-law softmax teacher BASELINE.json names (decoder stack of
                             model.py:158-196 with the 256-way softmax head the reference carries at
                             model.py:100-112); this is the benchmark path.
-* ``WaveNetAutoEncoder`` / ``ParallelWaveNet`` -- signatures kept; their mixture-of-logistics head,
-                            encoder and IAF flows are SURVEY §8(f) "next" rows and raise until built.
+* ``ParallelWaveNet``    -- model.py:290-656: the IAF student distilled against a frozen mixture-of-logistics
+                            teacher (student.StudentEngine); ``encode``/``reconstruct`` wait for the encoder.
+* ``WaveNetAutoEncoder`` -- signature kept; its encoder (ResidualDilationLayerNC) and mixture sampler are the
+                            next SURVEY §8(f) row and raise until built.
 """
 from __future__ import annotations
 
@@ -146,6 +148,12 @@ class WaveNetTeacher(_EngineOwner):
                  skip_channels=256, quantization_channels=256, latent_channels=16, pool_stride=512,
                  name="WaveNetTeacher", learning_rate=0.001, use_encoding=False, dtype=None, seed=0,
                  head="softmax", num_mixtures=5):
+        self._ctor = dict(input_size=int(input_size), condition_size=int(condition_size),
+                          dilations=[int(d) for d in dilations], filter_width=int(filter_width),
+                          dilation_channels=int(dilation_channels), skip_channels=int(skip_channels),
+                          quantization_channels=int(quantization_channels), latent_channels=int(latent_channels),
+                          pool_stride=int(pool_stride), name=name, learning_rate=float(learning_rate),
+                          use_encoding=bool(use_encoding), seed=int(seed), head=head, num_mixtures=int(num_mixtures))
         self.input_size = input_size
         self.condition_size = condition_size
         self.dilations = dilations
@@ -166,6 +174,27 @@ class WaveNetTeacher(_EngineOwner):
                                 head_mode="per_timestep" if head == "softmax" else "mol",
                                 dtype=dtype or _default_dtype(),
                                 learning_rate=learning_rate), seed)
+
+    def save(self, logdir, global_step, force=False):
+        """Checkpoint + ``config.json`` (the constructor arguments; the reference gets them from the meta graph
+        it imports at model.py:318)."""
+        done = super().save(logdir, global_step, force)
+        if done:
+            import json
+            with open(os.path.join(logdir, "config.json"), "w") as f:
+                json.dump(self._ctor, f)
+        return done
+
+    @classmethod
+    def from_checkpoint(cls, logdir, dtype=None):
+        import json
+        path = os.path.join(logdir, "config.json")
+        if not os.path.exists(path):
+            raise FileNotFoundError("%s: no config.json (save the teacher with WaveNetTeacher.save)" % logdir)
+        m = cls(dtype=dtype, **json.load(open(path)))
+        if not m.load(logdir):
+            raise FileNotFoundError("%s: no checkpoint to restore" % logdir)
+        return m
 
     def _stage(self, inputs, encoding=None, conditions=None):
         x = torch.as_tensor(np.asarray(inputs, dtype=np.float32), device="cuda")
@@ -228,13 +257,164 @@ class WaveNetAutoEncoder(object):
 
 
 class ParallelWaveNet(object):
-    """model.py:290-656.  Constructor signature kept; IAF flows + distillation losses are SURVEY §8(f)
-    rank 1 ("next"), not built yet."""
+    """model.py:290-656 on ``student.StudentEngine``: ``num_flows`` inverse-autoregressive flows distilled against a
+    frozen mixture-of-logistics teacher.
+
+    ``teacher`` is a ``WaveNetTeacher(head="mol", use_encoding=True)`` or a directory one was saved to (the
+    reference takes the checkpoint directory and imports its meta graph, model.py:313-324).  The ``sess`` argument of
+    every method is accepted for call compatibility with student.py and ignored (there is no session).
+    ``encode`` / ``reconstruct`` need the auto-encoder's encoder and mixture sampler (model.py:136-156; ops.py:178-201),
+    which are the next row to build; ``train`` (the per-sample-clipped slow path, model.py:603-632) is not built:
+    student.py:107 uses ``train_fast``."""
 
     def __init__(self, input_size, condition_size, dilations, teacher, num_flows=2, filter_width=2,
                  dilation_channels=32, skip_channels=256, latent_channels=16, pool_stride=512,
-                 name="ParallelWaveNet", alpha=1.0, beta=1.0, gamma=1.0, learning_rate=0.001):
-        raise NotImplementedError("ParallelWaveNet (student flows) is not built yet (SURVEY §8f rank 1)")
+                 name="ParallelWaveNet", alpha=1.0, beta=1.0, gamma=1.0, learning_rate=0.001, dtype=None, seed=0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("sr-wavenet_amd needs an MI355X (HIP) device; there is no CPU fallback")
+        self.input_size = input_size
+        self.condition_size = condition_size
+        self.dilations = dilations
+        self.teacher = teacher
+        self.num_flows = num_flows
+        self.filter_width = filter_width
+        self.dilation_channels = dilation_channels
+        self.skip_channels = skip_channels
+        self.latent_channels = latent_channels
+        self.pool_stride = pool_stride
+        self._name = name
+        self._abg = (float(alpha), float(beta), float(gamma))
+        self._lr, self._seed = learning_rate, seed
+        self._teacher_dir = None
+        if isinstance(teacher, (str, os.PathLike)):
+            self._teacher_dir = os.fspath(teacher)
+            self._teacher = WaveNetTeacher.from_checkpoint(self._teacher_dir, dtype=dtype)
+        else:
+            self._teacher = teacher
+        t = self._teacher
+        if not isinstance(t, WaveNetTeacher) or t.head != "mol" or not t.use_encoding:
+            raise ValueError("teacher must be a mixture-of-logistics WaveNetTeacher built with use_encoding=True")
+        if (t.latent_channels, t.condition_size, t.pool_stride) != (latent_channels, condition_size, pool_stride):
+            raise ValueError("student and teacher must agree on latent_channels, condition_size and pool_stride "
+                             "(they share the encoding placeholders, model.py:318-324)")
+        self._flow_cfg = StackConfig(dilations=list(dilations), filter_width=filter_width,
+                                     dilation_channels=dilation_channels, skip_channels=skip_channels,
+                                     cond_channels=latent_channels + condition_size, pool_stride=pool_stride,
+                                     dtype=dtype or t._cfg.dtype, learning_rate=learning_rate)
+        self._engines: Dict[tuple, object] = {}
+        self._primary = None
+        self.last_checkpoint_time = time.time()
+
+    # ------------------------------------------------------------------------------------------------
+    def _engine(self, B: int, T: int):
+        from .student import StudentEngine
+        key = (int(B), int(T))
+        eng = self._engines.get(key)
+        if eng is None:
+            if self._primary is not None:
+                raise NotImplementedError("ParallelWaveNet: one (batch, length) per model object for now; got %s "
+                                          "after %s" % (key, next(iter(self._engines))))
+            a, b, g = self._abg
+            eng = StudentEngine(self._teacher._engine(B, T), self._flow_cfg, self.num_flows, alpha=a, beta=b, gamma=g,
+                                learning_rate=self._lr, seed=self._seed)
+            self._primary = eng
+            self._engines[key] = eng
+        return eng
+
+    def _stage(self, inputs, truth, encoding, conditions):
+        z = torch.as_tensor(np.asarray(inputs, dtype=np.float32), device="cuda")
+        B, T = z.shape
+        eng = self._engine(B, T)
+        e = torch.as_tensor(np.asarray(encoding, dtype=np.float32), device="cuda")
+        if self.condition_size > 0:
+            if conditions is None:
+                raise ValueError("this student was built with condition_size > 0; pass conditions [B, condition_size]")
+            c = torch.as_tensor(np.asarray(conditions, dtype=np.float32), device="cuda")
+            e = torch.cat([e, c[:, None, :].expand(-1, e.shape[1], -1)], dim=2)          # model.py:496-499
+        if tuple(e.shape) != (B, T // self.pool_stride, self.latent_channels + self.condition_size):
+            raise ValueError("encoding must be [batch, samples/pool_stride, latent_channels]")
+        tr = None if truth is None else torch.as_tensor(np.asarray(truth, dtype=np.float32), device="cuda")
+        eng.set_inputs(z, tr, e.contiguous())
+        return eng
+
+    @property
+    def network_params(self):
+        if self._primary is None:
+            self._engine(1, self.input_size)
+        out = {}
+        for i, f in enumerate(self._primary.flows):
+            out.update(f.tf_variables("%s/Flow%d/Flow%d" % (self._name, i, i)))           # model.py:417,468,510
+        return out
+
+    # --- checkpointing (model.py:540-567) ---------------------------------------------------------------
+    def load(self, sess, logdir):
+        if self._teacher_dir is not None:
+            self._teacher.load(self._teacher_dir)                                         # model.py:543-544
+        if logdir is None or not os.path.exists(os.path.join(logdir, "checkpoint")):
+            return None
+        line = open(os.path.join(logdir, "checkpoint")).readline()
+        path = os.path.join(logdir, line.split('"')[1])
+        if not os.path.exists(path):
+            print("Could not find checkpoint at %s" % path)
+            return False
+        state = torch.load(path, weights_only=True)
+        for k, dst in self.network_params.items():
+            dst.copy_(state[k].to(dst.device).reshape(dst.shape))
+        for f in self._primary.flows:
+            f.repack()
+        print("Restoring previous session")
+        return True
+
+    def save(self, sess, logdir, global_step, force=False):
+        if force or time.time() - self.last_checkpoint_time > 60:
+            os.makedirs(logdir, exist_ok=True)
+            state = {k: v.detach().cpu().clone() for k, v in self.network_params.items()}
+            torch.save(state, os.path.join(logdir, "model.ckpt-%d.pt" % int(global_step)))
+            with open(os.path.join(logdir, "checkpoint"), "w") as f:
+                f.write('model_checkpoint_path: "model.ckpt-%d.pt"\n' % int(global_step))
+            self.last_checkpoint_time = time.time()
+            return True
+        return False
+
+    # --- graph outputs (model.py:570-597) ---------------------------------------------------------------
+    def generate(self, sess, inputs, encoding, conditions=None):
+        """noise [B,T] -> audio [B,T,1] in [-1,1] in ONE parallel pass (``self.out``, model.py:535)."""
+        eng = self._stage(inputs, None, encoding, conditions)
+        eng.forward_flows()
+        return eng.out.view(eng.B, eng.T, 1).cpu().numpy()
+
+    def getEntropy_fast(self, sess, inputs, encoding, conditions=None):
+        """sum(log s_tot + 2) over the batch (model.py:356)."""
+        eng = self._stage(inputs, None, encoding, conditions)
+        eng.forward_flows()
+        return np.float32(float(eng.logs.item()) + 2.0 * eng.N)
+
+    def getEntropy(self, sess, inputs, encoding, conditions=None):
+        """Per-sample entropies [B].  (The reference feeds one noise row against the whole batch of encodings,
+        model.py:584-590; here every row is paired with its own encoding.)"""
+        eng = self._stage(inputs, None, encoding, conditions)
+        eng.forward_flows()
+        logs = sum(f.prm[:, 0].view(eng.B, eng.T).sum(1) for f in eng.flows)
+        return (logs + 2.0 * eng.T).double().cpu().numpy()
+
+    def train_fast(self, sess, inputs, truth, encoding, conditions=None):
+        """One distillation step (model.py:634-642): returns (loss, power_loss)."""
+        eng = self._stage(inputs, truth, encoding, conditions)
+        eng.train_step()
+        l = eng.losses()
+        return np.float32(l["loss"]), np.float32(l["power_loss"])
+
+    def train(self, sess, inputs, truth, encoding, conditions=None):
+        raise NotImplementedError("ParallelWaveNet.train (per-sample clipping, model.py:603-632) is not built; "
+                                  "student.py:107 trains with train_fast")
+
+    def encode(self, sess, inputs, conditions=None):
+        raise NotImplementedError("ParallelWaveNet.encode runs the auto-encoder's encoder (model.py:136-156), "
+                                  "which is not built yet")
+
+    def reconstruct(self, sess, inputs, conditions=None):
+        raise NotImplementedError("ParallelWaveNet.reconstruct needs the auto-encoder's encoder and mixture sampler "
+                                  "(model.py:136-156; ops.py:178-201), which are not built yet")
 
 
 def smoke_check():

@@ -80,9 +80,58 @@ def test_teacher_with_encoding_and_conditions():
 def test_unbuilt_classes_say_so():
     M = sub("model")
     with pytest.raises(NotImplementedError):
-        M.ParallelWaveNet(4096, 0, [1, 2], "teachers/x")
-    with pytest.raises(NotImplementedError):
         M.WaveNetAutoEncoder(4096, 0, 5, [1, 2])
+
+
+def test_parallel_wavenet_student_api(tmp_path):
+    """student.py's calls on ParallelWaveNet (student.py:82-116): teacher from a checkpoint directory, train_fast,
+    generate, getEntropy[_fast], save/load; the flows' variables carry the reference's names."""
+    M = sub("model")
+    dil = [1, 2, 4, 8]
+    B, T, pool, lat, cs = 2, 1024, 64, 8, 4
+    teacher = M.WaveNetTeacher(T, cs, dil, dilation_channels=64, skip_channels=256, latent_channels=lat,
+                               pool_stride=pool, use_encoding=True, head="mol", num_mixtures=5, learning_rate=1e-3,
+                               dtype=torch.float32)
+    rng = np.random.default_rng(0)
+    x = O.synthetic_audio(B, T, seed=3)
+    enc = rng.standard_normal((B, T // pool, lat)).astype(np.float32)
+    y = np.eye(cs, dtype=np.float32)[[0, 2]]
+    for _ in range(3):
+        teacher.train(x, enc, y)
+    tdir = str(tmp_path / "teacher")
+    assert teacher.save(tdir, 3, force=True)
+    student = M.ParallelWaveNet(input_size=T, condition_size=cs, dilations=dil, teacher=tdir, dilation_channels=64,
+                                skip_channels=128, num_flows=2, latent_channels=lat, pool_stride=pool, alpha=1.0,
+                                beta=1.0, gamma=1e-3, learning_rate=1e-3, dtype=torch.float32)
+    assert student.load(None, str(tmp_path / "student")) is None
+    # the restored teacher gives the same logits as the one that was saved
+    assert np.array_equal(student._teacher.get_logits(x, enc, y), teacher.get_logits(x, enc, y))
+    noise = rng.logistic(0, 1, (B, T)).astype(np.float32)
+    out0 = student.generate(None, noise, enc, y)
+    assert out0.shape == (B, T, 1) and np.abs(out0).max() <= 1.0
+    ls = [student.train_fast(None, noise, x, enc, y) for _ in range(6)]
+    assert all(np.isfinite(l) and np.isfinite(p) for l, p in ls) and ls[-1][0] < ls[0][0]
+    ent = student.getEntropy(None, noise, enc, y)
+    assert ent.shape == (B,) and abs(ent.sum() - float(student.getEntropy_fast(None, noise, enc, y))) < 1e-2 * abs(ent.sum())
+    names = student.network_params
+    for k in ("ParallelWaveNet/Flow0/Flow0/causal_conv_Kernel", "ParallelWaveNet/Flow1/Flow1/conv1d_%d/kernel" % (3 * len(dil)),
+              "ParallelWaveNet/Flow1/Flow1/dilated_conv_2_gate/dilated_conv_2_Kernel", "ParallelWaveNet/Flow0/Flow0/conv1d_2/kernel"):
+        assert k in names, k
+    assert names["ParallelWaveNet/Flow1/Flow1/conv1d_%d/kernel" % (3 * len(dil))].shape == (1, 64, 2)
+    sdir = str(tmp_path / "student")
+    assert student.save(None, sdir, 6, force=True)
+    out1 = student.generate(None, noise, enc, y)
+    fresh = M.ParallelWaveNet(T, cs, dil, tdir, dilation_channels=64, skip_channels=128, num_flows=2,
+                              latent_channels=lat, pool_stride=pool, dtype=torch.float32, seed=99)
+    assert not np.array_equal(fresh.generate(None, noise, enc, y), out1)
+    assert fresh.load(None, sdir) is True
+    assert np.array_equal(fresh.generate(None, noise, enc, y), out1)
+    with pytest.raises(ValueError):
+        student.train_fast(None, noise, x, enc)          # conditions missing
+    with pytest.raises(NotImplementedError):
+        student.encode(None, x, y)
+    with pytest.raises(ValueError):
+        M.ParallelWaveNet(T, cs, dil, M.WaveNetTeacher(T, 0, dil, dilation_channels=64, skip_channels=256))
 
 
 def test_ops_surface(golden_dir):
