@@ -154,6 +154,10 @@ int srwn_reduce_partials(const float* partials, int32_t nslabs, int64_t n, int32
 /* ---- adjoint of ResizeEmbeddingNearestNeighbor (ops.py:64-74): out[b,e,c] = sum_{t in frame e} g[b,t,c] */
 int srwn_frame_sum(const void* g, void* out, int32_t B, int32_t T, int32_t C, int32_t frames, int32_t pool_stride,
                    int32_t dtype, void* stream);
+/* the same for `nbatch` layers in one launch: g + l*g_batch_stride -> out + l*out_batch_stride (elements) */
+int srwn_frame_sum_batched(const void* g, int64_t g_batch_stride, void* out, int64_t out_batch_stride, int32_t nbatch,
+                           int32_t B, int32_t T, int32_t C, int32_t frames, int32_t pool_stride, int32_t dtype,
+                           void* stream);
 
 /* ---- tf.train.AdamOptimizer update (model.py:31,117,382) on the flat fp32 parameter buffer:
  *   t = ++*step (device counter);  lr_t = lr*sqrt(1-b2^t)/(1-b1^t);  g = grads*grad_scale;

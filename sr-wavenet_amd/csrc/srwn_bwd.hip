@@ -572,12 +572,36 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partials, int n
   out[(int64_t)l * out_batch_stride + i] = (float)(s * (double)scale);
 }
 
+// few outputs, many slabs (bias / head gradients): 16 lanes share an output, each sums every 16th slab, then a
+// fixed xor-butterfly -- same result every run, 16x shorter dependent chain
+__global__ __launch_bounds__(256) void reduce_partials_wide_kernel(const float* __restrict__ partials, int nslabs,
+                                                                   int64_t n, int nbatch, int part_batch_mul,
+                                                                   float scale, float* __restrict__ out,
+                                                                   int64_t out_batch_stride) {
+  const int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int l = blockIdx.y, sub = threadIdx.x & 15;
+  double s = 0.0;
+  if (i < n) {
+    const float* p = partials + (int64_t)l * part_batch_mul * nslabs * n + i;
+    for (int k = sub; k < nslabs; k += 16) s += (double)p[(int64_t)k * n];
+  }
+#pragma unroll
+  for (int w = 8; w > 0; w >>= 1) s += __shfl_xor(s, w, 64);
+  if (i < n && sub == 0) out[(int64_t)l * out_batch_stride + i] = (float)(s * (double)scale);
+}
+
 extern "C" int srwn_reduce_partials(const float* partials, int32_t nslabs, int64_t n, int32_t nbatch,
                                     int32_t partials_batched, float scale, float* out, int64_t out_batch_stride,
                                     void* stream) {
   if (n == 0 || nbatch == 0) return 0;
   if (!partials || !out) return set_error(SRWN_E_NULL, "reduce_partials: null pointer");
   if (nslabs < 1 || n < 0 || nbatch < 0 || nbatch > 65535) return set_error(SRWN_E_SHAPE, "reduce_partials: nslabs=%d n=%lld nbatch=%d", nslabs, (long long)n, nbatch);
+  if (n <= 4096 && nslabs >= 32) {
+    dim3 grid((unsigned)((n + 15) / 16), (unsigned)nbatch), block(256);
+    hipLaunchKernelGGL(reduce_partials_wide_kernel, grid, block, 0, (hipStream_t)stream, partials, nslabs, n, nbatch,
+                       partials_batched ? 1 : 0, scale, out, out_batch_stride);
+    return check_launch("reduce_partials");
+  }
   dim3 grid((unsigned)((n + 255) / 256), (unsigned)nbatch), block(256);
   hipLaunchKernelGGL(reduce_partials_kernel, grid, block, 0, (hipStream_t)stream, partials, nslabs, n, nbatch,
                      partials_batched ? 1 : 0, scale, out, out_batch_stride);
@@ -585,34 +609,105 @@ extern "C" int srwn_reduce_partials(const float* partials, int32_t nslabs, int64
 }
 
 // sum of pool_stride consecutive time rows per frame: adjoint of the nearest-neighbour upsample
-// (ops.py:64-74) for the conditioning gradient: out[b,e,c] = sum_{t in frame e} g[b,t,c]
+// (ops.py:64-74) for the conditioning gradient: out[l][b,e,c] = sum_{t in frame e} g[l][b,t,c], batched over layers.
+// Block (frame, b, l): C/8 lanes per row (16 B each in bf16), 256/(C/8) rows per pass, fp32 partials through LDS.
+template <typename T> struct FsRow;
+template <> struct FsRow<bf16_t> {
+  static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
+    const bf16x8 r = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)r[j];
+  }
+};
+template <> struct FsRow<float> {
+  static __device__ __forceinline__ void load(const float* p, float (&v)[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
+  }
+};
+
+template <typename T, int C>
+__global__ __launch_bounds__(256) void frame_sum_kernel(const T* __restrict__ g, int64_t g_batch_stride,
+                                                        T* __restrict__ out, int64_t out_batch_stride, int Tlen,
+                                                        int frames, int pool) {
+  constexpr int LPR = C / 8, RPI = 256 / LPR;
+  __shared__ float red[256 * 8];
+  const int e = blockIdx.x, b = blockIdx.y, l = blockIdx.z;
+  const int sub = threadIdx.x % LPR, rloc = threadIdx.x / LPR;
+  const int t0 = e * pool;
+  const int t1 = min(t0 + pool, Tlen);
+  const T* src = g + (int64_t)l * g_batch_stride + (int64_t)b * Tlen * C + 8 * sub;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int t = t0 + rloc; t < t1; t += RPI) {
+    float v[8];
+    FsRow<T>::load(src + (int64_t)t * C, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += v[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[threadIdx.x * 8 + j] = acc[j];
+  __syncthreads();
+  if (threadIdx.x < C) {
+    const int c = threadIdx.x, sb = c >> 3, cj = c & 7;
+    float s = 0.0f;
+    for (int r = 0; r < RPI; ++r) s += red[(r * LPR + sb) * 8 + cj];
+    out[(int64_t)l * out_batch_stride + ((int64_t)b * frames + e) * C + c] = (T)s;
+  }
+}
+
 template <typename T>
-__global__ void frame_sum_kernel(const T* __restrict__ g, T* __restrict__ out, int B, int Tlen, int C, int frames,
-                                 int pool) {
+__global__ void frame_sum_generic_kernel(const T* __restrict__ g, int64_t g_batch_stride, T* __restrict__ out,
+                                         int64_t out_batch_stride, int B, int Tlen, int C, int frames, int pool) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t total = (int64_t)B * frames * C;
   if (i >= total) return;
+  const int l = blockIdx.y;
   const int c = (int)(i % C);
   const int64_t be = i / C;
   const int e = (int)(be % frames), b = (int)(be / frames);
   float s = 0.0f;
   const int t0 = e * pool;
-  for (int t = t0; t < t0 + pool && t < Tlen; ++t) s += (float)g[((int64_t)b * Tlen + t) * C + c];
-  out[i] = (T)s;
+  const T* src = g + (int64_t)l * g_batch_stride;
+  for (int t = t0; t < t0 + pool && t < Tlen; ++t) s += (float)src[((int64_t)b * Tlen + t) * C + c];
+  out[(int64_t)l * out_batch_stride + i] = (T)s;
+}
+
+template <typename T>
+static int launch_frame_sum(const void* g, int64_t gbs, void* out, int64_t obs, int nbatch, int B, int T_, int C,
+                            int frames, int pool, hipStream_t st) {
+  if (C == 64 || C == 32) {
+    dim3 grid(frames, B, nbatch), block(256);
+    if (C == 64)
+      hipLaunchKernelGGL((frame_sum_kernel<T, 64>), grid, block, 0, st, (const T*)g, gbs, (T*)out, obs, T_, frames, pool);
+    else
+      hipLaunchKernelGGL((frame_sum_kernel<T, 32>), grid, block, 0, st, (const T*)g, gbs, (T*)out, obs, T_, frames, pool);
+  } else {
+    const int64_t total = (int64_t)B * frames * C;
+    dim3 grid((unsigned)((total + 255) / 256), nbatch), block(256);
+    hipLaunchKernelGGL(frame_sum_generic_kernel<T>, grid, block, 0, st, (const T*)g, gbs, (T*)out, obs, B, T_, C,
+                       frames, pool);
+  }
+  return check_launch("frame_sum");
+}
+
+extern "C" int srwn_frame_sum_batched(const void* g, int64_t g_batch_stride, void* out, int64_t out_batch_stride,
+                                      int32_t nbatch, int32_t B, int32_t T, int32_t C, int32_t frames,
+                                      int32_t pool_stride, int32_t dtype, void* stream) {
+  if (B == 0 || frames == 0 || nbatch == 0) return 0;
+  if (!g || !out) return set_error(SRWN_E_NULL, "frame_sum: null pointer");
+  if (B < 0 || T < 1 || C < 1 || frames < 1 || pool_stride < 1 || nbatch < 0 || nbatch > 65535 || B > 65535)
+    return set_error(SRWN_E_SHAPE, "frame_sum: B=%d T=%d C=%d frames=%d pool=%d nbatch=%d", B, T, C, frames,
+                     pool_stride, nbatch);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SRWN_F32)
+    return launch_frame_sum<float>(g, g_batch_stride, out, out_batch_stride, nbatch, B, T, C, frames, pool_stride, st);
+  if (dtype == SRWN_BF16)
+    return launch_frame_sum<bf16_t>(g, g_batch_stride, out, out_batch_stride, nbatch, B, T, C, frames, pool_stride, st);
+  return set_error(SRWN_E_DTYPE, "frame_sum: dtype %d", dtype);
 }
 
 extern "C" int srwn_frame_sum(const void* g, void* out, int32_t B, int32_t T, int32_t C, int32_t frames,
                               int32_t pool_stride, int32_t dtype, void* stream) {
-  if (B == 0 || frames == 0) return 0;
-  if (!g || !out) return set_error(SRWN_E_NULL, "frame_sum: null pointer");
-  if (B < 0 || T < 1 || C < 1 || frames < 1 || pool_stride < 1) return set_error(SRWN_E_SHAPE, "frame_sum: shape");
-  const int64_t total = (int64_t)B * frames * C;
-  dim3 grid((unsigned)((total + 255) / 256)), block(256);
-  if (dtype == SRWN_F32)
-    hipLaunchKernelGGL(frame_sum_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)g, (float*)out, B, T, C, frames, pool_stride);
-  else if (dtype == SRWN_BF16)
-    hipLaunchKernelGGL(frame_sum_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)g, (bf16_t*)out, B, T, C, frames, pool_stride);
-  else
-    return set_error(SRWN_E_DTYPE, "frame_sum: dtype %d", dtype);
-  return check_launch("frame_sum");
+  return srwn_frame_sum_batched(g, 0, out, 0, 1, B, T, C, frames, pool_stride, dtype, stream);
 }

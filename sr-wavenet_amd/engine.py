@@ -646,10 +646,9 @@ class WaveNetEngine:
         if self.E:
             # conditioning 1x1 (model.py:180): dcb_l = adjoint of the NN upsample applied to G_l
             rows_c, Ep, E = B * self.frames, self.Ep, self.E
-            for l in range(L):
-                from ._lib import call
-                call("srwn_frame_sum", self.gs[l].data_ptr(), self.dcb[l].data_ptr(), B, T, R, self.frames,
-                     self.cfg.pool_stride, K.abi_dtype(dt), torch.cuda.current_stream().cuda_stream)
+            from ._lib import call
+            call("srwn_frame_sum_batched", self.gs.data_ptr(), B * T * R, self.dcb.data_ptr(), rows_c * R, L, B, T, R,
+                 self.frames, self.cfg.pool_stride, K.abi_dtype(dt), torch.cuda.current_stream().cuda_stream)
             K.wgrad(self.cond_in.data_ptr(), 0, Ep, self.dcb.data_ptr(), rows_c * R, R, None, L, self.wgc_parts,
                     self.wgc_bparts, rows_c, self.frames, self.nslabs_c, dt)
             if Ep == E:
