@@ -154,10 +154,11 @@ int srwn_reduce_partials(const float* partials, int32_t nslabs, int64_t n, int32
 /* ---- adjoint of ResizeEmbeddingNearestNeighbor (ops.py:64-74): out[b,e,c] = sum_{t in frame e} g[b,t,c] */
 int srwn_frame_sum(const void* g, void* out, int32_t B, int32_t T, int32_t C, int32_t frames, int32_t pool_stride,
                    int32_t dtype, void* stream);
-/* the same for `nbatch` layers in one launch: g + l*g_batch_stride -> out + l*out_batch_stride (elements) */
+/* the same for `nbatch` layers in one launch: g + l*g_batch_stride -> out + l*out_batch_stride (elements), times
+ * `scale` (1/pool_stride gives tf.nn.pool AVG, model.py:154) */
 int srwn_frame_sum_batched(const void* g, int64_t g_batch_stride, void* out, int64_t out_batch_stride, int32_t nbatch,
-                           int32_t B, int32_t T, int32_t C, int32_t frames, int32_t pool_stride, int32_t dtype,
-                           void* stream);
+                           int32_t B, int32_t T, int32_t C, int32_t frames, int32_t pool_stride, float scale,
+                           int32_t dtype, void* stream);
 
 /* ---- tf.train.AdamOptimizer update (model.py:31,117,382) on the flat fp32 parameter buffer:
  *   t = ++*step (device counter);  lr_t = lr*sqrt(1-b2^t)/(1-b1^t);  g = grads*grad_scale;
@@ -302,6 +303,40 @@ int srwn_clip_scale(const float* partials, int64_t n, float clip_norm, float pre
 int srwn_adam_step_scaled(float* params, const float* grads, float* m, float* v, int64_t n, int64_t* step, float lr,
                           float beta1, float beta2, float eps, const float* grad_scale_dev, int32_t tick,
                           void* stream);
+
+/* ---- WaveNetAutoEncoder pieces (model.py:75-285).  The encoder (createEncoder, model.py:136-156) is a chain of
+ * ResidualDilationLayerNC (ops.py:48-58): relu -> tf.layers.conv1d(K, SAME; the dilation argument is never passed
+ * on) -> relu, then 1x1 residual and 1x1 skip; skips summed, 1x1 to latent_channels, average-pooled.
+ *
+ * srwn_tap_linear: time-tap GEMM on MFMA for 128 or 256 output channels --
+ *   y[row][n] = epi( bias[n] + frame_add[clip*frames + t/pool_stride][n]*frame_add_scale
+ *                    + sum_{tap<ntaps} sum_i x[row + tap*tap_step][i] * W[tap*Cin + i][n] )
+ *   rows = clips*T; a tap that leaves its clip contributes 0 (SAME padding of the K=2 conv: tap_step=+1; its
+ *   data gradient: tap_step=-1 with the transposed kernel); wpack = MFMA image [cout/32][ntaps*Cin/16] (natural k);
+ *   epi = SRWN_EPI_NONE / _RELU / _MASK (aux > 0); frame_add (fp32, may be NULL) is the broadcast of a per-frame
+ *   term (the pooled skip path's gradient, the adjoint of tf.nn.pool AVG model.py:154). */
+int srwn_tap_linear(const void* x, int64_t x_row_stride, int32_t ntaps, int32_t tap_step, int32_t T, int32_t Cin,
+                    const void* wpack, const float* bias, void* y, int64_t y_row_stride, int32_t cout, int64_t rows,
+                    const void* aux, int64_t aux_row_stride, const float* frame_add, int64_t frame_add_ld,
+                    int32_t frames, int32_t pool_stride, float frame_add_scale, int32_t epi, int32_t dtype,
+                    void* stream);
+/* first encoder layer on the raw clip (model.py:141-142): a[b,t,c] = relu(bias[c] + sum_k w[k][c]*relu(x[b,t+k])) */
+int srwn_nc_input_fwd(const float* x, const float* w, const float* bias, void* a, int32_t B, int32_t T, int32_t C,
+                      int32_t K, int32_t dtype, void* stream);
+/* small products on the [B*frames] axis (latent 1x1 model.py:152, gradient wrt the encoding through model.py:180):
+ *   C[m][n] = (accumulate ? C : 0) + bias[n] + sum_k A(m,k)*B(k,n), chunked addressing on both operands:
+ *   A(m,k) = a[(k/a_chunk)*a_chunk_stride + m*lda + k%a_chunk];  B(k,n) = b[(k/b_chunk)*b_chunk_stride + (k%b_chunk)*ldb_k + n*ldb_n]
+ *   srwn_small_wgrad: c[k][n] = scale*sum_m a[m][k]*d[m][n], bias_out[n] = scale*sum_m d[m][n] (may be NULL) */
+int srwn_small_gemm(const void* a, int64_t lda, int32_t a_chunk, int64_t a_chunk_stride, int32_t a_dtype,
+                    const float* b, int64_t ldb_k, int64_t ldb_n, int32_t b_chunk, int64_t b_chunk_stride,
+                    const float* bias, void* c, int64_t ldc, int32_t c_dtype, int32_t M, int32_t N, int32_t K,
+                    int32_t accumulate, void* stream);
+int srwn_small_wgrad(const float* a, int64_t lda, const float* d, int64_t ldd, float* c, float* bias_out, int32_t M,
+                     int32_t K, int32_t N, float scale, void* stream);
+/* sample_from_discretized_mix_logistic (ops.py:178-201) given the uniform draws u1 [rows,M], u2 [rows] in
+ * (1e-5, 1-1e-5): Gumbel-max mixture choice, logistic sample, clip to [-1,1] -> out [rows] */
+int srwn_mol_sample(const float* logits, int64_t ldl, int32_t M, const float* u1, const float* u2, float* out,
+                    int64_t rows, void* stream);
 
 #ifdef __cplusplus
 }

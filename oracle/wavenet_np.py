@@ -642,3 +642,99 @@ def clip_by_global_norm(grads: Sequence[np.ndarray], clip_norm: float = 1.0):
     gn = math.sqrt(sum(float((g.astype(np.float64) ** 2).sum()) for g in grads))
     s = clip_norm / max(gn, clip_norm)
     return [g * s for g in grads], gn
+
+
+# --------------------------------------------------------------------------
+# WaveNetAutoEncoder (model.py:75-285): non-causal encoder + the conditioned decoder above + mixture sampler
+# --------------------------------------------------------------------------
+@dataclass
+class NCLayerParams:
+    w: np.ndarray    # [K,Cin,EC]  "<name>_NC/conv1d/kernel" (ops.py:51)
+    b: np.ndarray    # [EC]
+    wr: np.ndarray   # [EC,EC]     residual 1x1 (ops.py:54)
+    br: np.ndarray
+    ws: np.ndarray   # [EC,S]      skip 1x1 (ops.py:55)
+    bs: np.ndarray
+
+
+@dataclass
+class EncoderParams:
+    nc: NCLayerParams            # 'nc_conv' on the raw clip, Cin = 1; its skip output is discarded (model.py:141)
+    layers: List[NCLayerParams]
+    lat_w: np.ndarray            # [S, latent] (model.py:152)
+    lat_b: np.ndarray
+
+
+def init_encoder_params(seed: int, nlayers: int, K: int, EC: int, S: int, latent: int,
+                        bias_scale: float = 0.0) -> EncoderParams:
+    rng = np.random.default_rng(seed)
+    bias = lambda n: rng.normal(0, bias_scale, size=(n,)) if bias_scale else np.zeros((n,))
+
+    def layer(cin):
+        return NCLayerParams(xavier_uniform(rng, (K, cin, EC)), bias(EC), xavier_uniform(rng, (1, EC, EC))[0], bias(EC),
+                             xavier_uniform(rng, (1, EC, S))[0], bias(S))
+
+    return EncoderParams(layer(1), [layer(EC) for _ in range(nlayers)], xavier_uniform(rng, (1, S, latent))[0],
+                         bias(latent))
+
+
+def conv1d_same(x: np.ndarray, w: np.ndarray) -> np.ndarray:
+    """tf.layers.conv1d(strides=1, padding='SAME') (ops.py:51): cross-correlation with pad_left = (K-1)//2,
+    pad_right = K-1-pad_left -- for K = 2: y[t] = x[t] w[0] + x[t+1] w[1], zero beyond the clip."""
+    B, T, _ = x.shape
+    K = w.shape[0]
+    pl = (K - 1) // 2
+    y = np.zeros((B, T, w.shape[2]), dtype=np.result_type(x, w))
+    for k in range(K):
+        o = k - pl                      # y[t] += x[t+o] w[k]
+        lo, hi = max(0, -o), min(T, T - o)
+        if hi > lo:
+            y[:, lo:hi] += x[:, lo + o:hi + o] @ w[k]
+    return y
+
+
+def residual_dilation_layer_nc(x: np.ndarray, p: NCLayerParams):
+    """ops.py:48-58.  ``dilation_rate`` is accepted by the reference and never used.  Returns (residual, skip, a)."""
+    a = np.maximum(conv1d_same(np.maximum(x, 0), p.w) + p.b, 0)
+    return a @ p.wr + p.br, a @ p.ws + p.bs, a
+
+
+def encoder_forward(ep: EncoderParams, inputs: np.ndarray, pool_stride: int) -> np.ndarray:
+    """createEncoder (model.py:136-156): inputs [B,T] -> encoding [B, T//pool_stride, latent]."""
+    h, _, _ = residual_dilation_layer_nc(inputs[:, :, None], ep.nc)
+    total = None
+    for p in ep.layers:
+        h, skip, _ = residual_dilation_layer_nc(h, p)
+        total = skip if total is None else total + skip
+    reduced = total @ ep.lat_w + ep.lat_b                                        # model.py:152
+    B, T, C = reduced.shape
+    E = T // pool_stride
+    return reduced[:, :E * pool_stride].reshape(B, E, pool_stride, C).mean(2)    # tf.nn.pool AVG VALID, model.py:154
+
+
+def with_conditions(encoding: np.ndarray, conditions: Optional[np.ndarray]) -> np.ndarray:
+    """model.py:161-167: tile the clip-level condition over frames and concatenate."""
+    if conditions is None:
+        return encoding
+    c = np.repeat(conditions[:, None, :], encoding.shape[1], axis=1)
+    return np.concatenate([encoding, c], axis=2)
+
+
+def autoencoder_forward(ep: EncoderParams, dp_: StackParams, inputs: np.ndarray, pool_stride: int,
+                        conditions: Optional[np.ndarray] = None):
+    """createNetwork (model.py:203-216) + the loss (model.py:103,114): labels = inputs, decoder fed RightShift(inputs)."""
+    enc = encoder_forward(ep, inputs, pool_stride)
+    logits, _ = stack_forward(dp_, inputs, shift_input=True, cond=with_conditions(enc, conditions),
+                              pool_stride=pool_stride)
+    return dict(encoding=enc, logits=logits, loss=mol_loss(inputs, logits))
+
+
+def mol_sample(l: np.ndarray, u1: np.ndarray, u2: np.ndarray) -> np.ndarray:
+    """sample_from_discretized_mix_logistic (ops.py:178-201) with the two uniform draws given (the reference draws
+    them from U(1e-5, 1-1e-5)): l [B,T,4M], u1 [B,T,M], u2 [B,T] -> x [B,T] in [-1,1]."""
+    M = l.shape[-1] // 4
+    sel = np.argmax(l[..., :M] - np.log(-np.log(u1)), axis=-1)                   # ops.py:187
+    mean = np.take_along_axis(l[..., M:2 * M], sel[..., None], -1)[..., 0]
+    ls = np.maximum(np.take_along_axis(l[..., 2 * M:3 * M], sel[..., None], -1)[..., 0], -7.0)
+    x = mean + np.exp(ls) * (np.log(u2) - np.log(1.0 - u2))                      # ops.py:197
+    return np.minimum(np.maximum(x, -1.0), 1.0)

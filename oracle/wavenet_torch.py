@@ -249,3 +249,51 @@ def flow_named(st: TorchStack):
                 (f"l{i}.wc", l["wc"]), (f"l{i}.bc", l["bc"])]
     out += [("head_w2", st.head_w2), ("head_b2", st.head_b2)]
     return out
+
+
+# --------------------------------------------------------------------------
+# WaveNetAutoEncoder (model.py:75-285) with autograd
+# --------------------------------------------------------------------------
+class TorchEncoder:
+    def __init__(self, ep, dtype=torch.float64):
+        t = lambda a: torch.tensor(np.asarray(a), dtype=dtype, requires_grad=True)
+        lay = lambda p: dict(w=t(p.w), b=t(p.b), wr=t(p.wr), br=t(p.br), ws=t(p.ws), bs=t(p.bs))
+        self.nc = lay(ep.nc)
+        self.layers = [lay(p) for p in ep.layers]
+        self.lat_w, self.lat_b = t(ep.lat_w), t(ep.lat_b)
+
+    @staticmethod
+    def _nc(x_bct, p):
+        """ops.py:48-58 channels-first; SAME padding of a K-tap kernel = (K-1)//2 left, rest right."""
+        K = p["w"].shape[0]
+        pl = (K - 1) // 2
+        a = torch.relu(F.conv1d(F.pad(torch.relu(x_bct), (pl, K - 1 - pl)), p["w"].permute(2, 1, 0)) +
+                       p["b"][None, :, None])
+        res = torch.einsum("bct,cd->bdt", a, p["wr"]) + p["br"][None, :, None]
+        skip = torch.einsum("bct,cs->bst", a, p["ws"]) + p["bs"][None, :, None]
+        return res, skip
+
+    def forward(self, inputs: torch.Tensor, pool_stride: int) -> torch.Tensor:
+        h, _ = self._nc(inputs[:, None, :], self.nc)
+        total = None
+        for p in self.layers:
+            h, s = self._nc(h, p)
+            total = s if total is None else total + s
+        red = torch.einsum("bst,sl->btl", total, self.lat_w) + self.lat_b
+        B, T, C = red.shape
+        E = T // pool_stride
+        return red[:, :E * pool_stride].reshape(B, E, pool_stride, C).mean(2)
+
+    def named(self):
+        out = [("nc." + k, v) for k, v in self.nc.items()]
+        for i, p in enumerate(self.layers):
+            out += [(f"e{i}.{k}", v) for k, v in p.items()]
+        return out + [("lat_w", self.lat_w), ("lat_b", self.lat_b)]
+
+
+def autoencoder_loss(enc: TorchEncoder, dec: TorchStack, inputs: torch.Tensor, pool_stride: int,
+                     conditions: Optional[torch.Tensor] = None):
+    e = enc.forward(inputs, pool_stride)
+    cond = e if conditions is None else torch.cat([e, conditions[:, None, :].expand(-1, e.shape[1], -1)], dim=2)
+    logits = dec.forward(inputs, shift_input=True, cond=cond, pool_stride=pool_stride)
+    return mol_loss(inputs, logits), e, logits

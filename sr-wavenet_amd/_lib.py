@@ -42,7 +42,7 @@ SIGNATURES = {
                              _i32, _i32, _i32, _i32, _p]),
     "srwn_reduce_partials": (C.c_int, [_p, _i32, _i64, _i32, _i32, _f32, _p, _i64, _p]),
     "srwn_frame_sum": (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
-    "srwn_frame_sum_batched": (C.c_int, [_p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    "srwn_frame_sum_batched": (C.c_int, [_p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _p]),
     "srwn_adam_step": (C.c_int, [_p, _p, _p, _p, _i64, _p, _f32, _f32, _f32, _f32, _f32, _p]),
     "srwn_time_mean_slabs": (_i32, [_i32]),
     "srwn_time_mean": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _i32, _p]),
@@ -57,6 +57,13 @@ SIGNATURES = {
     "srwn_mol_loss": (C.c_int, [_p, _i64, _p, _i32, _p, _p, _i64, _i64, _f32, _i32, _p]),
     "srwn_wgrad256_slabs": (_i32, [_i64, _i32]),
     "srwn_wgrad256": (C.c_int, [_p, _i64, _i64, _i32, _p, _i64, _p, _p, _i64, _i32, _i32, _i32, _p]),
+    "srwn_tap_linear": (C.c_int, [_p, _i64, _i32, _i32, _i32, _i32, _p, _p, _p, _i64, _i32, _i64, _p, _i64, _p, _i64,
+                                  _i32, _i32, _f32, _i32, _i32, _p]),
+    "srwn_nc_input_fwd": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
+    "srwn_small_gemm": (C.c_int, [_p, _i64, _i32, _i64, _i32, _p, _i64, _i64, _i32, _i64, _p, _p, _i64, _i32, _i32,
+                                  _i32, _i32, _i32, _p]),
+    "srwn_small_wgrad": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _i32, _i32, _i32, _f32, _p]),
+    "srwn_mol_sample": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _i64, _p]),
     "srwn_mol_loss_dx": (C.c_int, [_p, _i64, _p, _i32, _p, _p, _i64, _f32, _p]),
     "srwn_clamp": (C.c_int, [_p, _p, _i64, _f32, _f32, _p]),
     "srwn_clamp_bwd": (C.c_int, [_p, _p, _p, _i64, _f32, _f32, _p]),

@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsrwn.so")
-SOURCES = ["srwn_util.hip", "srwn_fwd.hip", "srwn_bwd.hip", "srwn_opt.hip", "srwn_pool.hip", "srwn_gemm.hip", "srwn_wgrad2.hip", "srwn_gen.hip", "srwn_flow.hip"]
+SOURCES = ["srwn_util.hip", "srwn_fwd.hip", "srwn_bwd.hip", "srwn_opt.hip", "srwn_pool.hip", "srwn_gemm.hip", "srwn_wgrad2.hip", "srwn_gen.hip", "srwn_flow.hip", "srwn_enc.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-pass-failed", "-ffp-contract=on"]
 

@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
       const int rr = idx / (BM / VEC), cv = (idx % (BM / VEC)) * VEC;
       const int64_t row = r0 + rr;
       const int t = (int)(row % a.Tlen);
-      const bool valid = (row < r_end) && (t - shift >= 0) && (ci0 + cv < a.cin);
+      const bool valid = (row < r_end) && (t - shift >= 0) && (t - shift < a.Tlen) && (ci0 + cv < a.cin);
       float v[VEC];
       if (valid) {
         const T* p = in + (row - shift) * a.cin + ci0 + cv;
@@ -543,7 +543,7 @@ extern "C" int srwn_wgrad(const void* in, int64_t in_batch_stride, int32_t cin, 
   a.rows_per_slab = (int)rps;
   for (int i = 0; i < kWgMaxBatch; ++i) a.shifts[i] = (shifts && i < nbatch) ? shifts[i] : 0;
   for (int i = 0; i < nbatch; ++i)
-    if (a.shifts[i] < 0) return set_error(SRWN_E_SHAPE, "wgrad: negative shift");
+    if (a.shifts[i] <= -T || a.shifts[i] >= T) return set_error(SRWN_E_SHAPE, "wgrad: shift %d outside (-T, T)", a.shifts[i]);
   hipStream_t st = (hipStream_t)stream;
   const bool big = (cin % 64 == 0) && (cout % 256 == 0);
   const bool mid = (cin % 64 == 0) && (cout % 64 == 0);
@@ -630,7 +630,7 @@ template <> struct FsRow<float> {
 template <typename T, int C>
 __global__ __launch_bounds__(256) void frame_sum_kernel(const T* __restrict__ g, int64_t g_batch_stride,
                                                         T* __restrict__ out, int64_t out_batch_stride, int Tlen,
-                                                        int frames, int pool) {
+                                                        int frames, int pool, float scale) {
   constexpr int LPR = C / 8, RPI = 256 / LPR;
   __shared__ float red[256 * 8];
   const int e = blockIdx.x, b = blockIdx.y, l = blockIdx.z;
@@ -652,13 +652,14 @@ __global__ __launch_bounds__(256) void frame_sum_kernel(const T* __restrict__ g,
     const int c = threadIdx.x, sb = c >> 3, cj = c & 7;
     float s = 0.0f;
     for (int r = 0; r < RPI; ++r) s += red[(r * LPR + sb) * 8 + cj];
-    out[(int64_t)l * out_batch_stride + ((int64_t)b * frames + e) * C + c] = (T)s;
+    out[(int64_t)l * out_batch_stride + ((int64_t)b * frames + e) * C + c] = (T)(s * scale);
   }
 }
 
 template <typename T>
 __global__ void frame_sum_generic_kernel(const T* __restrict__ g, int64_t g_batch_stride, T* __restrict__ out,
-                                         int64_t out_batch_stride, int B, int Tlen, int C, int frames, int pool) {
+                                         int64_t out_batch_stride, int B, int Tlen, int C, int frames, int pool,
+                                         float scale) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t total = (int64_t)B * frames * C;
   if (i >= total) return;
@@ -670,30 +671,30 @@ __global__ void frame_sum_generic_kernel(const T* __restrict__ g, int64_t g_batc
   const int t0 = e * pool;
   const T* src = g + (int64_t)l * g_batch_stride;
   for (int t = t0; t < t0 + pool && t < Tlen; ++t) s += (float)src[((int64_t)b * Tlen + t) * C + c];
-  out[(int64_t)l * out_batch_stride + i] = (T)s;
+  out[(int64_t)l * out_batch_stride + i] = (T)(s * scale);
 }
 
 template <typename T>
 static int launch_frame_sum(const void* g, int64_t gbs, void* out, int64_t obs, int nbatch, int B, int T_, int C,
-                            int frames, int pool, hipStream_t st) {
+                            int frames, int pool, float scale, hipStream_t st) {
   if (C == 64 || C == 32) {
     dim3 grid(frames, B, nbatch), block(256);
     if (C == 64)
-      hipLaunchKernelGGL((frame_sum_kernel<T, 64>), grid, block, 0, st, (const T*)g, gbs, (T*)out, obs, T_, frames, pool);
+      hipLaunchKernelGGL((frame_sum_kernel<T, 64>), grid, block, 0, st, (const T*)g, gbs, (T*)out, obs, T_, frames, pool, scale);
     else
-      hipLaunchKernelGGL((frame_sum_kernel<T, 32>), grid, block, 0, st, (const T*)g, gbs, (T*)out, obs, T_, frames, pool);
+      hipLaunchKernelGGL((frame_sum_kernel<T, 32>), grid, block, 0, st, (const T*)g, gbs, (T*)out, obs, T_, frames, pool, scale);
   } else {
     const int64_t total = (int64_t)B * frames * C;
     dim3 grid((unsigned)((total + 255) / 256), nbatch), block(256);
     hipLaunchKernelGGL(frame_sum_generic_kernel<T>, grid, block, 0, st, (const T*)g, gbs, (T*)out, obs, B, T_, C,
-                       frames, pool);
+                       frames, pool, scale);
   }
   return check_launch("frame_sum");
 }
 
 extern "C" int srwn_frame_sum_batched(const void* g, int64_t g_batch_stride, void* out, int64_t out_batch_stride,
                                       int32_t nbatch, int32_t B, int32_t T, int32_t C, int32_t frames,
-                                      int32_t pool_stride, int32_t dtype, void* stream) {
+                                      int32_t pool_stride, float scale, int32_t dtype, void* stream) {
   if (B == 0 || frames == 0 || nbatch == 0) return 0;
   if (!g || !out) return set_error(SRWN_E_NULL, "frame_sum: null pointer");
   if (B < 0 || T < 1 || C < 1 || frames < 1 || pool_stride < 1 || nbatch < 0 || nbatch > 65535 || B > 65535)
@@ -701,13 +702,13 @@ extern "C" int srwn_frame_sum_batched(const void* g, int64_t g_batch_stride, voi
                      pool_stride, nbatch);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == SRWN_F32)
-    return launch_frame_sum<float>(g, g_batch_stride, out, out_batch_stride, nbatch, B, T, C, frames, pool_stride, st);
+    return launch_frame_sum<float>(g, g_batch_stride, out, out_batch_stride, nbatch, B, T, C, frames, pool_stride, scale, st);
   if (dtype == SRWN_BF16)
-    return launch_frame_sum<bf16_t>(g, g_batch_stride, out, out_batch_stride, nbatch, B, T, C, frames, pool_stride, st);
+    return launch_frame_sum<bf16_t>(g, g_batch_stride, out, out_batch_stride, nbatch, B, T, C, frames, pool_stride, scale, st);
   return set_error(SRWN_E_DTYPE, "frame_sum: dtype %d", dtype);
 }
 
 extern "C" int srwn_frame_sum(const void* g, void* out, int32_t B, int32_t T, int32_t C, int32_t frames,
                               int32_t pool_stride, int32_t dtype, void* stream) {
-  return srwn_frame_sum_batched(g, 0, out, 0, 1, B, T, C, frames, pool_stride, dtype, stream);
+  return srwn_frame_sum_batched(g, 0, out, 0, 1, B, T, C, frames, pool_stride, 1.0f, dtype, stream);
 }

@@ -24,6 +24,9 @@ struct RgArgs {
   const void* aux; int64_t aux_row_stride;
   // softmax-CE epilogue
   const int32_t* targets; float* loss_partials; float* logits_out; float grad_scale;
+  // TAPS: k-chunk c is time tap c -> row + c*tap_step inside the same clip of tap_T rows (zero outside);
+  // frame_add (fp32 [clips*frames, frame_add_ld]) * frame_add_scale is added per row before the epilogue
+  int tap_T; int tap_step; const float* frame_add; int64_t frame_add_ld; int frames; int pool; float frame_add_scale;
 };
 
 template <typename T> __device__ __forceinline__ void glds16(const void* g, void* l) {
@@ -31,7 +34,7 @@ template <typename T> __device__ __forceinline__ void glds16(const void* g, void
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-template <typename T, int MT, int KSC, int PRO, int EPI, int NT>
+template <typename T, int MT, int KSC, int PRO, int EPI, int NT, bool TAPS = false>
 __global__ __launch_bounds__(256, (EPI == SRWN_EPI_SOFTMAX_CE || NT == 2) ? 1 : 2) void rowgemm_kernel(RgArgs a) {
   static_assert(MT % 2 == 0, "outputs are emitted in 64-channel groups");
   static_assert(EPI != SRWN_EPI_SOFTMAX_CE || NT == 1, "softmax epilogue holds one column tile");
@@ -47,10 +50,12 @@ __global__ __launch_bounds__(256, (EPI == SRWN_EPI_SOFTMAX_CE || NT == 2) ? 1 : 
   const int64_t tile0 = ((int64_t)blockIdx.x * 4 + wave) * NT;   // first 32-row tile of this wave
   int64_t rowv[NT];
   bool valid[NT];
+  int tclip[NT];   // (TAPS) time index of the row inside its clip
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     rowv[nt] = (tile0 + nt) * 32 + col;
     valid[nt] = rowv[nt] < a.rows;
+    tclip[nt] = TAPS ? (int)((valid[nt] ? rowv[nt] : (a.rows - 1)) % a.tap_T) : 0;
   }
   const int nchunks = a.ks_total / KSC;
   const char* wbase = reinterpret_cast<const char*>(a.wpack);
@@ -67,16 +72,26 @@ __global__ __launch_bounds__(256, (EPI == SRWN_EPI_SOFTMAX_CE || NT == 2) ? 1 : 
     }
   };
   // unconditional (clamped) activation loads; rows beyond the end produce values that are never stored
-  auto load_b = [&](int c, Frag<T> (&dst)[NT][KSC]) {
+  auto load_b = [&](int c, Frag<T> (&dst)[NT][KSC], bool (&ok)[NT][KSC]) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int ks = 0; ks < KSC; ++ks) {
         const int kg = 16 * (c * KSC + ks);
         const int chunk = kg / a.chunk_len, within = kg - chunk * a.chunk_len;
-        const T* p = reinterpret_cast<const T*>(a.x) + (int64_t)chunk * a.x_chunk_stride +
-                     (valid[nt] ? rowv[nt] : (a.rows - 1)) * a.x_row_stride + within + 8 * half;
-        dst[nt][ks] = load_nat(p);
+        const int64_t rbase = valid[nt] ? rowv[nt] : (a.rows - 1);
+        if (TAPS) {
+          const int tp = tclip[nt] + chunk * a.tap_step;
+          ok[nt][ks] = tp >= 0 && tp < a.tap_T;
+          const T* p = reinterpret_cast<const T*>(a.x) + (rbase + (ok[nt][ks] ? chunk * a.tap_step : 0)) * a.x_row_stride +
+                       within + 8 * half;
+          dst[nt][ks] = load_nat(p);
+        } else {
+          ok[nt][ks] = true;
+          const T* p = reinterpret_cast<const T*>(a.x) + (int64_t)chunk * a.x_chunk_stride + rbase * a.x_row_stride +
+                       within + 8 * half;
+          dst[nt][ks] = load_nat(p);
+        }
       }
   };
 
@@ -92,8 +107,9 @@ __global__ __launch_bounds__(256, (EPI == SRWN_EPI_SOFTMAX_CE || NT == 2) ? 1 : 
     }
 
   Frag<T> bcur[NT][KSC], bnext[NT][KSC];
+  bool oknext[NT][KSC];
   stage(0, 0);
-  load_b(0, bnext);
+  load_b(0, bnext, oknext);
   __syncthreads();   // (drains the glds: vmcnt(0) + barrier)
   for (int c = 0; c < nchunks; ++c) {
 #pragma unroll
@@ -101,6 +117,7 @@ __global__ __launch_bounds__(256, (EPI == SRWN_EPI_SOFTMAX_CE || NT == 2) ? 1 : 
 #pragma unroll
       for (int ks = 0; ks < KSC; ++ks) {
         bcur[nt][ks] = bnext[nt][ks];   // rows past the end are clamped re-reads: computed, never stored
+        if (TAPS) bcur[nt][ks] = oknext[nt][ks] ? bcur[nt][ks] : zero_frag<T>();   // taps outside the clip
         if (PRO == SRWN_PRO_GATE) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) bcur[nt][ks].set(j, gate_of_z<T>(bcur[nt][ks].get(j)));
@@ -109,7 +126,7 @@ __global__ __launch_bounds__(256, (EPI == SRWN_EPI_SOFTMAX_CE || NT == 2) ? 1 : 
     {
       const int cn = (c + 1 < nchunks) ? c + 1 : c;   // (last iteration re-fetches chunk c: harmless, keeps counts fixed)
       if (c + 1 < nchunks) stage(cn, (c + 1) & 1);
-      load_b(cn, bnext);
+      load_b(cn, bnext, oknext);
     }
     const Frag<T>* lw = reinterpret_cast<const Frag<T>*>(smem + (c & 1) * CHUNK_B) + lane;
 #pragma unroll
@@ -194,6 +211,11 @@ __global__ __launch_bounds__(256, (EPI == SRWN_EPI_SOFTMAX_CE || NT == 2) ? 1 : 
     const T* arow = (EPI == SRWN_EPI_MASK)
                         ? reinterpret_cast<const T*>(a.aux) + (valid[nt] ? rowv[nt] : 0) * a.aux_row_stride
                         : nullptr;
+    const float* frow = nullptr;
+    if (TAPS && a.frame_add) {
+      const int64_t rr = valid[nt] ? rowv[nt] : 0;
+      frow = a.frame_add + ((rr / a.tap_T) * a.frames + (tclip[nt] / a.pool)) * a.frame_add_ld;
+    }
 #pragma unroll
     for (int j = 0; j < MT / 2; ++j) {
       if (64 * j >= a.cout_valid) continue;   // cout_valid is a multiple of 64 on this path (host check)
@@ -204,9 +226,12 @@ __global__ __launch_bounds__(256, (EPI == SRWN_EPI_SOFTMAX_CE || NT == 2) ? 1 : 
         for (int g = 0; g < 4; ++g) {
           f32x4 mk = {1.f, 1.f, 1.f, 1.f};
           if (EPI == SRWN_EPI_MASK) mk = load4(arow + 32 * (2 * j + m2) + 8 * g + 4 * half);
+          f32x4 fa = {0.f, 0.f, 0.f, 0.f};
+          if (TAPS && frow) fa = *reinterpret_cast<const f32x4*>(frow + 32 * (2 * j + m2) + 8 * g + 4 * half);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float x = acc[2 * j + m2][nt][4 * g + e];
+            if (TAPS) x = fmaf(fa[e], a.frame_add_scale, x);
             if (EPI == SRWN_EPI_RELU) x = fmaxf(x, 0.0f);
             if (EPI == SRWN_EPI_MASK) x = (mk[e] > 0.0f) ? x : 0.0f;
             v[m2][4 * g + e] = x;
@@ -347,6 +372,30 @@ static int launch_rg(const RgArgs& a, int pro, int epi, hipStream_t st) {
   return set_error(SRWN_E_UNSUPPORTED, "rowgemm: pro %d / epi %d combination not built", pro, epi);
 }
 
+template <typename T, int MT, int KSC>
+static int launch_rg_taps(const RgArgs& a, int epi, hipStream_t st) {
+  constexpr int CHUNK_B = MT * KSC * (int)sizeof(Frag<T>) * 64;
+  // the weight double buffer is reused as 4 private row stages in the epilogue: take the larger of the two
+  const size_t stage_b = (size_t)4 * 32 * RowStage<T>::stride(64) * sizeof(T);
+  const size_t sh = 2 * (size_t)CHUNK_B > stage_b ? 2 * (size_t)CHUNK_B : stage_b;
+  dim3 grid((unsigned)((a.rows + 127) / 128)), block(256);
+#define SRWN_RGT(E)                                                                                          \
+  if (epi == E) {                                                                                            \
+    auto kfn = rowgemm_kernel<T, MT, KSC, SRWN_PRO_NONE, E, 1, true>;                                        \
+    if (sh > 32768) {                                                                                        \
+      hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+      if (e != hipSuccess) return set_error((int)e, "tap_linear: LDS %zu: %s", sh, hipGetErrorString(e));    \
+    }                                                                                                        \
+    hipLaunchKernelGGL(kfn, grid, block, sh, st, a);                                                         \
+    return check_launch("tap_linear");                                                                       \
+  }
+  SRWN_RGT(SRWN_EPI_NONE)
+  SRWN_RGT(SRWN_EPI_RELU)
+  SRWN_RGT(SRWN_EPI_MASK)
+#undef SRWN_RGT
+  return set_error(SRWN_E_UNSUPPORTED, "tap_linear: epilogue %d not built", epi);
+}
+
 // Returns 1 if the shape is served by the row-streaming kernel (then *rc holds the launch result).
 int rowgemm_dispatch(const void* x, int64_t x_row_stride, int64_t x_chunk_stride, int chunk_len, int Cin,
                      const void* wpack, const float* bias, void* y, int64_t y_row_stride, int cout_pad,
@@ -356,7 +405,7 @@ int rowgemm_dispatch(const void* x, int64_t x_row_stride, int64_t x_chunk_stride
   if (cout_pad != 256 || (Cin % 64) != 0 || rows < 1) return 0;
   if (epi != SRWN_EPI_SOFTMAX_CE && (cout_valid % 64) != 0) return 0;
   RgArgs a{x, x_row_stride, x_chunk_stride, chunk_len, Cin / 16, wpack, bias, y, y_row_stride, cout_valid, rows,
-           aux, aux_row_stride, targets, loss_partials, logits_out, grad_scale};
+           aux, aux_row_stride, targets, loss_partials, logits_out, grad_scale, 0, 0, nullptr, 0, 0, 1, 0.0f};
   static const int nt_bf16 = [] { const char* e = getenv("SRWN_RG_NT"); return (e && atoi(e) == 2) ? 2 : 1; }();
   if (dtype == SRWN_BF16) *rc = (nt_bf16 == 2) ? launch_rg<bf16_t, 8, 4, 2>(a, pro, epi, st) : launch_rg<bf16_t, 8, 4, 1>(a, pro, epi, st);
   else if (dtype == SRWN_F32) *rc = launch_rg<float, 8, 2, 1>(a, pro, epi, st);
@@ -365,3 +414,29 @@ int rowgemm_dispatch(const void* x, int64_t x_row_stride, int64_t x_chunk_stride
 }
 
 }  // namespace srwn
+
+// ------------------------------------------------------------------------------------------
+// time-tap GEMM (the non-causal K=2 convolutions of ResidualDilationLayerNC, ops.py:48-58, their data
+// gradients, and the 1x1s around them), 128 or 256 output channels:
+//   y[row][n] = epi( bias[n] + frame_add[clip*frames + t/pool][n]*scale
+//                    + sum_tap sum_i x[row + tap*tap_step][i] * W[tap*Cin + i][n] ),   taps outside the clip = 0
+// ------------------------------------------------------------------------------------------
+extern "C" int srwn_tap_linear(const void* x, int64_t x_row_stride, int32_t ntaps, int32_t tap_step, int32_t T,
+                               int32_t Cin, const void* wpack, const float* bias, void* y, int64_t y_row_stride,
+                               int32_t cout, int64_t rows, const void* aux, int64_t aux_row_stride,
+                               const float* frame_add, int64_t frame_add_ld, int32_t frames, int32_t pool_stride,
+                               float frame_add_scale, int32_t epi, int32_t dtype, void* stream) {
+  if (rows == 0) return 0;
+  if (!x || !wpack || !y) return set_error(SRWN_E_NULL, "tap_linear: null pointer");
+  if (epi == SRWN_EPI_MASK && !aux) return set_error(SRWN_E_NULL, "tap_linear: EPI_MASK needs aux");
+  if (rows < 0 || T < 1 || rows % T || ntaps < 1 || Cin < 64 || Cin % 64 || (cout != 128 && cout != 256) ||
+      (frame_add && (frames < 1 || pool_stride < 1 || (int64_t)frames * pool_stride < T || frame_add_ld < cout)))
+    return set_error(SRWN_E_SHAPE, "tap_linear: rows=%lld T=%d taps=%d Cin=%d cout=%d frames=%d pool=%d",
+                     (long long)rows, T, ntaps, Cin, cout, frames, pool_stride);
+  RgArgs a{x, x_row_stride, 0, Cin, ntaps * Cin / 16, wpack, bias, y, y_row_stride, cout, rows, aux, aux_row_stride,
+           nullptr, nullptr, nullptr, 0.0f, T, tap_step, frame_add, frame_add_ld, frames, pool_stride, frame_add_scale};
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SRWN_BF16) return cout == 128 ? launch_rg_taps<bf16_t, 4, 4>(a, epi, st) : launch_rg_taps<bf16_t, 8, 4>(a, epi, st);
+  if (dtype == SRWN_F32) return cout == 128 ? launch_rg_taps<float, 4, 2>(a, epi, st) : launch_rg_taps<float, 8, 2>(a, epi, st);
+  return set_error(SRWN_E_DTYPE, "tap_linear: dtype %d", dtype);
+}

@@ -157,7 +157,7 @@ __global__ void causal_conv_kernel(const float* __restrict__ x, const float* __r
   for (int q = 0; q < 4; ++q) acc[q] = (bias && o0 + q < Cout) ? bias[o0 + q] : 0.0f;
   for (int k = 0; k < K; ++k) {
     int tk = t - (K - 1 - k) * dilation - shift;
-    if (tk < 0) continue;
+    if (tk < 0 || tk >= T) continue;
     const float* xr = x + ((int64_t)b * T + tk) * Cin;
     const float* wk = w + (int64_t)k * Cin * Cout;
     for (int ci = 0; ci < Cin; ++ci) {
@@ -178,7 +178,7 @@ extern "C" int srwn_causal_conv1d_fwd(const float* x, const float* w, const floa
                                       int32_t shift, int32_t dtype_out, void* stream) {
   if (B == 0 || T == 0) return 0;
   if (!x || !w || !y) return set_error(SRWN_E_NULL, "causal_conv1d_fwd: null pointer");
-  if (B < 0 || T < 0 || Cin < 1 || Cout < 1 || K < 1 || dilation < 1 || shift < 0)
+  if (B < 0 || T < 0 || Cin < 1 || Cout < 1 || K < 1 || dilation < 1 || shift <= -T || shift >= T)
     return set_error(SRWN_E_SHAPE, "causal_conv1d_fwd: B=%d T=%d Cin=%d Cout=%d K=%d d=%d shift=%d", B, T, Cin, Cout,
                      K, dilation, shift);
   int64_t total = (int64_t)B * T * ((Cout + 3) / 4);
@@ -236,8 +236,8 @@ __global__ __launch_bounds__(256) void init_conv_wgrad_stage1(const float* __res
       if (k > K) break;
       float xv = 1.0f;                       // k == K: bias gradient (sum of g)
       if (k < K) {
-        const int tk = t - (K - 1 - k) - shift;
-        xv = (tk >= 0) ? audio[row - t + tk] : 0.0f;
+        const int tk = t - (K - 1 - k) - shift;   // shift < 0: taps ahead of t (the non-causal encoder input conv)
+        xv = (tk >= 0 && tk < Tlen) ? audio[row - t + tk] : 0.0f;
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[k][e] = fmaf(xv, gv[e], acc[k][e]);

@@ -648,7 +648,7 @@ class WaveNetEngine:
             rows_c, Ep, E = B * self.frames, self.Ep, self.E
             from ._lib import call
             call("srwn_frame_sum_batched", self.gs.data_ptr(), B * T * R, self.dcb.data_ptr(), rows_c * R, L, B, T, R,
-                 self.frames, self.cfg.pool_stride, K.abi_dtype(dt), torch.cuda.current_stream().cuda_stream)
+                 self.frames, self.cfg.pool_stride, 1.0, K.abi_dtype(dt), torch.cuda.current_stream().cuda_stream)
             K.wgrad(self.cond_in.data_ptr(), 0, Ep, self.dcb.data_ptr(), rows_c * R, R, None, L, self.wgc_parts,
                     self.wgc_bparts, rows_c, self.frames, self.nslabs_c, dt)
             if Ep == E:

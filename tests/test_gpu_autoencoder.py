@@ -1,0 +1,173 @@
+"""GPU parity of the WaveNetAutoEncoder path (model.py:75-285; ops.py:48-58, 178-201) vs the CPU oracles.
+
+Unpinned by the reference; anchored on oracle (i) == oracle (ii) (tests/test_oracle.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import wavenet_np as O
+from oracle import wavenet_torch as OT
+from tests._pkg import sub
+from tests.test_gpu_kernels import DEV, dev, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _tap(x, ntaps, step, T, Cin, wp, bias, y, cout, aux, fadd, frames, pool, fscale, epi, dt):
+    L = sub("_lib"); K = sub("kernels")
+    rows = x.shape[0]
+    L.call("srwn_tap_linear", x.data_ptr(), Cin, ntaps, step, T, Cin, wp, None if bias is None else bias.data_ptr(),
+           y.data_ptr(), cout, cout, rows, None if aux is None else aux.data_ptr(), cout,
+           None if fadd is None else fadd.data_ptr(), 0 if fadd is None else fadd.shape[-1], frames, pool, fscale, epi,
+           K.abi_dtype(dt), torch.cuda.current_stream().cuda_stream)
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-4), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("cout", [128, 256])
+def test_tap_linear(dt, tol, cout):
+    """Time-tap GEMM: the SAME-padded K=2 conv (ops.py:51), its data gradient, a 1x1 with the per-frame broadcast."""
+    K = sub("kernels"); P = sub("packing")
+    rng = np.random.default_rng(cout)
+    B, T, Cin, pool = 3, 100, 128, 25
+    frames = T // pool
+    x = torch.tensor(rng.standard_normal((B * T, Cin)), dtype=dt, device=DEV)
+    xq = x.double().cpu().numpy().reshape(B, T, Cin)
+    w = rng.standard_normal((2, Cin, cout)) * 0.1
+    b = rng.standard_normal(cout) * 0.1
+    wq = torch.tensor(w, dtype=dt).double().numpy()
+    flat = dev(w.reshape(-1))
+    pk = K.Packer(DEV)
+    off = pk.reserve(cout // 32, 2 * Cin // 16)
+    P.fill_linear(pk, off, 0, 2 * Cin, cout, cout // 32, 2 * Cin // 16)      # [K*Cin, cout] natural: k = tap*Cin + i
+    offT = pk.reserve(cout // 32, Cin // 16)                                 # one tap as a 1x1 (first Cin rows)
+    P.fill_linear(pk, offT, 0, Cin, cout, cout // 32, Cin // 16)
+    pk.finalize()
+    packed = torch.zeros(pk.total, dtype=dt, device=DEV); pk.gather(flat, packed)
+    wp = packed.data_ptr(); es = packed.element_size()
+    # forward conv, relu
+    y = torch.zeros((B * T, cout), dtype=dt, device=DEV)
+    _tap(x, 2, 1, T, Cin, wp + off * es, dev(b), y, cout, None, None, 1, 1, 0.0, K.EPI_RELU, dt)
+    ref = np.maximum(O.conv1d_same(xq, wq) + b, 0).reshape(B * T, cout)
+    assert rel_err(y.double().cpu().numpy(), ref) < tol
+    # taps going backwards in time (the data-gradient direction), masked by aux
+    aux = torch.tensor(rng.standard_normal((B * T, cout)), dtype=dt, device=DEV)
+    _tap(x, 2, -1, T, Cin, wp + off * es, None, y, cout, aux, None, 1, 1, 0.0, K.EPI_MASK, dt)
+    back = np.zeros((B, T, cout))
+    back += xq @ wq[0]
+    back[:, 1:] += xq[:, :-1] @ wq[1]
+    ref = (back.reshape(B * T, cout)) * (aux.double().cpu().numpy() > 0)
+    assert rel_err(y.double().cpu().numpy(), ref) < tol
+    # 1x1 with the per-frame broadcast term added before the mask
+    fadd = dev(rng.standard_normal((B * frames, cout + 64)))
+    _tap(x, 1, 0, T, Cin, wp + offT * es, dev(b), y, cout, aux, fadd, frames, pool, 0.5, K.EPI_MASK, dt)
+    fa = np.repeat(fadd.cpu().numpy().reshape(B, frames, -1)[:, :, :cout], pool, axis=1).reshape(B * T, cout)
+    ref = (xq.reshape(B * T, Cin) @ wq[0] + b + 0.5 * fa) * (aux.double().cpu().numpy() > 0)
+    assert rel_err(y.double().cpu().numpy(), ref) < tol
+
+
+def test_encoder_small_kernels():
+    L = sub("_lib"); K = sub("kernels")
+    rng = np.random.default_rng(2)
+    st = torch.cuda.current_stream().cuda_stream
+    # first encoder layer on the raw clip
+    B, T, C = 2, 77, 128
+    x = rng.standard_normal((B, T)); w = rng.standard_normal((2, 1, C)); b = rng.standard_normal(C)
+    a = torch.zeros((B, T, C), device=DEV)
+    xd, wd, bd = dev(x), dev(w), dev(b)     # (keep the device tensors alive across the raw-pointer call)
+    L.call("srwn_nc_input_fwd", xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), a.data_ptr(), B, T, C, 2, K.F32, st)
+    ref = np.maximum(O.conv1d_same(np.maximum(x, 0)[:, :, None], w) + b, 0)
+    assert rel_err(a.cpu().numpy(), ref) < 1e-5
+    # its weight gradient: taps relu(x)[t+k]  (srwn_init_conv_wgrad with a negative shift)
+    g = rng.standard_normal((B, T, C))
+    gw = torch.zeros(2 * C, device=DEV); gb = torch.zeros(C, device=DEV)
+    ws = torch.zeros(int(L.load().srwn_init_conv_wgrad_partials(B, T, C, 2)), device=DEV)
+    K.init_conv_wgrad(dev(np.maximum(x, 0)), dev(g), gw, gb, 2, -1, ws)
+    xr = np.maximum(x, 0)
+    ref_w = np.stack([np.einsum("bt,btc->c", xr, g), np.einsum("bt,btc->c", xr[:, 1:], g[:, :-1])])
+    assert rel_err(gw.cpu().numpy().reshape(2, C), ref_w) < 1e-4 and rel_err(gb.cpu().numpy(), g.sum((0, 1))) < 1e-4
+    # small products with chunked operands
+    M, N, R, Lc, E = 50, 6, 8, 3, 10
+    A = rng.standard_normal((Lc, M, R)); W = rng.standard_normal((Lc, E, R)); bias = rng.standard_normal(N)
+    Cq = torch.full((M, N), 1.0, device=DEV)
+    Ad, Wd, biasd = dev(A), dev(W), dev(bias)
+    L.call("srwn_small_gemm", Ad.data_ptr(), R, R, M * R, K.F32, Wd.data_ptr(), 1, R, R, E * R,
+           biasd.data_ptr(), Cq.data_ptr(), N, K.F32, M, N, Lc * R, 1, st)
+    ref = 1.0 + bias + np.einsum("lmr,lnr->mn", A, W[:, :N])
+    assert rel_err(Cq.cpu().numpy(), ref) < 1e-5
+    Ab = torch.tensor(A, dtype=torch.bfloat16, device=DEV)
+    Cb = torch.zeros((M, N), dtype=torch.bfloat16, device=DEV)
+    L.call("srwn_small_gemm", Ab.data_ptr(), R, R, M * R, K.BF16, Wd.data_ptr(), 1, R, R, E * R, None,
+           Cb.data_ptr(), N, K.BF16, M, N, Lc * R, 0, st)
+    assert rel_err(Cb.double().cpu().numpy(), np.einsum("lmr,lnr->mn", Ab.double().cpu().numpy(), W[:, :N])) < 1e-2
+    Am = rng.standard_normal((M, 12)); D = rng.standard_normal((M, N))
+    cw = torch.zeros((12, N), device=DEV); cb = torch.zeros(N, device=DEV)
+    Amd, Dd = dev(Am), dev(D)
+    L.call("srwn_small_wgrad", Amd.data_ptr(), 12, Dd.data_ptr(), N, cw.data_ptr(), cb.data_ptr(), M, 12, N, 0.5, st)
+    assert rel_err(cw.cpu().numpy(), 0.5 * Am.T @ D) < 1e-5 and rel_err(cb.cpu().numpy(), 0.5 * D.sum(0)) < 1e-5
+    # mixture sampler with given uniforms (ops.py:178-201)
+    rows, Mx = 3000, 5
+    lg = rng.standard_normal((rows, 4 * Mx)); lg[:, 2 * Mx:3 * Mx] = rng.uniform(-9, -1, (rows, Mx))
+    u1 = rng.uniform(1e-5, 1 - 1e-5, (rows, Mx)).astype(np.float32); u2 = rng.uniform(1e-5, 1 - 1e-5, rows).astype(np.float32)
+    out = torch.zeros(rows, device=DEV)
+    lgd, u1d, u2d = dev(lg), dev(u1), dev(u2)
+    L.call("srwn_mol_sample", lgd.data_ptr(), 4 * Mx, Mx, u1d.data_ptr(), u2d.data_ptr(), out.data_ptr(), rows, st)
+    ref = O.mol_sample(lg.astype(np.float32).astype(np.float64)[None], u1.astype(np.float64)[None], u2.astype(np.float64)[None])[0]
+    assert np.abs(out.cpu().numpy() - ref).max() < 1e-4
+
+
+def _ae(dt, R, S, cs, B=2, T=256, pool=32, lat=8, M=5, dil=(1, 2, 4), lr=1e-3):
+    EG = sub("engine"); EN = sub("encoder")
+    dil = list(dil)
+    ep = O.init_encoder_params(60, len(dil), 2, 128, S, lat, bias_scale=0.05)
+    dp_ = O.init_stack_params(61, dil, 2, R, S, 4 * M, cond_channels=lat + cs, bias_scale=0.05)
+    cfg = EG.StackConfig(dilations=dil, dilation_channels=R, skip_channels=S, output_channels=4 * M,
+                         cond_channels=lat + cs, pool_stride=pool, shift_input=True, head_mode="mol", dtype=dt,
+                         learning_rate=lr)
+    ae = EN.AutoEncoderEngine(cfg, B, T, 128, lat, cs, DEV)
+    ae.enc.load_oracle_params(ep); ae.dec.load_oracle_params(dp_)
+    x = O.synthetic_audio(B, T, seed=21).astype(np.float64)
+    c = np.eye(max(cs, 1))[[0, cs - 1]][:, :cs] if cs else None
+    ae.set_inputs(dev(x), None if c is None else dev(c))
+    return ae, ep, dp_, x, c, pool
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-3), (torch.bfloat16, 6e-2)])
+@pytest.mark.parametrize("R,S,cs", [(64, 256, 3), (32, 128, 0)])
+def test_autoencoder_forward_backward(dt, tol, R, S, cs):
+    ae, ep, dp_, x, c, pool = _ae(dt, R, S, cs)
+    B, T = x.shape
+    ref = O.autoencoder_forward(ep, dp_, x, pool, c)
+    lg = ae.forward(want_logits=True)
+    assert rel_err(ae.enc.enc.cpu().numpy().reshape(ref["encoding"].shape), ref["encoding"]) < tol
+    assert rel_err(lg.cpu().numpy(), ref["logits"]) < tol
+    assert abs(float(ae.loss.item()) - ref["loss"]) < tol * abs(ref["loss"])
+    te, td = OT.TorchEncoder(ep), OT.TorchStack(dp_)
+    loss, _, _ = OT.autoencoder_loss(te, td, torch.tensor(x), pool, None if c is None else torch.tensor(c))
+    loss.backward()
+    ae.backward()
+    fp32 = dt == torch.float32
+    def cmp(mine, want, name):
+        a = mine.float().cpu().numpy()
+        if want is None:                       # variables outside the graph get no gradient
+            assert np.abs(a).max() == 0, name
+            return
+        r = want.numpy()
+        e = (np.abs(a - r).max() / (np.abs(r).max() + 1e-30)) if fp32 else (np.linalg.norm(a - r) / (np.linalg.norm(r) + 1e-30))
+        assert e < (tol if fp32 else 0.15), (name, e)
+    mine = ae.enc.named_tensors(ae.enc.grads)
+    for n, t in te.named():
+        if n.startswith("nc.ws") or n.startswith("nc.bs"):
+            continue
+        cmp(mine[n], t.grad, "enc." + n)
+    dm = ae.dec.named_tensors(ae.dec.grads)
+    for n, t in td.named(include_cond=True):
+        cmp(dm[n], t.grad, "dec." + n)
+
+
+def test_autoencoder_trains():
+    ae, *_ = _ae(torch.float32, 64, 256, 0, lr=1e-3)
+    ae.train_step()
+    l0 = float(ae.loss.item())
+    for _ in range(10):
+        ae.train_step()
+    assert float(ae.loss.item()) < l0

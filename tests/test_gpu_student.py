@@ -100,7 +100,8 @@ def test_stft_power_fwd_bwd(T):
     K.stft_power_bwd(spec, dpow, dx)
     assert rel_err(dx.cpu().numpy(), gs * xt.grad.numpy()) < 1e-3
     with pytest.raises(RuntimeError):   # a clip shorter than one frame (the reference would average zero frames)
-        sub("_lib").call("srwn_stft_power", dev(x).data_ptr(), None, fp.data_ptr(), pw.data_ptr(), B, 300,
+        xd = dev(x)
+        sub("_lib").call("srwn_stft_power", xd.data_ptr(), None, fp.data_ptr(), pw.data_ptr(), B, 300,
                          torch.cuda.current_stream().cuda_stream)
 
 
@@ -124,8 +125,8 @@ def test_mol_loss_dx_and_clamp():
     v = np.array([-2.0, -1.0, -0.5, 1.0, 1.5], np.float32)
     y = torch.zeros(5, device=DEV); g = torch.zeros(5, device=DEV)
     st = torch.cuda.current_stream().cuda_stream
-    L.call("srwn_clamp", dev(v).data_ptr(), y.data_ptr(), 5, -1.0, 1.0, st)
     dvv = dev(v); ones = torch.ones(5, device=DEV)
+    L.call("srwn_clamp", dvv.data_ptr(), y.data_ptr(), 5, -1.0, 1.0, st)
     L.call("srwn_clamp_bwd", dvv.data_ptr(), ones.data_ptr(), g.data_ptr(), 5, -1.0, 1.0, st)
     assert y.cpu().tolist() == [-1.0, -1.0, -0.5, 1.0, 1.0]
     assert g.cpu().tolist() == [0.0, 1.0, 1.0, 1.0, 0.0]
