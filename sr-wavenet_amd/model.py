@@ -7,10 +7,10 @@ wrappers, but no TensorFlow: the graph body is the fixed kernel sequence of ``en
 * ``WaveNetTeacher``     -- the 30-layer mu-law softmax teacher BASELINE.json names (decoder stack of
                             model.py:158-196 with the 256-way softmax head the reference carries at
                             model.py:100-112); this is the benchmark path.
-* ``ParallelWaveNet``    -- model.py:290-656: the IAF student distilled against a frozen mixture-of-logistics
-                            teacher (student.StudentEngine); ``encode``/``reconstruct`` wait for the encoder.
-* ``WaveNetAutoEncoder`` -- signature kept; its encoder (ResidualDilationLayerNC) and mixture sampler are the
-                            next SURVEY §8(f) row and raise until built.
+* ``WaveNetAutoEncoder`` -- model.py:75-285: non-causal encoder + conditioned mixture-of-logistics decoder
+                            (encoder.AutoEncoderEngine), the teacher teacher.py trains.
+* ``ParallelWaveNet``    -- model.py:290-656: the IAF student distilled against that frozen teacher
+                            (student.StudentEngine).
 """
 from __future__ import annotations
 
@@ -245,27 +245,181 @@ class WaveNetTeacher(_EngineOwner):
 
 
 class WaveNetAutoEncoder(object):
-    """model.py:75-285.  Constructor signature kept; the encoder (ResidualDilationLayerNC), the
-    mixture-of-logistics head and its sampler are SURVEY §8(f) rank-1 "next" rows, not built yet."""
+    """model.py:75-285 on ``encoder.AutoEncoderEngine``: the non-causal encoder (ResidualDilationLayerNC chain,
+    skip sum -> latent 1x1 -> average pool) and the conditioned mixture-of-logistics decoder, trained jointly on
+    ``discretized_mix_logistic_loss(inputs, logits)`` (model.py:103,114,116).
+
+    NumPy in / NumPy out like the reference's ``sess.run`` wrappers; there is no session.  One (batch, length) per
+    model object.  ``reconstruct*`` draw the sampler's uniforms on the device (``seed`` makes them repeatable)."""
 
     def __init__(self, input_size, condition_size, num_mixtures, dilations, filter_width=2, encoder_channels=128,
                  dilation_channels=32, skip_channels=256, latent_channels=16, pool_stride=512,
-                 name="WaveNetAutoEncoder", learning_rate=0.001):
-        raise NotImplementedError(
-            "WaveNetAutoEncoder (mixture-of-logistics teacher + encoder) is not built yet (SURVEY §8f rank 1); "
-            "use WaveNetTeacher for the mu-law softmax teacher on the same decoder stack")
+                 name="WaveNetAutoEncoder", learning_rate=0.001, dtype=None, seed=0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("sr-wavenet_amd needs an MI355X (HIP) device; there is no CPU fallback")
+        self._ctor = dict(input_size=int(input_size), condition_size=int(condition_size),
+                          num_mixtures=int(num_mixtures), dilations=[int(d) for d in dilations],
+                          filter_width=int(filter_width), encoder_channels=int(encoder_channels),
+                          dilation_channels=int(dilation_channels), skip_channels=int(skip_channels),
+                          latent_channels=int(latent_channels), pool_stride=int(pool_stride), name=name,
+                          learning_rate=float(learning_rate), seed=int(seed))
+        self.input_size = input_size
+        self.condition_size = condition_size
+        self.num_mixtures = num_mixtures
+        self.dilations = dilations
+        self.filter_width = filter_width
+        self.encoder_channels = encoder_channels
+        self.dilation_channels = dilation_channels
+        self.skip_channels = skip_channels
+        self.latent_channels = latent_channels
+        self.pool_stride = pool_stride
+        self._name, self._seed = name, seed
+        self._cfg = StackConfig(dilations=list(dilations), filter_width=filter_width,
+                                dilation_channels=dilation_channels, skip_channels=skip_channels,
+                                output_channels=4 * num_mixtures, cond_channels=latent_channels + condition_size,
+                                pool_stride=pool_stride, shift_input=True, head_mode="mol",
+                                dtype=dtype or _default_dtype(), learning_rate=learning_rate)
+        self._eng = None
+        self._gen = None
+        self.last_checkpoint_time = time.time()
+
+    # ------------------------------------------------------------------------------------------------
+    def _engine(self, B: int, T: int):
+        from .encoder import AutoEncoderEngine
+        if self._eng is None:
+            self._eng = AutoEncoderEngine(self._cfg, B, T, self.encoder_channels, self.latent_channels,
+                                          self.condition_size, "cuda", seed=self._seed)
+        elif (self._eng.B, self._eng.T) != (int(B), int(T)):
+            raise NotImplementedError("WaveNetAutoEncoder: one (batch, length) per model object for now; built for "
+                                      "%s, got %s" % ((self._eng.B, self._eng.T), (B, T)))
+        return self._eng
+
+    def _stage(self, inputs, conditions):
+        x = torch.as_tensor(np.asarray(inputs, dtype=np.float32), device="cuda")
+        if x.ndim != 2:
+            raise ValueError("inputs must be [batch, samples]")
+        eng = self._engine(*x.shape)
+        c = None
+        if self.condition_size > 0:
+            if conditions is None:
+                raise ValueError("this auto-encoder was built with condition_size > 0; pass conditions")
+            c = torch.as_tensor(np.asarray(conditions, dtype=np.float32), device="cuda")
+        eng.set_inputs(x, c)
+        return eng
+
+    def _put_encoding(self, eng, encoding):
+        e = torch.as_tensor(np.asarray(encoding, dtype=np.float32), device="cuda")
+        d = eng.dec
+        if tuple(e.shape) != (eng.B, d.frames, self.latent_channels):
+            raise ValueError("encoding must be [batch, samples/pool_stride, latent_channels]")
+        d.cond_in.view(eng.B, d.frames, d.Ep)[:, :, :self.latent_channels].copy_(e)
+
+    def _sample(self, eng, seed=None):
+        """``sample_from_discretized_mix_logistic`` on the decoder's logits (model.py:198; ops.py:178-201)."""
+        d = eng.dec
+        M = self.num_mixtures
+        if self._gen is None:
+            self._gen = torch.Generator(device="cuda")
+            self._gen.manual_seed(self._seed)
+        if seed is not None:
+            self._gen.manual_seed(int(seed))
+        u1 = torch.empty((d.N, M), dtype=torch.float32, device="cuda").uniform_(1e-5, 1.0 - 1e-5, generator=self._gen)
+        u2 = torch.empty((d.N,), dtype=torch.float32, device="cuda").uniform_(1e-5, 1.0 - 1e-5, generator=self._gen)
+        out = torch.empty((d.N,), dtype=torch.float32, device="cuda")
+        from ._lib import call
+        call("srwn_mol_sample", d.logits32.data_ptr(), d.logits32.stride(0), M, u1.data_ptr(), u2.data_ptr(),
+             out.data_ptr(), d.N, torch.cuda.current_stream().cuda_stream)
+        return out.view(eng.B, eng.T).cpu().numpy()
+
+    @property
+    def network_params(self):
+        eng = self._eng or self._engine(1, self.input_size)
+        out = dict(eng.enc.tf_variables(self._name + "/Encoder"))
+        out.update(eng.dec.tf_variables(self._name + "/Decoder", decoder=True))
+        return out
+
+    # --- the reference's methods (model.py:217-285) ---------------------------------------------------
+    def save(self, logdir, global_step, force=False):
+        if force or time.time() - self.last_checkpoint_time > 60:
+            import json
+            os.makedirs(logdir, exist_ok=True)
+            state = {k: v.detach().cpu().clone() for k, v in self.network_params.items()}
+            torch.save(state, os.path.join(logdir, "model.ckpt-%d.pt" % int(global_step)))
+            with open(os.path.join(logdir, "checkpoint"), "w") as f:
+                f.write('model_checkpoint_path: "model.ckpt-%d.pt"\n' % int(global_step))
+            with open(os.path.join(logdir, "config.json"), "w") as f:
+                json.dump(dict(self._ctor, **{"class": "WaveNetAutoEncoder"}), f)
+            self.last_checkpoint_time = time.time()
+            return True
+        return False
+
+    def load(self, logdir):
+        if logdir is None or not os.path.exists(os.path.join(logdir, "checkpoint")):
+            return None
+        line = open(os.path.join(logdir, "checkpoint")).readline()
+        path = os.path.join(logdir, line.split('"')[1])
+        if not os.path.exists(path):
+            print("Could not find checkpoint at %s" % path)
+            return False
+        state = torch.load(path, weights_only=True)
+        for k, dst in self.network_params.items():
+            dst.copy_(state[k].to(dst.device).reshape(dst.shape))
+        self._eng.enc.repack(); self._eng.dec.repack()
+        print("Restoring previous session")
+        return True
+
+    @classmethod
+    def from_checkpoint(cls, logdir, batch, length, dtype=None):
+        import json
+        cfg = json.load(open(os.path.join(logdir, "config.json")))
+        cfg.pop("class", None)
+        m = cls(dtype=dtype, **cfg)
+        m._engine(batch, length)
+        if not m.load(logdir):
+            raise FileNotFoundError("%s: no checkpoint to restore" % logdir)
+        return m
+
+    def train(self, inputs, conditions=None):
+        eng = self._stage(inputs, conditions)
+        eng.train_step()
+        return np.float32(eng.loss.item())
+
+    def encode(self, inputs, conditions=None):
+        eng = self._stage(inputs, conditions)
+        return eng.encode().view(eng.B, -1, self.latent_channels).cpu().numpy()
+
+    def reconstruct(self, inputs, conditions=None, seed=None):
+        """``self.out`` (model.py:268-273): encode, run the decoder teacher-forced on the same clip, sample."""
+        eng = self._stage(inputs, conditions)
+        eng.forward()
+        return self._sample(eng, seed)
+
+    def reconstruct_with_encoding(self, inputs, encoding, conditions=None, seed=None):
+        eng = self._stage(inputs, conditions)
+        self._put_encoding(eng, encoding)
+        eng.dec.forward(with_loss=False)
+        return self._sample(eng, seed)
+
+    def get_logits(self, inputs, encoding, conditions=None):
+        eng = self._stage(inputs, conditions)
+        self._put_encoding(eng, encoding)
+        return eng.dec.forward(want_logits=True, with_loss=False).cpu().numpy()
+
+    def mu_law(self, inputs, conditions=None):
+        raise AttributeError("WaveNetAutoEncoder.mu_law reads self.targets, which the reference never defines "
+                             "(model.py:100,276): it raises there too")
 
 
 class ParallelWaveNet(object):
     """model.py:290-656 on ``student.StudentEngine``: ``num_flows`` inverse-autoregressive flows distilled against a
     frozen mixture-of-logistics teacher.
 
-    ``teacher`` is a ``WaveNetTeacher(head="mol", use_encoding=True)`` or a directory one was saved to (the
-    reference takes the checkpoint directory and imports its meta graph, model.py:313-324).  The ``sess`` argument of
+    ``teacher`` is a ``WaveNetAutoEncoder`` (or a decoder-only ``WaveNetTeacher(head="mol", use_encoding=True)``), or
+    the directory one was saved to (the reference takes the checkpoint directory and imports its meta graph,
+    model.py:313-324).  The ``sess`` argument of
     every method is accepted for call compatibility with student.py and ignored (there is no session).
-    ``encode`` / ``reconstruct`` need the auto-encoder's encoder and mixture sampler (model.py:136-156; ops.py:178-201),
-    which are the next row to build; ``train`` (the per-sample-clipped slow path, model.py:603-632) is not built:
-    student.py:107 uses ``train_fast``."""
+    ``encode`` / ``reconstruct`` run the teacher auto-encoder (model.py:644-656).  ``train`` (the per-sample-clipped
+    slow path, model.py:603-632) is not built: student.py:107 uses ``train_fast``."""
 
     def __init__(self, input_size, condition_size, dilations, teacher, num_flows=2, filter_width=2,
                  dilation_channels=32, skip_channels=256, latent_channels=16, pool_stride=512,
@@ -286,21 +440,38 @@ class ParallelWaveNet(object):
         self._abg = (float(alpha), float(beta), float(gamma))
         self._lr, self._seed = learning_rate, seed
         self._teacher_dir = None
+        self._dtype = dtype
         if isinstance(teacher, (str, os.PathLike)):
             self._teacher_dir = os.fspath(teacher)
-            self._teacher = WaveNetTeacher.from_checkpoint(self._teacher_dir, dtype=dtype)
+            import json
+            cfgp = os.path.join(self._teacher_dir, "config.json")
+            if not os.path.exists(cfgp):
+                raise FileNotFoundError("%s: no config.json (save the teacher with its save() method)" % self._teacher_dir)
+            if json.load(open(cfgp)).get("class") == "WaveNetAutoEncoder":
+                self._teacher = None      # built on first use: the auto-encoder is tied to one (batch, length)
+                self._teacher_cfg = {k: v for k, v in json.load(open(cfgp)).items() if k != "class"}
+            else:
+                self._teacher = WaveNetTeacher.from_checkpoint(self._teacher_dir, dtype=dtype)
         else:
             self._teacher = teacher
         t = self._teacher
-        if not isinstance(t, WaveNetTeacher) or t.head != "mol" or not t.use_encoding:
-            raise ValueError("teacher must be a mixture-of-logistics WaveNetTeacher built with use_encoding=True")
-        if (t.latent_channels, t.condition_size, t.pool_stride) != (latent_channels, condition_size, pool_stride):
+        if t is None:
+            tc = self._teacher_cfg
+            tl, tcs, tp, tdt = tc["latent_channels"], tc["condition_size"], tc["pool_stride"], None
+        elif isinstance(t, WaveNetAutoEncoder):
+            tl, tcs, tp, tdt = t.latent_channels, t.condition_size, t.pool_stride, t._cfg.dtype
+        elif isinstance(t, WaveNetTeacher) and t.head == "mol" and t.use_encoding:
+            tl, tcs, tp, tdt = t.latent_channels, t.condition_size, t.pool_stride, t._cfg.dtype
+        else:
+            raise ValueError("teacher must be a WaveNetAutoEncoder, or a mixture-of-logistics WaveNetTeacher built "
+                             "with use_encoding=True, or a directory one of them was saved to")
+        if (tl, tcs, tp) != (latent_channels, condition_size, pool_stride):
             raise ValueError("student and teacher must agree on latent_channels, condition_size and pool_stride "
                              "(they share the encoding placeholders, model.py:318-324)")
         self._flow_cfg = StackConfig(dilations=list(dilations), filter_width=filter_width,
                                      dilation_channels=dilation_channels, skip_channels=skip_channels,
                                      cond_channels=latent_channels + condition_size, pool_stride=pool_stride,
-                                     dtype=dtype or t._cfg.dtype, learning_rate=learning_rate)
+                                     dtype=dtype or tdt or _default_dtype(), learning_rate=learning_rate)
         self._engines: Dict[tuple, object] = {}
         self._primary = None
         self.last_checkpoint_time = time.time()
@@ -315,8 +486,11 @@ class ParallelWaveNet(object):
                 raise NotImplementedError("ParallelWaveNet: one (batch, length) per model object for now; got %s "
                                           "after %s" % (key, next(iter(self._engines))))
             a, b, g = self._abg
-            eng = StudentEngine(self._teacher._engine(B, T), self._flow_cfg, self.num_flows, alpha=a, beta=b, gamma=g,
-                                learning_rate=self._lr, seed=self._seed)
+            if self._teacher is None:
+                self._teacher = WaveNetAutoEncoder.from_checkpoint(self._teacher_dir, B, T, dtype=self._dtype)
+            teng = self._teacher._engine(B, T)
+            eng = StudentEngine(teng.dec if isinstance(self._teacher, WaveNetAutoEncoder) else teng, self._flow_cfg,
+                                self.num_flows, alpha=a, beta=b, gamma=g, learning_rate=self._lr, seed=self._seed)
             self._primary = eng
             self._engines[key] = eng
         return eng
@@ -348,7 +522,7 @@ class ParallelWaveNet(object):
 
     # --- checkpointing (model.py:540-567) ---------------------------------------------------------------
     def load(self, sess, logdir):
-        if self._teacher_dir is not None:
+        if self._teacher_dir is not None and self._teacher is not None:
             self._teacher.load(self._teacher_dir)                                         # model.py:543-544
         if logdir is None or not os.path.exists(os.path.join(logdir, "checkpoint")):
             return None
@@ -408,13 +582,22 @@ class ParallelWaveNet(object):
         raise NotImplementedError("ParallelWaveNet.train (per-sample clipping, model.py:603-632) is not built; "
                                   "student.py:107 trains with train_fast")
 
+    def _ae_teacher(self, inputs):
+        if self._teacher is None:
+            x = np.asarray(inputs)
+            self._teacher = WaveNetAutoEncoder.from_checkpoint(self._teacher_dir, x.shape[0], x.shape[1], dtype=self._dtype)
+        if not isinstance(self._teacher, WaveNetAutoEncoder):
+            raise NotImplementedError("encode/reconstruct run the teacher's encoder (model.py:644-656): build the "
+                                      "student on a WaveNetAutoEncoder teacher")
+        return self._teacher
+
     def encode(self, sess, inputs, conditions=None):
-        raise NotImplementedError("ParallelWaveNet.encode runs the auto-encoder's encoder (model.py:136-156), "
-                                  "which is not built yet")
+        """The teacher's encoding of a clip (``teacher_encoding``, model.py:644-649)."""
+        return self._ae_teacher(inputs).encode(inputs, conditions)
 
     def reconstruct(self, sess, inputs, conditions=None):
-        raise NotImplementedError("ParallelWaveNet.reconstruct needs the auto-encoder's encoder and mixture sampler "
-                                  "(model.py:136-156; ops.py:178-201), which are not built yet")
+        """The teacher's own reconstruction (``teacher_out``, model.py:651-656)."""
+        return self._ae_teacher(inputs).reconstruct(inputs, conditions)
 
 
 def smoke_check():

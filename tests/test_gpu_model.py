@@ -77,10 +77,51 @@ def test_teacher_with_encoding_and_conditions():
         m.train(audio)
 
 
-def test_unbuilt_classes_say_so():
+def test_autoencoder_api_and_student_on_it(tmp_path):
+    """teacher.py's calls on WaveNetAutoEncoder (teacher.py:61-112) and student.py's use of it as the frozen teacher
+    (student.py:82-116: encode -> train_fast -> generate / reconstruct)."""
     M = sub("model")
-    with pytest.raises(NotImplementedError):
-        M.WaveNetAutoEncoder(4096, 0, 5, [1, 2])
+    dil = [1, 2, 4, 8]
+    B, T, pool, lat = 2, 1024, 64, 8
+    ae = M.WaveNetAutoEncoder(input_size=T, condition_size=0, num_mixtures=5, dilations=dil, latent_channels=lat,
+                              skip_channels=128, pool_stride=pool, learning_rate=1e-3, dtype=torch.float32)
+    x = O.synthetic_audio(B, T, seed=4)
+    ls = [float(ae.train(x)) for _ in range(6)]
+    assert ls[-1] < ls[0]
+    enc = ae.encode(x)
+    assert enc.shape == (B, T // pool, lat)
+    r1 = ae.reconstruct(x, seed=7); r2 = ae.reconstruct(x, seed=7); r3 = ae.reconstruct(x, seed=8)
+    assert r1.shape == (B, T) and np.abs(r1).max() <= 1.0 and np.array_equal(r1, r2) and not np.array_equal(r1, r3)
+    lg = ae.get_logits(x, enc)
+    assert lg.shape == (B, T, 20)
+    # reconstruct == sample(logits_from_encoding(encode(x))) for the same draws (model.py:214-215)
+    assert np.array_equal(ae.reconstruct_with_encoding(x, enc, seed=7), r1)
+    assert abs(O.mol_loss(x.astype(np.float64), lg.astype(np.float64)) - float(ae.train(x))) < 1e-3 * ls[-1]
+    names = ae.network_params
+    for k in ("WaveNetAutoEncoder/Encoder/nc_conv_NC/conv1d/kernel", "WaveNetAutoEncoder/Encoder/conv1d/kernel",
+              "WaveNetAutoEncoder/Encoder/dilated_conv_3_NC/conv1d/bias",
+              "WaveNetAutoEncoder/Encoder/conv1d_%d/kernel" % (2 * len(dil) + 2),
+              "WaveNetAutoEncoder/Decoder/causal_conv_Kernel", "WaveNetAutoEncoder/Decoder/conv1d_%d/kernel" % (3 * len(dil) + 1)):
+        assert k in names, k
+    assert names["WaveNetAutoEncoder/Encoder/conv1d_%d/kernel" % (2 * len(dil) + 2)].shape == (1, 128, lat)
+    with pytest.raises(AttributeError):
+        ae.mu_law(x)
+    tdir = str(tmp_path / "ae")
+    assert ae.save(tdir, 7, force=True)
+    enc_before = ae.encode(x)
+    # the student rebuilds the teacher from the directory (model.py:313-324)
+    st = M.ParallelWaveNet(input_size=T, condition_size=0, dilations=dil, teacher=tdir, dilation_channels=64,
+                           skip_channels=128, num_flows=2, latent_channels=lat, pool_stride=pool, gamma=1e-3,
+                           dtype=torch.float32)
+    e2 = st.encode(None, x)
+    assert np.array_equal(e2, enc_before)
+    noise = (0.15 * np.random.default_rng(1).logistic(0, 1, (B, T))).astype(np.float32)
+    l = [st.train_fast(None, noise, x, e2) for _ in range(8)]
+    assert all(np.isfinite(v[0]) for v in l) and min(v[0] for v in l[4:]) < l[0][0]
+    assert np.array_equal(st.encode(None, x), enc_before)          # the teacher stays frozen (model.py:334-341)
+    rec = st.reconstruct(None, x)
+    assert rec.shape == (B, T) and np.abs(rec).max() <= 1.0
+    assert st.generate(None, noise, e2).shape == (B, T, 1)
 
 
 def test_parallel_wavenet_student_api(tmp_path):
@@ -129,7 +170,7 @@ def test_parallel_wavenet_student_api(tmp_path):
     with pytest.raises(ValueError):
         student.train_fast(None, noise, x, enc)          # conditions missing
     with pytest.raises(NotImplementedError):
-        student.encode(None, x, y)
+        student.encode(None, x, y)        # a decoder-only teacher has no encoder
     with pytest.raises(ValueError):
         M.ParallelWaveNet(T, cs, dil, M.WaveNetTeacher(T, 0, dil, dilation_channels=64, skip_channels=256))
 

@@ -289,3 +289,73 @@ def test_mol_dx_and_global_norm_clip():
     small = [g * 1e-3 for g in gs]
     c2, _ = O.clip_by_global_norm(small, 1.0)
     assert all(np.array_equal(a, b) for a, b in zip(c2, small))
+
+
+# --------------------------------------------------------------------------
+# WaveNetAutoEncoder (model.py:75-285): encoder, joint loss, sampler
+# --------------------------------------------------------------------------
+def test_conv1d_same_padding_and_nc_layer():
+    """tf.layers.conv1d SAME with K=2 pads one zero on the RIGHT: y[t] = x[t] w0 + x[t+1] w1 (ops.py:51)."""
+    x = np.arange(1, 6, dtype=np.float64).reshape(1, 5, 1)
+    w = np.array([10.0, 1.0]).reshape(2, 1, 1)
+    assert O.conv1d_same(x, w)[0, :, 0].tolist() == [12.0, 23.0, 34.0, 45.0, 50.0]
+    w3 = np.array([100.0, 10.0, 1.0]).reshape(3, 1, 1)          # K=3: one zero each side
+    assert O.conv1d_same(x, w3)[0, :, 0].tolist() == [12.0, 123.0, 234.0, 345.0, 450.0]
+    rng = np.random.default_rng(0)
+    p = O.NCLayerParams(rng.standard_normal((2, 3, 4)), rng.standard_normal(4), rng.standard_normal((4, 4)),
+                        rng.standard_normal(4), rng.standard_normal((4, 6)), rng.standard_normal(6))
+    xx = rng.standard_normal((2, 7, 3))
+    res, skip, a = O.residual_dilation_layer_nc(xx, p)
+    assert res.shape == (2, 7, 4) and skip.shape == (2, 7, 6) and (a >= 0).all()
+    assert np.allclose(res, a @ p.wr + p.br)                      # no "+ x": the NC layer returns the 1x1 alone
+
+
+def test_autoencoder_np_vs_torch_and_finite_differences():
+    B, T, pool, EC, S, lat, cs = 2, 128, 16, 8, 12, 3, 2
+    dil = [1, 2, 4]
+    ep = O.init_encoder_params(1, len(dil), 2, EC, S, lat, bias_scale=0.1)
+    dp_ = O.init_stack_params(2, dil, 2, 8, S, 12, cond_channels=lat + cs, bias_scale=0.1)
+    x = O.synthetic_audio(B, T, seed=1).astype(np.float64)
+    c = np.eye(cs)[[0, 1]]
+    r = O.autoencoder_forward(ep, dp_, x, pool, c)
+    assert r["encoding"].shape == (B, T // pool, lat)
+    te, td = OT.TorchEncoder(ep), OT.TorchStack(dp_)
+    loss, e, lg = OT.autoencoder_loss(te, td, torch.tensor(x), pool, torch.tensor(c))
+    assert np.allclose(r["encoding"], e.detach().numpy(), rtol=1e-10, atol=1e-12)
+    assert np.allclose(r["logits"], lg.detach().numpy(), rtol=1e-9, atol=1e-11)
+    assert float(loss.detach()) == pytest.approx(r["loss"], rel=1e-10)
+    loss.backward()
+    g = dict(te.named())
+    # variables outside the graph: the skip 1x1 of 'nc_conv' and the last layer's residual 1x1 (model.py:141-150)
+    assert g["nc.ws"].grad is None and g["e%d.wr" % (len(dil) - 1)].grad is None and g["e0.wr"].grad is not None
+    rng = np.random.default_rng(0)
+    for holder, attr, name in ((ep.nc, "w", "nc.w"), (ep.layers[1], "w", "e1.w"), (ep.layers[0], "wr", "e0.wr"),
+                               (ep.layers[2], "ws", "e2.ws"), (ep, "lat_w", "lat_w"), (ep.layers[1], "b", "e1.b")):
+        arr = getattr(holder, attr)
+        idx = tuple(rng.integers(0, s) for s in arr.shape)
+        old = arr[idx]; h = 1e-6
+        arr[idx] = old + h; lp = O.autoencoder_forward(ep, dp_, x, pool, c)["loss"]
+        arr[idx] = old - h; lm = O.autoencoder_forward(ep, dp_, x, pool, c)["loss"]
+        arr[idx] = old
+        assert (lp - lm) / (2 * h) == pytest.approx(g[name].grad.numpy()[idx], rel=1e-4, abs=1e-6), name
+
+
+def test_mol_sample_closed_forms():
+    """ops.py:178-201 with given draws: u2 = 0.5 returns the selected mean; a dominant logit is always selected;
+    the log-scale floor is -7; the output is clipped to [-1, 1]."""
+    M = 3
+    l = np.zeros((1, 4, 4 * M))
+    l[..., :M] = [0.0, 50.0, 0.0]
+    l[..., M:2 * M] = [0.1, -0.3, 0.7]
+    l[..., 2 * M:3 * M] = [-1.0, -20.0, -1.0]
+    u1 = np.full((1, 4, M), 0.5)
+    u2 = np.array([[0.5, 0.9, 1e-5, 1 - 1e-5]])
+    x = O.mol_sample(l, u1, u2)
+    assert x[0, 0] == pytest.approx(-0.3)
+    assert x[0, 1] == pytest.approx(-0.3 + math.exp(-7.0) * math.log(9.0))
+    l[..., M:2 * M] = [0.1, 0.9999, 0.7]; l[..., 2 * M:3 * M] = 0.0
+    assert O.mol_sample(l, u1, u2)[0].tolist()[2:] == [-1.0, 1.0]
+    # Gumbel-max: with equal logits the largest -log(-log(u1)) wins
+    l[..., :M] = 0.0
+    u1[0, 0] = [0.2, 0.3, 0.9]
+    assert O.mol_sample(l, u1, np.full((1, 4), 0.5))[0, 0] == pytest.approx(0.7)
