@@ -105,6 +105,14 @@ int srwn_pw_linear(const void* x, int64_t x_row_stride, int64_t x_chunk_stride, 
                    int32_t cout_valid, int64_t rows, const void* aux, int64_t aux_row_stride, int32_t pro,
                    int32_t epi, int32_t dtype, void* stream);
 
+/* the same product split over the contraction axis (few rows, long K): slice z of nsplit writes its fp32 partial to
+ * y_partials + z*rows*y_row_stride (bias in slice 0); srwn_reduce_partials(nslabs = nsplit, n = rows*y_row_stride)
+ * finishes it.  Used for the encoder's pooled skip sum (model.py:150: B*frames rows, K = L*encoder_channels). */
+int srwn_pw_linear_ksplit(const void* x, int64_t x_row_stride, int64_t x_chunk_stride, int32_t chunk_len, int32_t Cin,
+                          const void* wpack, const float* bias, float* y_partials, int64_t y_row_stride,
+                          int32_t cout_pad, int32_t cout_valid, int64_t rows, int32_t nsplit, int32_t dtype,
+                          void* stream);
+
 /* ---- last 1x1 + softmax head: model.py:56 then the mu-law softmax-CE the reference carries at
  * model.py:100-112 (log-softmax as ops.py:111-115), per time step, fused in registers:
  *   logits = bias + x @ W;  loss_row = logsumexp(logits) - logits[target]

@@ -32,6 +32,7 @@ SIGNATURES = {
                                           _i32, _i32, _p]),
     "srwn_pw_linear": (C.c_int, [_p, _i64, _i64, _i32, _i32, _p, _p, _p, _i64, _i32, _i32, _i64, _p, _i64, _i32,
                                  _i32, _i32, _p]),
+    "srwn_pw_linear_ksplit": (C.c_int, [_p, _i64, _i64, _i32, _i32, _p, _p, _p, _i64, _i32, _i32, _i64, _i32, _i32, _p]),
     "srwn_softmax_ce_partials": (_i64, [_i64]),
     "srwn_head_softmax_ce": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _p, _p, _p, _i32, _i32, _i64, _f32, _i32, _p]),
     "srwn_reduce_loss": (C.c_int, [_p, _i64, _f32, _p, _p]),

@@ -677,9 +677,11 @@ __global__ void frame_sum_generic_kernel(const T* __restrict__ g, int64_t g_batc
 template <typename T>
 static int launch_frame_sum(const void* g, int64_t gbs, void* out, int64_t obs, int nbatch, int B, int T_, int C,
                             int frames, int pool, float scale, hipStream_t st) {
-  if (C == 64 || C == 32) {
+  if (C == 128 || C == 64 || C == 32) {
     dim3 grid(frames, B, nbatch), block(256);
-    if (C == 64)
+    if (C == 128)
+      hipLaunchKernelGGL((frame_sum_kernel<T, 128>), grid, block, 0, st, (const T*)g, gbs, (T*)out, obs, T_, frames, pool, scale);
+    else if (C == 64)
       hipLaunchKernelGGL((frame_sum_kernel<T, 64>), grid, block, 0, st, (const T*)g, gbs, (T*)out, obs, T_, frames, pool, scale);
     else
       hipLaunchKernelGGL((frame_sum_kernel<T, 32>), grid, block, 0, st, (const T*)g, gbs, (T*)out, obs, T_, frames, pool, scale);

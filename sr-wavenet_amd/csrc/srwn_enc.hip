@@ -55,6 +55,7 @@ __global__ __launch_bounds__(256) void nc_input_kernel(const float* __restrict__
 //   C[m][n] = (accumulate ? C : 0) + bias[n] + sum_k A(m,k) * B(k,n)
 //   A(m,k) = a[(k/a_chunk)*a_chunk_stride + m*lda + k%a_chunk]   (dtype TA: bf16 or fp32)
 //   B(k,n) = b[(k/b_chunk)*b_chunk_stride + (k%b_chunk)*ldb_k + n*ldb_n]   (fp32)
+// 16 lanes share an output and stride over k (coalesced A reads), then a fixed xor-butterfly.
 template <typename TA, typename TC>
 __global__ __launch_bounds__(256) void small_gemm_kernel(const TA* __restrict__ a, int64_t lda, int a_chunk,
                                                          int64_t a_chunk_stride, const float* __restrict__ b,
@@ -62,39 +63,51 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(const TA* __restrict__ 
                                                          int64_t b_chunk_stride, const float* __restrict__ bias,
                                                          TC* __restrict__ c, int64_t ldc, int M, int N, int Kd,
                                                          int accumulate) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (int64_t)M * N) return;
-  const int n = (int)(i % N), m = (int)(i / N);
-  float s = bias ? bias[n] : 0.0f;
-  for (int k0 = 0; k0 < Kd; k0 += a_chunk) {   // a_chunk divides b_chunk or vice versa (host check): walk a-chunks
-    const TA* ap = a + (int64_t)(k0 / a_chunk) * a_chunk_stride + (int64_t)m * lda;
-    for (int kk = 0; kk < a_chunk; ++kk) {
-      const int k = k0 + kk;
+  const int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int sub = threadIdx.x & 15;
+  const bool live = i < (int64_t)M * N;
+  const int n = live ? (int)(i % N) : 0, m = live ? (int)(i / N) : 0;
+  float s = 0.0f;
+  if (live) {
+    for (int k = sub; k < Kd; k += 16) {
+      const float av = (float)a[(int64_t)(k / a_chunk) * a_chunk_stride + (int64_t)m * lda + (k % a_chunk)];
       const float bv = b[(int64_t)(k / b_chunk) * b_chunk_stride + (int64_t)(k % b_chunk) * ldb_k + (int64_t)n * ldb_n];
-      s = fmaf((float)ap[kk], bv, s);
+      s = fmaf(av, bv, s);
     }
   }
-  TC* d = c + (int64_t)m * ldc + n;
-  *d = (TC)(accumulate ? (float)*d + s : s);
+#pragma unroll
+  for (int w = 8; w > 0; w >>= 1) s += __shfl_xor(s, w, 64);
+  if (live && sub == 0) {
+    if (bias) s += bias[n];
+    TC* d = c + (int64_t)m * ldc + n;
+    *d = (TC)(accumulate ? (float)*d + s : s);
+  }
 }
 
 // C[k][n] = scale * sum_m A[m][k] * D[m][n]  (+ bias_out[n] = scale * sum_m D[m][n]): weight gradients of the small
-// products above, all fp32, M in the thousands.  One thread per output, fixed order.
+// products above, all fp32, M in the thousands.  16 lanes share an output and stride over m; fixed butterfly.
 __global__ __launch_bounds__(256) void small_wgrad_kernel(const float* __restrict__ a, int64_t lda,
                                                           const float* __restrict__ d, int64_t ldd,
                                                           float* __restrict__ c, float* __restrict__ bias_out, int M,
                                                           int Kd, int N, float scale) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int sub = threadIdx.x & 15;
   const int64_t total = (int64_t)(Kd + 1) * N;
-  if (i >= total) return;
-  const int n = (int)(i % N), k = (int)(i / N);
+  const bool live = i < total;
+  const int n = live ? (int)(i % N) : 0, k = live ? (int)(i / N) : 0;
   double s = 0.0;
-  if (k < Kd) {
-    for (int m = 0; m < M; ++m) s += (double)a[(int64_t)m * lda + k] * (double)d[(int64_t)m * ldd + n];
-    c[(int64_t)k * N + n] = (float)(s * (double)scale);
-  } else if (bias_out) {
-    for (int m = 0; m < M; ++m) s += (double)d[(int64_t)m * ldd + n];
-    bias_out[n] = (float)(s * (double)scale);
+  if (live) {
+    if (k < Kd) {
+      for (int m = sub; m < M; m += 16) s += (double)a[(int64_t)m * lda + k] * (double)d[(int64_t)m * ldd + n];
+    } else {
+      for (int m = sub; m < M; m += 16) s += (double)d[(int64_t)m * ldd + n];
+    }
+  }
+#pragma unroll
+  for (int w = 8; w > 0; w >>= 1) s += __shfl_xor(s, w, 64);
+  if (live && sub == 0) {
+    if (k < Kd) c[(int64_t)k * N + n] = (float)(s * (double)scale);
+    else if (bias_out) bias_out[n] = (float)(s * (double)scale);
   }
 }
 
@@ -146,7 +159,7 @@ extern "C" int srwn_small_gemm(const void* a, int64_t lda, int32_t a_chunk, int6
       (a_chunk % b_chunk && b_chunk % a_chunk))
     return set_error(SRWN_E_SHAPE, "small_gemm: M=%d N=%d K=%d a_chunk=%d b_chunk=%d", M, N, K, a_chunk, b_chunk);
   const int64_t total = (int64_t)M * N;
-  dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  dim3 grid((unsigned)((total + 15) / 16)), block(256);
   hipStream_t st = (hipStream_t)stream;
 #define SRWN_SG(TA, TC)                                                                                          \
   hipLaunchKernelGGL((small_gemm_kernel<TA, TC>), grid, block, 0, st, (const TA*)a, lda, a_chunk, a_chunk_stride, \
@@ -166,7 +179,7 @@ extern "C" int srwn_small_wgrad(const float* a, int64_t lda, const float* d, int
   if (!a || !d || !c) return set_error(SRWN_E_NULL, "small_wgrad: null pointer");
   if (M < 0 || K < 0 || N < 0) return set_error(SRWN_E_SHAPE, "small_wgrad: M=%d K=%d N=%d", M, K, N);
   const int64_t total = (int64_t)(K + 1) * N;
-  hipLaunchKernelGGL(small_wgrad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a,
+  hipLaunchKernelGGL(small_wgrad_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, (hipStream_t)stream, a,
                      lda, d, ldd, c, bias_out, M, K, N, scale);
   return check_launch("small_wgrad");
 }

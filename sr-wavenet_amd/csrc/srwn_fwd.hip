@@ -335,6 +335,7 @@ struct PwArgs {
   const void* x; int64_t x_row_stride; int64_t x_chunk_stride; int chunk_len; int ks_total;
   const void* wpack; const float* bias; void* y; int64_t y_row_stride; int cout_valid; int64_t rows;
   const void* aux; int64_t aux_row_stride;
+  int ks_per_split; int64_t y_split_stride;   // grid.z = k-splits: slice z covers k-steps [z*ks_per_split, ...) -> y + z*stride
 };
 
 template <typename T, int PRO>
@@ -360,6 +361,8 @@ __global__ __launch_bounds__(256) void pw_linear_kernel(PwArgs a) {
   if (row_wave >= a.rows) return;
   const int mb = blockIdx.y;  // block of MT row tiles
   const Frag<T>* wp = reinterpret_cast<const Frag<T>*>(a.wpack) + (size_t)mb * MT * a.ks_total * 64 + lane;
+  const int ks_lo = blockIdx.z * a.ks_per_split;
+  const int ks_hi = (ks_lo + a.ks_per_split < a.ks_total) ? ks_lo + a.ks_per_split : a.ks_total;
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(256) void pw_linear_kernel(PwArgs a) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int n = 32 * (mb * MT + mt) + crow(q, half);
-      const float bv = (a.bias && n < a.cout_valid) ? a.bias[n] : 0.0f;
+      const float bv = (a.bias && n < a.cout_valid && blockIdx.z == 0) ? a.bias[n] : 0.0f;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt][q] = bv;
     }
@@ -380,7 +383,7 @@ __global__ __launch_bounds__(256) void pw_linear_kernel(PwArgs a) {
     valid[nt] = rowc[nt] < a.rows;
   }
 
-  for (int ks = 0; ks < a.ks_total; ++ks) {
+  for (int ks = ks_lo; ks < ks_hi; ++ks) {
     Frag<T> bf[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) bf[nt] = pw_load_b<T, PRO>(a, rowc[nt], valid[nt], ks, half);
@@ -414,7 +417,9 @@ __global__ __launch_bounds__(256) void pw_linear_kernel(PwArgs a) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = (m[e] > 0.0f) ? v[e] : 0.0f;
         }
-        if (EPI == SRWN_EPI_F32) store4(reinterpret_cast<float*>(a.y) + rowc[nt] * a.y_row_stride + n0, v[0], v[1], v[2], v[3]);
+        if (EPI == SRWN_EPI_F32)
+          store4(reinterpret_cast<float*>(a.y) + (int64_t)blockIdx.z * a.y_split_stride + rowc[nt] * a.y_row_stride + n0,
+                 v[0], v[1], v[2], v[3]);
         else store4(yrow + n0, v[0], v[1], v[2], v[3]);
       }
     }
@@ -423,7 +428,9 @@ __global__ __launch_bounds__(256) void pw_linear_kernel(PwArgs a) {
 
 template <typename T, int MT, int NT>
 static int launch_pw(const PwArgs& a, int cout_pad, int pro, int epi, hipStream_t st) {
-  dim3 grid((unsigned)((a.rows + 4 * 32 * NT - 1) / (4 * 32 * NT)), (unsigned)(cout_pad / (32 * MT))), block(256);
+  const int nsplit = (a.ks_total + a.ks_per_split - 1) / a.ks_per_split;
+  dim3 grid((unsigned)((a.rows + 4 * 32 * NT - 1) / (4 * 32 * NT)), (unsigned)(cout_pad / (32 * MT)), (unsigned)nsplit),
+      block(256);
 #define SRWN_PW(P, E)                                                                                   \
   if (pro == P && epi == E) {                                                                           \
     hipLaunchKernelGGL((pw_linear_kernel<T, MT, NT, P, E>), grid, block, 0, st, a);                     \
@@ -438,6 +445,8 @@ static int launch_pw(const PwArgs& a, int cout_pad, int pro, int epi, hipStream_
 #undef SRWN_PW
   return set_error(SRWN_E_UNSUPPORTED, "pw_linear: pro %d / epi %d combination not built", pro, epi);
 }
+
+static int pw_dispatch(const PwArgs& a, int cout_pad, int pro, int epi, int dtype, hipStream_t st);
 
 extern "C" int srwn_pw_linear(const void* x, int64_t x_row_stride, int64_t x_chunk_stride, int32_t chunk_len,
                               int32_t Cin, const void* wpack, const float* bias, void* y, int64_t y_row_stride,
@@ -459,7 +468,11 @@ extern "C" int srwn_pw_linear(const void* x, int64_t x_row_stride, int64_t x_chu
       return rc;
   }
   PwArgs a{x, x_row_stride, x_chunk_stride, chunk_len, Cin / 16, wpack, bias, y, y_row_stride, cout_valid, rows, aux,
-           aux_row_stride};
+           aux_row_stride, Cin / 16, 0};
+  return pw_dispatch(a, cout_pad, pro, epi, dtype, st);
+}
+
+static int pw_dispatch(const PwArgs& a, int cout_pad, int pro, int epi, int dtype, hipStream_t st) {
   const int tiles = cout_pad / 32;
   if (dtype == SRWN_BF16) {
     if (tiles % 4 == 0) return launch_pw<bf16_t, 4, 2>(a, cout_pad, pro, epi, st);
@@ -471,6 +484,25 @@ extern "C" int srwn_pw_linear(const void* x, int64_t x_row_stride, int64_t x_chu
     return launch_pw<float, 1, 1>(a, cout_pad, pro, epi, st);
   }
   return set_error(SRWN_E_DTYPE, "pw_linear: dtype %d", dtype);
+}
+
+// The same product split over the contraction axis: slice z of `nsplit` covers Cin/nsplit inputs and writes its
+// fp32 partial to y_partials + z*rows*y_row_stride (bias in slice 0); finish with srwn_reduce_partials.  For
+// few-row products with a long contraction (the pooled skip sum of the encoder: 1024 rows x K = L*128).
+extern "C" int srwn_pw_linear_ksplit(const void* x, int64_t x_row_stride, int64_t x_chunk_stride, int32_t chunk_len,
+                                     int32_t Cin, const void* wpack, const float* bias, float* y_partials,
+                                     int64_t y_row_stride, int32_t cout_pad, int32_t cout_valid, int64_t rows,
+                                     int32_t nsplit, int32_t dtype, void* stream) {
+  if (rows == 0) return 0;
+  if (!x || !wpack || !y_partials) return set_error(SRWN_E_NULL, "pw_linear_ksplit: null pointer");
+  if (rows < 0 || Cin < 16 || Cin % 16 || chunk_len < 16 || chunk_len % 16 || Cin % chunk_len || cout_pad < 32 ||
+      cout_pad % 32 || cout_valid < 4 || cout_valid % 4 || cout_valid > cout_pad || nsplit < 1 || nsplit > 1024 ||
+      (Cin / 16) % nsplit)
+    return set_error(SRWN_E_SHAPE, "pw_linear_ksplit: rows=%lld Cin=%d chunk=%d cout_pad=%d cout_valid=%d nsplit=%d",
+                     (long long)rows, Cin, chunk_len, cout_pad, cout_valid, nsplit);
+  PwArgs a{x, x_row_stride, x_chunk_stride, chunk_len, Cin / 16, wpack, bias, y_partials, y_row_stride, cout_valid, rows,
+           nullptr, 0, (Cin / 16) / nsplit, rows * y_row_stride};
+  return pw_dispatch(a, cout_pad, SRWN_PRO_NONE, SRWN_EPI_F32, dtype, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------

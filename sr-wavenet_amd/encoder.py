@@ -190,6 +190,7 @@ class EncoderStack:
         self.a_mean = z(L, self.rows_c, EC)
         self.bs_sum = f(S)
         self.s_mean = f(self.rows_c, S)
+        self.s_parts = f(L * self.rows_c * S)
         self.enc = f(self.rows_c, self.lat)
         self.ds_mean = z(self.rows_c, S)
         self.da_all = f(self.rows_c, L * EC)
@@ -225,8 +226,10 @@ class EncoderStack:
         call("srwn_frame_sum_batched", self.a[1].data_ptr(), N * EC, self.a_mean.data_ptr(), self.rows_c * EC, L, B, T,
              EC, self.frames, self.pool, 1.0 / self.pool, K.abi_dtype(self.dt), st)
         K.reduce_partials(v("EBS").reshape(-1), L, S, 1, True, 1.0, self.bs_sum.data_ptr(), 0)
-        K.pw_linear(self.a_mean.data_ptr(), EC, self.rows_c * EC, EC, L * EC, self.wptr(self.o_ws), self.bs_sum,
-                    self.s_mean, S, S, self.rows_c, epi=K.EPI_F32, compute_dtype=self.dt)
+        # K = L*EC on few rows: one k-slice per layer, then a fixed-order sum of the slices
+        call("srwn_pw_linear_ksplit", self.a_mean.data_ptr(), EC, self.rows_c * EC, EC, L * EC, self.wptr(self.o_ws),
+             self.bs_sum.data_ptr(), self.s_parts.data_ptr(), S, S, S, self.rows_c, L, K.abi_dtype(self.dt), st)
+        K.reduce_partials(self.s_parts, L, self.rows_c * S, 1, True, 1.0, self.s_mean.data_ptr(), 0)
         call("srwn_small_gemm", self.s_mean.data_ptr(), S, S, 0, K.F32, v("lat_w").data_ptr(), self.lat, 1, S, 0,
              v("lat_b").data_ptr(), self.enc.data_ptr(), self.lat, K.F32, self.rows_c, self.lat, S, 0, st)
         return self.enc
@@ -351,4 +354,23 @@ class AutoEncoderEngine:
         self.backward()
         self.allreduce_grads()
         self.optimizer_step()
+        return self.loss
+
+    def capture_graphs(self):
+        """{forward, backward} and {Adam, re-pack} as two hipGraphs with the all-reduce between them (see
+        WaveNetEngine.capture_graphs).  Call after one eager train_step."""
+        torch.cuda.synchronize()
+        self._g_fb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g_fb):
+            self.forward()
+            self.backward()
+        self._g_opt = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g_opt, pool=self._g_fb.pool()):
+            self.optimizer_step()
+        torch.cuda.synchronize()
+
+    def train_step_graphed(self):
+        self._g_fb.replay()
+        self.allreduce_grads()
+        self._g_opt.replay()
         return self.loss
