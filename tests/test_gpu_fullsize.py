@@ -1,0 +1,109 @@
+"""BASELINE config 2 at FULL size (30 layers, 64/256 ch, 256-way softmax, batch 8 x 16000) through size-independent
+properties -- the oracle cannot run these shapes in seconds, so parity here is structural:
+
+  causality          logits before a perturbed sample do not change (bit-exact)
+  batch separability the batch-8 gradient is the mean of the two batch-4 half gradients; losses average
+  directional FD     (loss(p + e v) - loss(p - e v)) / 2e == <grad, v>   (fp32 mode, whole-model direction)
+  determinism        two steps from the same state are bit-identical (no atomics anywhere on the path)
+  mu-law             decode(encode(x)) within half a quantisation step on 128 000 samples; encode(decode(c)) == c
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import wavenet_np as O
+from tests._pkg import sub
+from tests.test_gpu_kernels import DEV, dev
+
+pytestmark = pytest.mark.gpu
+
+DIL = [1, 2, 4, 8, 16, 32, 64, 128, 256, 512] * 3
+B, T, R, S, C = 8, 16000, 64, 256, 256
+
+
+def _engine(dt, batch=B, seed=0, share=None):
+    EG = sub("engine")
+    cfg = EG.StackConfig(dilations=DIL, dilation_channels=R, skip_channels=S, output_channels=C, shift_input=True,
+                         dtype=dt, learning_rate=1e-3)
+    return EG.WaveNetEngine(cfg, batch, T, DEV, seed=seed, share_from=share)
+
+
+def _inputs():
+    K = sub("kernels")
+    audio = dev(O.synthetic_audio(B, T, seed=0))
+    return audio, K.mu_law_encode(audio, C)
+
+
+def test_full_size_causality_and_loss_scale():
+    eng = _engine(torch.bfloat16)
+    audio, codes = _inputs()
+    eng.set_inputs(audio, codes)
+    lg0 = eng.forward(want_logits=True).clone()
+    assert abs(float(eng.loss.item()) - np.log(C)) < 0.5          # near-uniform softmax at initialisation
+    t0 = 9001
+    a2 = audio.clone(); a2[:, t0] += 0.25
+    eng.set_inputs(a2, codes)
+    lg1 = eng.forward(want_logits=True)
+    # RightShift (ops.py:78-80): logits[t] see audio[< t] only
+    assert torch.equal(lg0[:, :t0 + 1], lg1[:, :t0 + 1])
+    assert not torch.equal(lg0[:, t0 + 1], lg1[:, t0 + 1])
+    # the receptive field is 1 + sum(d) = 3070 samples (+1 for the shift): nothing beyond it moves either
+    rf = 1 + sum(DIL) + 1
+    assert torch.equal(lg0[:, t0 + rf + 1:], lg1[:, t0 + rf + 1:])
+
+
+def test_full_size_batch_separability_and_determinism():
+    dt = torch.bfloat16
+    full = _engine(dt)
+    audio, codes = _inputs()
+    full.set_inputs(audio, codes)
+    full.forward(); full.backward()
+    g8, l8 = full.grads.clone(), float(full.loss.item())
+    full.forward(); full.backward()
+    assert torch.equal(g8, full.grads) and l8 == float(full.loss.item())      # bit-reproducible
+    half = _engine(dt, batch=B // 2, share=full)
+    gs, ls = [], []
+    for h in range(2):
+        half.set_inputs(audio[h * 4:(h + 1) * 4], codes.view(B, T)[h * 4:(h + 1) * 4].contiguous())
+        half.forward(); half.backward()
+        gs.append(half.grads.clone()); ls.append(float(half.loss.item()))
+    gm = 0.5 * (gs[0] + gs[1])
+    # every op is per batch element: identical activations, only the fp32 summation order differs
+    err = float((g8 - gm).norm() / g8.norm())
+    assert err < 1e-4, err
+    assert abs(l8 - 0.5 * (ls[0] + ls[1])) < 1e-5 * abs(l8)
+
+
+def test_full_size_directional_finite_difference_fp32():
+    eng = _engine(torch.float32)
+    audio, codes = _inputs()
+    eng.set_inputs(audio, codes)
+    eng.forward(); eng.backward()
+    g = eng.grads.clone()
+    p0 = eng.params.clone()
+    gen = torch.Generator(device=DEV); gen.manual_seed(5)
+    v = torch.randn(p0.shape, device=DEV, generator=gen)
+    v = v / v.norm() + g / g.norm()          # a random direction with a component along the gradient (so <g,v> is
+    v = v / v.norm()                         # well above the fp32 resolution of the loss)
+    ana = float((g.double() * v.double()).sum())
+    eps = 1e-2
+    ls = []
+    for sgn in (1.0, -1.0):
+        eng.params.copy_(p0 + sgn * eps * v); eng.repack()
+        eng.forward()
+        ls.append(float(eng.loss.double().item()))
+    eng.params.copy_(p0); eng.repack()
+    fd = (ls[0] - ls[1]) / (2 * eps)
+    assert abs(fd - ana) < 2e-2 * abs(ana) + 1e-5, (fd, ana)
+
+
+def test_full_size_mu_law_round_trip():
+    K = sub("kernels")
+    audio, codes = _inputs()
+    dec = K.mu_law_decode(codes, C)
+    # decode(encode(x)) lands in the same quantisation bin: re-encoding is the identity, all 256 bins included
+    assert torch.equal(K.mu_law_encode(dec, C), codes)
+    allc = torch.arange(C, dtype=torch.int32, device=DEV)
+    assert torch.equal(K.mu_law_encode(K.mu_law_decode(allc, C), C), allc)
+    # companded error bound: |x - decode(encode(x))| <= half a bin of the expanded grid (at most ~2.2 % of full scale)
+    assert float((dec.view(-1) - audio.view(-1)).abs().max()) < 0.0222
