@@ -13,6 +13,9 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsrwn.so")
+IO_LIB = os.path.join(HERE, "libsrwn_io.so")     # host-only data path (TFRecord reader), plain g++
+IO_SOURCES = ["srwn_tfrecord.cpp"]
+CXX = os.environ.get("CXX", "g++")
 SOURCES = ["srwn_util.hip", "srwn_fwd.hip", "srwn_bwd.hip", "srwn_opt.hip", "srwn_pool.hip", "srwn_gemm.hip", "srwn_wgrad2.hip", "srwn_gen.hip", "srwn_flow.hip", "srwn_enc.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-pass-failed", "-ffp-contract=on"]
@@ -54,7 +57,18 @@ def build(force: bool = False, verbose: bool = False) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s" % r.stderr[-8000:])
+    build_io(force)
     return LIB
+
+
+def build_io(force: bool = False) -> str:
+    srcs = [os.path.join(CSRC, s) for s in IO_SOURCES]
+    if force or _stale(IO_LIB, srcs + [os.path.join(HERE, "..", "include", "srwn_io.h")]):
+        cmd = [CXX, "-O2", "-fPIC", "-shared", "-std=c++17", "-pthread", "-Wall", "-o", IO_LIB] + srcs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("g++ failed for the IO library:\n%s" % r.stderr[-8000:])
+    return IO_LIB
 
 
 if __name__ == "__main__":
