@@ -240,6 +240,21 @@ int srwn_generate(const void* wcr, const void* wskip, const void* w1, const void
                   int32_t nsteps, int32_t R, int32_t S, int32_t C, int32_t K, int32_t mode, uint64_t seed,
                   int32_t dtype, void* stream);
 
+/* The same generator for the conditioned mixture-of-logistics decoder of WaveNetAutoEncoder (model.py:158-200; the
+ * reference samples it with one whole-clip pass per sample, generator.py:150-170): cond [B*cond_frames, cond_ld] in
+ * `dtype` holds the conditioning biases cb_l of every layer at columns [l*R, (l+1)*R) (model.py:180: one
+ * srwn_pw_linear of encoding_w_condition); layer l adds row (u, t / pool_stride), rounded like the training kernel.
+ * cond = NULL: unconditioned.  Head: 4*num_mixtures logits (w2 image / b2 padded to a multiple of 32 rows), sampled
+ * as sample_from_discretized_mix_logistic (ops.py:178-201) with counter-based uniforms in (1e-5, 1-1e-5);
+ * mode 0 returns the selected mixture's mean.  codes_out = selected mixture; logits_out [B, Tout, 4M] (may be NULL). */
+int srwn_generate_mol(const void* wcr, const void* wskip, const void* w1, const void* w2, const float* bias_f,
+                      const float* bias_r, const float* bs_sum, const float* b1, const float* b2, const float* init_w,
+                      const float* init_b, void* ring, float* audio_out, int32_t* codes_out, float* logits_out,
+                      const float* forced, const int32_t* dilations, int32_t nlayers, int32_t B, int32_t Tout,
+                      int32_t nsteps, int32_t R, int32_t S, int32_t K, int32_t num_mixtures, const void* cond,
+                      int32_t cond_frames, int32_t pool_stride, int64_t cond_ld, int32_t mode, uint64_t seed,
+                      int32_t dtype, void* stream);
+
 /* ---- discretised mixture-of-logistics loss of the reference's live teacher:
  * discretized_mix_logistic_loss (ops.py:124-175, sum_all=True) on logits [rows, ldl] fp32 whose first 4*M
  * columns are (logit_probs, means, log_scales, coeffs) and targets x [rows] in [-1,1]:

@@ -1,4 +1,6 @@
-// Queue-cached incremental (autoregressive) generation for the mu-law softmax teacher.
+// Queue-cached incremental (autoregressive) generation for the mu-law softmax teacher and for the conditioned
+// mixture-of-logistics decoder of WaveNetAutoEncoder (the teacher generator.py:150-170 / teacher.py:140-171 sample
+// from with a whole-clip pass per sample).
 //
 // The reference has no fast generator: its only sampler re-runs the whole clip once per
 // generated sample (teacher.py:140-171, O(T^2 L)).  This kernel keeps, per layer, a ring of the last
@@ -12,6 +14,7 @@
 // (64 channels) of the skip / head products; conv+residual weights of layer l+1 stream into LDS by LDS-DMA
 // while layer l computes; skip/head weights are read straight from L2 (each wave uses distinct rows).
 #include <cstdlib>
+#include <type_traits>
 #include "srwn_common.h"
 #include "srwn_host.h"
 #include "../../include/srwn.h"
@@ -31,6 +34,10 @@ struct GenArgs {
   void* ring;           // layer input rings, element offsets ring_off[l], depth dil[l]+1 slots of [32][R]
   float* audio_out; int32_t* codes_out; float* logits_out; const float* forced;
   int B, Tout, nsteps, L, C, mode, Q;
+  // conditioning (model.py:180-183): cond [B*frames, cond_ld] holds cb of every layer at columns [l*R, (l+1)*R);
+  // layer l adds row (u, t / pool) to its input, rounded to T like the training kernel.  NULL = unconditioned.
+  const void* cond; int cond_frames; int pool; long long cond_ld;
+  int M;                // > 0: mixture-of-logistics head with M mixtures (C = 4M logits) instead of the softmax
   long long ring_group_elems;
   unsigned long long seed;
   int dil[kGenMaxLayers];
@@ -52,7 +59,10 @@ __device__ __forceinline__ float gen_uniform(unsigned long long seed, unsigned u
   return (float)((x >> 40) + 0.5) * (1.0f / 16777216.0f);   // (0,1)
 }
 
-template <typename T, int NBUF>
+template <typename T> struct GenCond { Frag<T> cd[4]; f32x4 cc[2][4]; };
+struct GenNoCond {};
+
+template <typename T, int NBUF, bool COND>
 __global__ __launch_bounds__(256) void generate_kernel(GenArgs a) {
   constexpr int RT = 2, R = 64, KS = 4, S = 256, SQ = 64;       // SQ: skip/head channels per wave
   constexpr int FB = sizeof(Frag<T>) * 64;
@@ -86,7 +96,10 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a) {
   int par = 0;   // which weight buffer holds the layer being computed (toggles every layer, across steps)
 
   for (int i = threadIdx.x; i < a.L * R; i += 256) { c_bf[i] = a.bias_f[i]; c_br[i] = a.bias_r[i]; }
-  for (int i = threadIdx.x; i < S; i += 256) { c_bs[i] = a.bs_sum[i]; c_b1[i] = a.b1[i]; c_b2[i] = a.b2[i]; }
+  for (int i = threadIdx.x; i < S; i += 256) {
+    c_bs[i] = a.bs_sum[i]; c_b1[i] = a.b1[i];
+    c_b2[i] = (i < (a.C + 31) / 32 * 32) ? a.b2[i] : 0.0f;     // the last 1x1 has ceil(C/32)*32 rows
+  }
   if (threadIdx.x < 2 * R) c_iw[threadIdx.x] = a.init_w[threadIdx.x];
   if (threadIdx.x < R) c_ib[threadIdx.x] = a.init_b[threadIdx.x];
   if (threadIdx.x < 64) prev[threadIdx.x] = 0.0f;
@@ -96,7 +109,10 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a) {
   // operands of one layer that do not depend on the current step's activations: the tap-0 window from
   // the ring (written d >= 1 steps ago) and this wave's skip-weight fragments (from L2).  Loaded two
   // layers ahead, unconditionally (clamped), so their latency hides behind the dependent MFMA chain.
-  struct Pre { Frag<T> xd[KS]; Frag<T> ws[2][KS]; };
+  // (the conditioning operands exist only in the COND instantiation: they cost 32 VGPRs per operand set)
+  struct Pre : std::conditional<COND, GenCond<T>, GenNoCond>::type { Frag<T> xd[KS]; Frag<T> ws[2][KS]; };
+  const T* condp = COND ? reinterpret_cast<const T*>(a.cond) : nullptr;
+  const int ucl = uok ? ug : (a.B - 1);                          // clamped utterance for conditioning loads
   auto preload = [&](int l_, int t, Pre& p) {
     const int l = l_ < a.L ? l_ : a.L - 1;
     const int d = a.dil[l], depth = d + 1;
@@ -105,6 +121,17 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a) {
     const T* rp = ring + a.ring_off[l] + ((size_t)slot * 32 + col) * R + 8 * half;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) p.xd[ks] = load_nat(rp + 16 * ks);
+    if constexpr (COND) {   // cb_l of the delayed tap's frame (fragment layout) and of the current frame (accumulator layout)
+      const int fd = min((td >= 0 ? td : 0) / a.pool, a.cond_frames - 1), fc = min(t / a.pool, a.cond_frames - 1);
+      const T* cdp = condp + ((size_t)ucl * a.cond_frames + fd) * a.cond_ld + (size_t)l * R + 8 * half;
+      const T* ccp = condp + ((size_t)ucl * a.cond_frames + fc) * a.cond_ld + (size_t)l * R + 4 * half;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) p.cd[ks] = load_nat(cdp + 16 * ks);
+#pragma unroll
+      for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) p.cc[mt][g] = load4(ccp + 32 * mt + 8 * g);
+    }
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -150,7 +177,14 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a) {
       Frag<T> xd[KS];
       const bool tap0 = (t - d) >= 0;   // zero before the clip starts
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) xd[ks] = tap0 ? p.xd[ks] : zero_frag<T>();
+      for (int ks = 0; ks < KS; ++ks) {
+        Frag<T> f = p.xd[ks];
+        if constexpr (COND) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f.set(j, f.get(j) + p.cd[ks].get(j));   // T(x + cb) as in layer_fwd_kernel
+        }
+        xd[ks] = tap0 ? f : zero_frag<T>();
+      }
       // x_l[t] -> ring (one writer), and as the permuted-order B fragments of tap 1
       Frag<T> xc[KS];
 #pragma unroll
@@ -170,6 +204,15 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a) {
       for (int mt = 0; mt < RT; ++mt)
 #pragma unroll
         for (int q = 0; q < 16; ++q) h[mt][q] = xc[2 * mt + (q >> 3)].get(q & 7);
+      if constexpr (COND) {   // conv operand and residual base are T(x + cb) (the ring keeps the unconditioned x)
+#pragma unroll
+        for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            h[mt][q] = (float)(T)(h[mt][q] + p.cc[mt][q >> 2][q & 3]);
+            xc[2 * mt + (q >> 3)].set(q & 7, h[mt][q]);
+          }
+      }
 
       const Frag<T>* lw = reinterpret_cast<const Frag<T>*>(wbuf + buf * LAYER_B) + lane;
       f32x16 accF[RT];
@@ -259,6 +302,7 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a) {
                fmaxf(acc1[m][4 * g + 1], 0.f), fmaxf(acc1[m][4 * g + 2], 0.f), fmaxf(acc1[m][4 * g + 3], 0.f));
     __syncthreads();
     f32x16 acc2[2];
+    const int cp_pad = (a.C + 31) / 32 * 32;   // rows of the last 1x1's image (256 for the softmax head, 4M padded for MoL)
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -267,7 +311,8 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a) {
     for (int ks = 0; ks < S / 16; ++ks) {
       const Frag<T> bf = load_nat(xch + col * S + 16 * ks + 8 * half);
 #pragma unroll
-      for (int m = 0; m < 2; ++m) mma(acc2[m], w2[((size_t)(2 * wave + m) * (S / 16) + ks) * 64 + lane], bf);
+      for (int m = 0; m < 2; ++m)
+        if (32 * (2 * wave + m) < cp_pad) mma(acc2[m], w2[((size_t)(2 * wave + m) * (S / 16) + ks) * 64 + lane], bf);
     }
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -277,6 +322,40 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a) {
             f32x4{acc2[m][4 * g], acc2[m][4 * g + 1], acc2[m][4 * g + 2], acc2[m][4 * g + 3]};
     __syncthreads();
 
+    if (a.M > 0) {
+      // ---- mixture-of-logistics head (model.py:196-198): sample_from_discretized_mix_logistic (ops.py:178-201) with
+      //      counter-based uniforms; lanes = utterances (M <= 16 mixtures: a short serial loop)
+      if (wave == 0 && half == 0) {
+        const float* l = lgl + col * S;
+        int sel = 0;
+        float best = -INFINITY;
+        for (int m = 0; m < a.M; ++m) {
+          const float u1 = 1e-5f + (1.0f - 2e-5f) * gen_uniform(a.seed, (unsigned)ug, (unsigned)(t * (a.M + 1) + m));
+          const float v = l[m] - logf(-logf(u1));
+          if (v > best) { best = v; sel = m; }
+        }
+        float smp = l[a.M + sel];                                  // mode 0: the selected mean (no logistic noise)
+        if (a.mode == 1) {
+          const float u2 = 1e-5f + (1.0f - 2e-5f) * gen_uniform(a.seed, (unsigned)ug, (unsigned)(t * (a.M + 1) + a.M));
+          smp += expf(fmaxf(l[2 * a.M + sel], -7.0f)) * (logf(u2) - logf(1.0f - u2));
+        }
+        smp = fminf(fmaxf(smp, -1.0f), 1.0f);
+        if (uok) {
+          a.audio_out[(size_t)ug * a.Tout + t] = smp;
+          a.codes_out[(size_t)ug * a.Tout + t] = sel;
+        }
+        prev[32 + col] = prev[col];
+        prev[col] = smp;
+      }
+      if (a.logits_out) {
+        for (int i = threadIdx.x; i < 32 * a.C; i += 256) {
+          const int ul = i / a.C, c = i - ul * a.C;
+          if (u0 + ul < a.B) a.logits_out[((size_t)(u0 + ul) * a.Tout + t) * a.C + c] = lgl[ul * S + c];
+        }
+      }
+      __syncthreads();
+      continue;
+    }
     // ---- softmax over the C classes, pick a code, mu-law decode: wave w serves utterances 8w..8w+7 with
     //      lanes = classes (4 per lane: conflict-free LDS rows, shuffle reductions instead of serial loops)
     for (int i = 0; i < 8; ++i) {
@@ -340,12 +419,13 @@ extern "C" int64_t srwn_generate_ring_elems(const int32_t* dilations, int32_t nl
   return n;   // per group of 32 utterances
 }
 
-extern "C" int srwn_generate(const void* wcr, const void* wskip, const void* w1, const void* w2, const float* bias_f,
-                             const float* bias_r, const float* bs_sum, const float* b1, const float* b2,
-                             const float* init_w, const float* init_b, void* ring, float* audio_out,
-                             int32_t* codes_out, float* logits_out, const float* forced, const int32_t* dilations,
-                             int32_t nlayers, int32_t B, int32_t Tout, int32_t nsteps, int32_t R, int32_t S,
-                             int32_t C, int32_t K, int32_t mode, uint64_t seed, int32_t dtype, void* stream) {
+static int generate_impl(const void* wcr, const void* wskip, const void* w1, const void* w2, const float* bias_f,
+                         const float* bias_r, const float* bs_sum, const float* b1, const float* b2,
+                         const float* init_w, const float* init_b, void* ring, float* audio_out, int32_t* codes_out,
+                         float* logits_out, const float* forced, const int32_t* dilations, int32_t nlayers, int32_t B,
+                         int32_t Tout, int32_t nsteps, int32_t R, int32_t S, int32_t C, int32_t K, int32_t mode,
+                         uint64_t seed, int32_t dtype, void* stream, const void* cond, int32_t cond_frames,
+                         int32_t pool, int64_t cond_ld, int32_t M) {
   if (B == 0 || nsteps == 0) return 0;
   if (!wcr || !wskip || !w1 || !w2 || !bias_f || !bias_r || !bs_sum || !b1 || !b2 || !init_w || !init_b || !ring ||
       !audio_out || !codes_out || !dilations)
@@ -359,6 +439,7 @@ extern "C" int srwn_generate(const void* wcr, const void* wskip, const void* w1,
   a.b1 = b1; a.b2 = b2; a.init_w = init_w; a.init_b = init_b; a.ring = ring; a.audio_out = audio_out;
   a.codes_out = codes_out; a.logits_out = logits_out; a.forced = forced;
   a.B = B; a.Tout = Tout; a.nsteps = nsteps; a.L = nlayers; a.C = C; a.mode = mode; a.Q = C; a.seed = seed;
+  a.cond = cond; a.cond_frames = cond_frames; a.pool = pool; a.cond_ld = cond_ld; a.M = M;
   long long off = 0;
   for (int l = 0; l < kGenMaxLayers; ++l) {
     a.dil[l] = (l < nlayers) ? dilations[l] : 1;
@@ -372,14 +453,14 @@ extern "C" int srwn_generate(const void* wcr, const void* wskip, const void* w1,
   const unsigned groups = (unsigned)((B + 31) / 32);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == SRWN_BF16) {
-    auto kfn = generate_kernel<bf16_t, 2>;
+    auto kfn = cond ? generate_kernel<bf16_t, 2, true> : generate_kernel<bf16_t, 2, false>;
     const size_t sh = 2 * 24 * sizeof(Frag<bf16_t>) * 64 + 32 * 256 * sizeof(bf16_t) + 32 * 256 * 4 + 64 * 4 +
                       (size_t)(2 * nlayers * 64 + 3 * 256 + 3 * 64) * 4;
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     if (e != hipSuccess) return set_error((int)e, "generate: LDS %zu: %s", sh, hipGetErrorString(e));
     hipLaunchKernelGGL(kfn, dim3(groups), dim3(256), sh, st, a);
   } else if (dtype == SRWN_F32) {
-    auto kfn = generate_kernel<float, 1>;
+    auto kfn = cond ? generate_kernel<float, 1, true> : generate_kernel<float, 1, false>;
     const size_t sh = 1 * 24 * sizeof(Frag<float>) * 64 + 32 * 256 * sizeof(float) + 32 * 256 * 4 + 64 * 4 +
                       (size_t)(2 * nlayers * 64 + 3 * 256 + 3 * 64) * 4;
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
@@ -389,4 +470,37 @@ extern "C" int srwn_generate(const void* wcr, const void* wskip, const void* w1,
     return set_error(SRWN_E_DTYPE, "generate: dtype %d", dtype);
   }
   return check_launch("generate");
+}
+
+extern "C" int srwn_generate(const void* wcr, const void* wskip, const void* w1, const void* w2, const float* bias_f,
+                             const float* bias_r, const float* bs_sum, const float* b1, const float* b2,
+                             const float* init_w, const float* init_b, void* ring, float* audio_out,
+                             int32_t* codes_out, float* logits_out, const float* forced, const int32_t* dilations,
+                             int32_t nlayers, int32_t B, int32_t Tout, int32_t nsteps, int32_t R, int32_t S,
+                             int32_t C, int32_t K, int32_t mode, uint64_t seed, int32_t dtype, void* stream) {
+  return generate_impl(wcr, wskip, w1, w2, bias_f, bias_r, bs_sum, b1, b2, init_w, init_b, ring, audio_out, codes_out,
+                       logits_out, forced, dilations, nlayers, B, Tout, nsteps, R, S, C, K, mode, seed, dtype, stream,
+                       nullptr, 1, 1, 0, 0);
+}
+
+// The conditioned mixture-of-logistics decoder (WaveNetAutoEncoder.createDecoder, model.py:158-200): cond
+// [B*cond_frames, cond_ld] = the per-layer conditioning biases cb_l at columns [l*R, (l+1)*R) (srwn_pw_linear of
+// encoding_w_condition, model.py:180); head = 4*num_mixtures logits, sampled as ops.py:178-201.  b2 and the w2
+// image cover ceil(4M/32)*32 rows.  codes_out receives the selected mixture index.
+extern "C" int srwn_generate_mol(const void* wcr, const void* wskip, const void* w1, const void* w2,
+                                 const float* bias_f, const float* bias_r, const float* bs_sum, const float* b1,
+                                 const float* b2, const float* init_w, const float* init_b, void* ring,
+                                 float* audio_out, int32_t* codes_out, float* logits_out, const float* forced,
+                                 const int32_t* dilations, int32_t nlayers, int32_t B, int32_t Tout, int32_t nsteps,
+                                 int32_t R, int32_t S, int32_t K, int32_t num_mixtures, const void* cond,
+                                 int32_t cond_frames, int32_t pool_stride, int64_t cond_ld, int32_t mode, uint64_t seed,
+                                 int32_t dtype, void* stream) {
+  if (num_mixtures < 1 || num_mixtures > 16)
+    return set_error(SRWN_E_SHAPE, "generate_mol: num_mixtures=%d (1..16)", num_mixtures);
+  if (cond && (cond_frames < 1 || pool_stride < 1 || cond_ld < (int64_t)nlayers * R))
+    return set_error(SRWN_E_SHAPE, "generate_mol: cond_frames=%d pool_stride=%d cond_ld=%lld", cond_frames, pool_stride,
+                     (long long)cond_ld);
+  return generate_impl(wcr, wskip, w1, w2, bias_f, bias_r, bs_sum, b1, b2, init_w, init_b, ring, audio_out, codes_out,
+                       logits_out, forced, dilations, nlayers, B, Tout, nsteps, R, S, 4 * num_mixtures, K, mode, seed,
+                       dtype, stream, cond, cond ? cond_frames : 1, cond ? pool_stride : 1, cond_ld, num_mixtures);
 }

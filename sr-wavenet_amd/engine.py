@@ -682,13 +682,15 @@ class WaveNetEngine:
         return self.loss
 
     def generate(self, nsteps: int, mode: str = "sample", seed: int = 0, forced: Optional[torch.Tensor] = None,
-                 want_logits: bool = False, batch: Optional[int] = None):
+                 want_logits: bool = False, batch: Optional[int] = None, cond: Optional[torch.Tensor] = None):
         """Queue-cached autoregressive generation of `nsteps` samples for `batch` utterances.
-        Returns (audio [B,nsteps] f32, codes [B,nsteps] i32, logits [B,nsteps,C] f32 or None)."""
+        Softmax teacher: returns (audio [B,nsteps] f32, mu-law codes [B,nsteps] i32, logits [B,nsteps,C] f32 or None).
+        Mixture-of-logistics decoder (head_mode "mol"; `cond` = encoding_w_condition [B, frames, cond_channels] when the
+        stack is conditioned): returns (audio, selected mixture, logits [B,nsteps,4M])."""
         import ctypes as C
         from . import _lib
-        if self.o_gen is None or self.E or self.pooled:
-            raise NotImplementedError("generate: built for the unconditioned per-time-step teacher with R=64, S=256, K=2")
+        if self.o_gen is None or self.pooled:
+            raise NotImplementedError("generate: built for R=64, S=256, K=2 stacks with a per-time-step head")
         B = int(batch or self.B)
         dl = (C.c_int32 * self.L)(*self.dil)
         relems = int(_lib.load().srwn_generate_ring_elems(dl, self.L, self.R))
@@ -704,13 +706,37 @@ class WaveNetEngine:
             fp = forced.data_ptr()
         v = self.view
         K.reduce_partials(v("BS").reshape(-1), self.L, self.S, 1, True, 1.0, self.bs_sum.data_ptr(), 0)
-        _lib.call("srwn_generate", self.wptr(self.o_gen), self.wptr(self.o_skip_gen), self.wptr(self.o_w1),
-                  self.wptr(self.o_w2), v("BF").data_ptr(), v("BR").data_ptr(), self.bs_sum.data_ptr(),
-                  v("head_b1").data_ptr(), v("head_b2").data_ptr(), v("init_w").data_ptr(), v("init_b").data_ptr(),
-                  ring.data_ptr(), audio.data_ptr(), codes.data_ptr(), None if logits is None else logits.data_ptr(),
-                  fp, dl, self.L, B, nsteps, nsteps, self.R, self.S, self.C, self.Kw,
-                  {"argmax": 0, "sample": 1}[mode], int(seed), K.abi_dtype(self.dt),
-                  torch.cuda.current_stream().cuda_stream)
+        common = (self.wptr(self.o_gen), self.wptr(self.o_skip_gen), self.wptr(self.o_w1), self.wptr(self.o_w2),
+                  v("BF").data_ptr(), v("BR").data_ptr(), self.bs_sum.data_ptr(), v("head_b1").data_ptr(),
+                  v("head_b2").data_ptr(), v("init_w").data_ptr(), v("init_b").data_ptr(), ring.data_ptr(),
+                  audio.data_ptr(), codes.data_ptr(), None if logits is None else logits.data_ptr(), fp, dl, self.L, B,
+                  nsteps, nsteps, self.R, self.S)
+        md = {"argmax": 0, "mean": 0, "sample": 1}[mode]
+        st = torch.cuda.current_stream().cuda_stream
+        if self.mol:
+            cond_all, frames = None, 1
+            if self.E:
+                if cond is None:
+                    raise ValueError("this decoder is conditioned: pass cond [batch, frames, cond_channels]")
+                cond = cond.to(device=self.dev, dtype=torch.float32)
+                frames = cond.shape[1]
+                if tuple(cond.shape) != (B, frames, self.E) or frames * self.cfg.pool_stride < nsteps:
+                    raise ValueError("cond must be [batch, frames >= nsteps/pool_stride, %d]" % self.E)
+                cin = torch.zeros((B * frames, self.Ep), dtype=self.dt, device=self.dev)
+                cin[:, :self.E].copy_(cond.reshape(B * frames, self.E))
+                cond_all = torch.empty((B * frames, self.L * self.R), dtype=self.dt, device=self.dev)
+                K.pw_linear(cin.data_ptr(), self.Ep, 0, self.Ep, self.Ep, self.wptr(self.o_wc), v("BC").reshape(-1),
+                            cond_all, self.L * self.R, self.L * self.R, B * frames)          # model.py:180
+            elif cond is not None:
+                raise ValueError("this decoder is not conditioned")
+            _lib.call("srwn_generate_mol", *common, self.Kw, self.C // 4,
+                      None if cond_all is None else cond_all.data_ptr(), frames, self.cfg.pool_stride, self.L * self.R,
+                      md, int(seed), K.abi_dtype(self.dt), st)
+        else:
+            if self.E or cond is not None:
+                raise NotImplementedError("generate: the conditioned softmax teacher is not built (the conditioned "
+                                          "decoder of the reference has the mixture-of-logistics head)")
+            _lib.call("srwn_generate", *common, self.C, self.Kw, md, int(seed), K.abi_dtype(self.dt), st)
         return audio, codes, logits
 
     def capture_graphs(self):

@@ -229,16 +229,27 @@ class WaveNetTeacher(_EngineOwner):
         eng.forward()
         return np.float32(eng.loss.item())
 
-    def generate(self, batch_size, num_samples, mode="sample", seed=0, forced=None, return_logits=False):
+    def generate(self, batch_size, num_samples, mode="sample", seed=0, forced=None, return_logits=False,
+                 encoding=None, conditions=None):
         """Queue-cached autoregressive generation (the O(T L) replacement of the reference's O(T^2 L)
-        loop, teacher.py:140-171): returns audio [B, num_samples] float32 (mu-law decoded), or
-        (audio, codes, logits) when return_logits.  `forced` [B, num_samples] = teacher forcing."""
-        if self.use_encoding or self.head != "softmax":
-            raise NotImplementedError("generation: built for the unconditioned mu-law softmax teacher")
+        loop, teacher.py:140-171): returns audio [B, num_samples] float32, or (audio, codes, logits) when
+        return_logits.  `forced` [B, num_samples] = teacher forcing.  The softmax teacher emits mu-law decoded
+        samples; the mixture-of-logistics teacher (optionally conditioned on `encoding`) emits logistic samples."""
+        if self.head == "softmax" and self.use_encoding:
+            raise NotImplementedError("generation: the conditioned softmax teacher is not built")
         eng = self._primary or self._engine(1, self._default_length)
         f = None if forced is None else torch.as_tensor(np.asarray(forced, dtype=np.float32), device="cuda")
+        cond = None
+        if self.use_encoding:
+            if encoding is None:
+                raise ValueError("this teacher was built with use_encoding=True; pass encoding [B, frames, latent]")
+            cond = torch.as_tensor(np.asarray(encoding, dtype=np.float32), device="cuda")
+            if self.condition_size > 0:
+                c = torch.as_tensor(np.asarray(conditions, dtype=np.float32), device="cuda")
+                cond = torch.cat([cond, c[:, None, :].expand(-1, cond.shape[1], -1)], dim=2)
+            cond = cond.contiguous()
         a, c, lg = eng.generate(int(num_samples), mode=mode, seed=seed, forced=f, want_logits=return_logits,
-                                batch=int(batch_size))
+                                batch=int(batch_size), cond=cond)
         if return_logits:
             return a.cpu().numpy(), c.cpu().numpy(), lg.cpu().numpy()
         return a.cpu().numpy()
@@ -404,6 +415,26 @@ class WaveNetAutoEncoder(object):
         eng = self._stage(inputs, conditions)
         self._put_encoding(eng, encoding)
         return eng.dec.forward(want_logits=True, with_loss=False).cpu().numpy()
+
+    def generate(self, encoding, conditions=None, num_samples=None, mode="sample", seed=0):
+        """Queue-cached autoregressive sampling from the decoder given an encoding (the O(T L) replacement of the
+        reference's sample-by-sample loop over ``reconstruct_with_encoding``, generator.py:150-170 /
+        teacher.py:140-171): audio [B, num_samples] in [-1, 1]."""
+        e = torch.as_tensor(np.asarray(encoding, dtype=np.float32), device="cuda")
+        if e.ndim != 3 or e.shape[2] != self.latent_channels:
+            raise ValueError("encoding must be [batch, frames, latent_channels]")
+        B, frames = int(e.shape[0]), int(e.shape[1])
+        T = int(num_samples) if num_samples is not None else frames * self.pool_stride
+        if T > frames * self.pool_stride:
+            raise ValueError("num_samples %d exceeds frames * pool_stride = %d" % (T, frames * self.pool_stride))
+        if self.condition_size > 0:
+            if conditions is None:
+                raise ValueError("this auto-encoder was built with condition_size > 0; pass conditions")
+            c = torch.as_tensor(np.asarray(conditions, dtype=np.float32), device="cuda")
+            e = torch.cat([e, c[:, None, :].expand(-1, frames, -1)], dim=2)               # model.py:161-167
+        eng = self._eng or self._engine(B, frames * self.pool_stride)
+        a, _, _ = eng.dec.generate(T, mode=mode, seed=seed, batch=B, cond=e.contiguous())
+        return a.cpu().numpy()
 
     def mu_law(self, inputs, conditions=None):
         raise AttributeError("WaveNetAutoEncoder.mu_law reads self.targets, which the reference never defines "

@@ -95,3 +95,83 @@ def test_teacher_generate_api():
     assert audio.shape == (3, 300) and np.isfinite(audio).all() and np.abs(audio).max() <= 1.0
     a2, codes, logits = m.generate(3, 300, mode="sample", seed=7, return_logits=True)
     assert np.array_equal(audio, a2) and logits.shape == (3, 300, 256) and codes.dtype == np.int32
+
+
+def _gen_uniform(seed, u, t):
+    """Host replica of the kernel's counter-based generator (splitmix64 finaliser), for draw-for-draw checks."""
+    M64 = (1 << 64) - 1
+    x = (seed + 0x9E3779B97F4A7C15 * ((u * 0x100000001 + t + 1) & M64)) & M64
+    x ^= x >> 30; x = (x * 0xBF58476D1CE4E5B9) & M64
+    x ^= x >> 27; x = (x * 0x94D049BB133111EB) & M64
+    x ^= x >> 31
+    return np.float32((np.float32(x >> 40) + np.float32(0.5)) * np.float32(1.0 / 16777216.0))
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-3), (torch.bfloat16, 6e-2)])
+@pytest.mark.parametrize("B,T,M,E,pool", [(3, 256, 5, 6, 32), (33, 96, 10, 20, 16), (2, 200, 5, 0, 1)])
+def test_mol_decoder_incremental_equals_full_forward(dt, tol, B, T, M, E, pool):
+    """The conditioned mixture-of-logistics decoder (model.py:158-200): teacher-forced incremental logits equal the
+    full forward's; the emitted samples are sample_from_discretized_mix_logistic of those logits draw for draw."""
+    EG = sub("engine")
+    dil = [1, 2, 4, 8, 16, 32, 64, 1, 2, 5]
+    C = 4 * M
+    sp = O.init_stack_params(7, dil, 2, 64, 256, C, cond_channels=E, bias_scale=0.05)
+    cfg = EG.StackConfig(dilations=dil, dilation_channels=64, skip_channels=256, output_channels=C, cond_channels=E,
+                         pool_stride=pool if E else 1, shift_input=True, head_mode="mol", dtype=dt)
+    eng = EG.WaveNetEngine(cfg, B, T, DEV)
+    eng.load_oracle_params(sp)
+    rng = np.random.default_rng(3)
+    audio = O.synthetic_audio(B, T, seed=9)
+    cond = rng.standard_normal((B, T // pool, E)) if E else None
+    eng.set_inputs(dev(audio), None, None if cond is None else dev(cond))
+    full = eng.forward(want_logits=True).cpu().numpy()
+    a, sel, inc = eng.generate(T, mode="sample", seed=11, forced=dev(audio), want_logits=True,
+                               cond=None if cond is None else dev(cond))
+    inc = inc.cpu().numpy()
+    assert np.isfinite(inc).all() and rel_err(inc, full) < tol
+    if dt == torch.float32:
+        ref, _ = O.stack_forward(sp, audio.astype(np.float64), shift_input=True, cond=cond, pool_stride=pool if E else 1)
+        assert rel_err(inc, ref) < tol
+    # sampler, draw for draw, on the kernel's own logits
+    u1 = np.empty((B, T, M)); u2 = np.empty((B, T))
+    for b in range(B):
+        for t in range(0, T, 7):
+            for m in range(M):
+                u1[b, t, m] = 1e-5 + (1 - 2e-5) * float(_gen_uniform(11, b, t * (M + 1) + m))
+            u2[b, t] = 1e-5 + (1 - 2e-5) * float(_gen_uniform(11, b, t * (M + 1) + M))
+    want = O.mol_sample(inc[:, ::7].astype(np.float64), u1[:, ::7], u2[:, ::7])
+    got = a.cpu().numpy()[:, ::7]
+    close = np.abs(got - want) < 1e-3
+    assert close.mean() > 0.995          # (a Gumbel-max tie within fp32 rounding may pick another mixture)
+    assert np.abs(a.cpu().numpy()).max() <= 1.0 and int(sel.max()) < M and int(sel.min()) >= 0
+
+
+def test_mol_decoder_free_running_and_model_api(tmp_path):
+    """Free-running generation feeds its own samples back (closed loop); WaveNetAutoEncoder.generate wraps it."""
+    M = sub("model")
+    dil = [1, 2, 4, 8, 16]
+    B, T, pool, lat = 2, 256, 32, 8
+    ae = M.WaveNetAutoEncoder(input_size=T, condition_size=0, num_mixtures=5, dilations=dil, dilation_channels=64,
+                              skip_channels=256, latent_channels=lat, pool_stride=pool, dtype=torch.float32)
+    x = O.synthetic_audio(B, T, seed=2)
+    for _ in range(3):
+        ae.train(x)
+    enc = ae.encode(x)
+    g1 = ae.generate(enc, seed=5)
+    g2 = ae.generate(enc, seed=5)
+    g3 = ae.generate(enc, seed=6)
+    assert g1.shape == (B, T) and np.abs(g1).max() <= 1.0 and np.array_equal(g1, g2) and not np.array_equal(g1, g3)
+    # closed loop: teacher-forcing the decoder with the generated clip reproduces the same per-step logits, hence
+    # (same seed) the same samples
+    eng = ae._eng.dec
+    cond = torch.as_tensor(enc, device=DEV)
+    a, _, lg = eng.generate(T, mode="sample", seed=5, want_logits=True, cond=cond)
+    a2, _, lg2 = eng.generate(T, mode="sample", seed=5, forced=a, want_logits=True, cond=cond)
+    assert np.array_equal(a.cpu().numpy(), g1)
+    assert rel_err(lg2.cpu().numpy(), lg.cpu().numpy()) < 1e-4 and np.abs(a2.cpu().numpy() - a.cpu().numpy()).max() < 1e-4
+    # the slow path of the reference (generator.py:150-170): reconstruct_with_encoding on the prefix, one sample at a
+    # time, gives the same distribution parameters as the incremental kernel
+    lg_full = ae.get_logits(g1, enc)
+    assert rel_err(lg_full[:, :64], lg.cpu().numpy()[:, :64]) < 1e-3
+    with pytest.raises(ValueError):
+        ae.generate(enc[:, :, :3])          # wrong latent width

@@ -15,3 +15,17 @@ for dt in (torch.bfloat16, torch.float32):
         dt_s = time.perf_counter() - t0
         print("%s  B=%2d  %d steps in %.3f s -> %.1f us/step, RTF %.3f per stream (16 kHz), aggregate %.1fx real time"
               % (str(dt).split(".")[-1], B, n, dt_s, dt_s / n * 1e6, dt_s / n * 16000, B * n / 16000 / dt_s), flush=True)
+
+# the conditioned mixture-of-logistics decoder of WaveNetAutoEncoder (the teacher generator.py samples from)
+pool, lat, Mx = 125, 16, 10
+cfg = EG.StackConfig(dilations=dil, dilation_channels=64, skip_channels=256, output_channels=4 * Mx, cond_channels=lat,
+                     pool_stride=pool, shift_input=True, head_mode="mol", dtype=torch.bfloat16)
+eng = EG.WaveNetEngine(cfg, 1, pool, "cuda")
+for B in (1, 32, 2048):
+    n = 4000
+    cond = torch.randn((B, n // pool, lat), device="cuda")
+    eng.generate(250, batch=B, cond=cond[:, :2]); torch.cuda.synchronize()
+    t0 = time.perf_counter(); a, c, _ = eng.generate(n, mode="sample", seed=1, batch=B, cond=cond); torch.cuda.synchronize()
+    dt_s = time.perf_counter() - t0
+    print("bfloat16 MoL-%d decoder, conditioned  B=%2d  %d steps in %.3f s -> %.1f us/step, RTF %.3f per stream, aggregate %.1fx real time"
+          % (Mx, B, n, dt_s, dt_s / n * 1e6, dt_s / n * 16000, B * n / 16000 / dt_s), flush=True)
