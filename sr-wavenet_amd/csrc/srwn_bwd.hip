@@ -511,8 +511,10 @@ static int launch_wgrad(const WgradArgs& a, int nbatch, int pro, hipStream_t st)
 }
 
 extern "C" int32_t srwn_wgrad_slabs(int64_t rows) {
-  // ~2048 rows per slab, at most 256 slabs
-  int64_t n = (rows + 2047) / 2048;
+  // ~3072 rows per slab (swept 2048..6144 on config 2: fewer, longer slabs shrink the partial volume until the
+  // per-group launches stop filling the chip), at most 256 slabs
+  static const int64_t per = [] { const char* e = getenv("SRWN_WG_SLAB_ROWS"); int64_t v = e ? atoll(e) : 3072; return v < 256 ? 256 : v; }();
+  int64_t n = (rows + per - 1) / per;
   if (n < 1) n = 1;
   if (n > 256) n = 256;
   return (int32_t)n;
