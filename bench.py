@@ -24,7 +24,7 @@ import numpy as np
 import torch
 
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
-PEAK_HBM_GBS = 8000.0
+PEAK_HBM_GBS = 8000.0        # HBM3E peak (same guide); ~4.9 TB/s is what a plain copy kernel reaches (tools/micro/membench.hip)
 
 
 def algorithmic_flops(N, L, R, S, C, Kw):
@@ -139,12 +139,27 @@ def main():
     kflops = {"skip_sum": 2.0 * N * L * R * S, "wgrad_skip": 2.0 * N * L * R * S,
               "fwd_layers": 2.0 * N * L * (Kw * R * R + R * R), "bwd_layers": 2.0 * N * L * (Kw * R * R + R * R + R * S),
               "head_1x1": 2.0 * N * S * S, "head_softmax_ce": 2.0 * N * S * C, "bwd_head": 2.0 * N * (S * C + S * S)}
+    # Dominant kernel = the fused layer data-gradient kernel (layer_bwd_kernel): 31 launches per step, the largest
+    # share of the step, HBM-bound.  Algorithmic bytes per launch: per sample and layer it reads
+    # G_{l+2}, df_{l+1}, dcs_l, z_l and writes G_{l+1}, df_l = 6 x R x 2 B (bf16) = 768 B.  `traffic` is the PMC
+    # measurement of the same kernel (profiles/r01_d_hbm_traffic.md: FETCH_SIZE x2-corrected + WRITE_SIZE).
+    es = 2 if args.dtype == "bf16" else 4
+    step_ms = 1e3 * dt_s / args.steps
+    bwd_launch_ms = spans["bwd_layers"] / (L + 1)          # L DOWN(+UP) launches + the UP-only launch below layer 0
+    bwd_bytes = 6.0 * R * es * N
+    ach_bw = bwd_bytes / (bwd_launch_ms * 1e-3) / 1e9
+    roofline = {"kernel": "layer_bwd_kernel", "bound": "hbm", "achieved": ach_bw, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": ach_bw / PEAK_HBM_GBS, "traffic": 100.3e6 if (args.dtype == "bf16" and (B, T, R, S) == (8, 16000, 64, 256)) else None,
+                "bytes_per_launch": bwd_bytes, "launch_us": 1e3 * bwd_launch_ms, "launches_per_step": L + 1,
+                "share_of_step": spans["bwd_layers"] / step_ms,
+                "whole_step_mfma_frac": fl["per_step"] / (dt_s / args.steps) / 1e12 / PEAK_BF16_TFLOPS,
+                "spans_ms": spans}
+    # the largest single kernel by FLOPs: the skip sum as one K = L*R contraction (row-streaming MFMA GEMM)
     dom = max((k for k in spans if k in ("skip_sum", "wgrad_skip")), key=lambda k: spans[k])
     achieved = kflops[dom] / (spans[dom] * 1e-3) / 1e12
-    roofline = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
-                "whole_step_frac": fl["per_step"] / (dt_s / args.steps) / 1e12 / PEAK_BF16_TFLOPS,
-                "spans_ms": spans}
+    roofline_gemm = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / PEAK_BF16_TFLOPS,
+                     "traffic": 546.6e6 if (dom == "skip_sum" and args.dtype == "bf16" and (B, T, R, S, L) == (8, 16000, 64, 256, 30)) else None}
 
     if rank == 0:
         out = {
@@ -157,6 +172,7 @@ def main():
                        "global_batch": world * B, "seq_len": T, "parallelism": "dp%d" % world,
                        "launch": "hipGraph" if use_graph else "eager", "final_loss": loss},
             "roofline": roofline,
+            "roofline_gemm": roofline_gemm,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(dil, R, S, C, threads=min(os.cpu_count() or 1, 16))

