@@ -173,6 +173,39 @@ __global__ void causal_conv_kernel(const float* __restrict__ x, const float* __r
     if (o0 + q < Cout) yr[q] = (TOut)acc[q];
 }
 
+// Cin = 1 (the input conv of every stack, model.py:40,173,424): 8 output channels per thread, one 16-byte store (bf16)
+template <typename TOut>
+__global__ __launch_bounds__(256) void causal_conv_cin1_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, TOut* __restrict__ y,
+                                                               int B, int T, int Cout, int K, int dilation, int shift) {
+  const int lpr = Cout / 8;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t row = idx / lpr;
+  const int sub = (int)(idx % lpr);
+  if (row >= (int64_t)B * T) return;
+  const int t = (int)(row % T);
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = bias ? bias[8 * sub + j] : 0.0f;
+  for (int k = 0; k < K; ++k) {
+    const int tk = t - (K - 1 - k) * dilation - shift;
+    if (tk < 0 || tk >= T) continue;
+    const float xv = x[row - t + tk];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = fmaf(xv, w[k * Cout + 8 * sub + j], v[j]);
+  }
+  TOut* yr = y + row * Cout + 8 * sub;
+  if (sizeof(TOut) == 2) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (bf16_t)v[j];
+    *reinterpret_cast<bf16x8*>(yr) = r;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) yr[j] = (TOut)v[j];
+  }
+}
+
 extern "C" int srwn_causal_conv1d_fwd(const float* x, const float* w, const float* bias, void* y, int32_t B,
                                       int32_t T, int32_t Cin, int32_t Cout, int32_t K, int32_t dilation,
                                       int32_t shift, int32_t dtype_out, void* stream) {
@@ -181,6 +214,17 @@ extern "C" int srwn_causal_conv1d_fwd(const float* x, const float* w, const floa
   if (B < 0 || T < 0 || Cin < 1 || Cout < 1 || K < 1 || dilation < 1 || shift <= -T || shift >= T)
     return set_error(SRWN_E_SHAPE, "causal_conv1d_fwd: B=%d T=%d Cin=%d Cout=%d K=%d d=%d shift=%d", B, T, Cin, Cout,
                      K, dilation, shift);
+  if (Cin == 1 && Cout % 8 == 0 && (dtype_out == SRWN_F32 || dtype_out == SRWN_BF16)) {
+    const int64_t tot = (int64_t)B * T * (Cout / 8);
+    dim3 g1((unsigned)((tot + 255) / 256)), b1(256);
+    if (dtype_out == SRWN_F32)
+      hipLaunchKernelGGL(causal_conv_cin1_kernel<float>, g1, b1, 0, (hipStream_t)stream, x, w, bias, (float*)y, B, T, Cout,
+                         K, dilation, shift);
+    else
+      hipLaunchKernelGGL(causal_conv_cin1_kernel<bf16_t>, g1, b1, 0, (hipStream_t)stream, x, w, bias, (bf16_t*)y, B, T,
+                         Cout, K, dilation, shift);
+    return check_launch("causal_conv1d_fwd");
+  }
   int64_t total = (int64_t)B * T * ((Cout + 3) / 4);
   dim3 grid((unsigned)((total + 255) / 256)), block(256);
   if (dtype_out == SRWN_F32)
@@ -216,10 +260,11 @@ __global__ __launch_bounds__(256) void init_conv_wgrad_stage1(const float* __res
   for (int k = 0; k < 9; ++k)
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[k][e] = 0.0f;
+  const int t_block = (int)(r0 % Tlen);   // one 64-bit modulo per block; rows inside use 32-bit arithmetic
   for (int rr = rg; rr < kIcRows; rr += nrg) {
     const int64_t row = r0 + rr;
     if (row >= rows) break;
-    const int t = (int)(row % Tlen);
+    const int t = (t_block + rr) % Tlen;
     float gv[8];
     const T* gp = g + row * R + cg * 8;
     if (sizeof(T) == 2) {
