@@ -81,10 +81,13 @@ int srwn_init_conv_wgrad(const float* audio, const void* g, float* partials, flo
 
 /* ---- fused residual layer forward: ResidualDilationLayer (ops.py:23-46) for K=2 taps, with the
  * decoder's conditioning add (model.py:180-183; NN upsample ops.py:64-74 as t/pool_stride) fused in.
- *   xin = x + cond[b, t/pool_stride, :]          (cond may be NULL)
- *   z   = tanh(conv_K(xin) + bias_f)             -> z_out  (saved for skip GEMM and backward)
- *   c   = z * sigmoid(z)                          (ops.py:33: the gate conv result is discarded)
- *   h   = (xin + c @ Wr + bias_r) * sqrt(.5)      -> h_out
+ * x is the layer's COMPLETE input (the conditioning bias of this layer already added); the kernel adds the NEXT
+ * layer's bias to what it stores, so no consumer (taps, residual base, weight gradients, the generator's rings)
+ * ever re-adds it:
+ *   z   = tanh(conv_K(x) + bias_f)                          -> z_out  (saved for skip GEMM and backward)
+ *   c   = z * sigmoid(z)                                     (ops.py:33: the gate conv result is discarded)
+ *   h   = (x + c @ Wr + bias_r) * sqrt(.5) + cond_next[b, t/pool_stride, :]   -> h_out   (cond_next may be NULL)
+ * The first layer's bias is added to the input conv's output by srwn_add_frame_bias.
  * The skip 1x1 (ops.py:44) is deferred to srwn_pw_linear over the stored z of all layers.
  * wconv: packed [R/32][K*R/16] (last tap permuted k order), wres: packed [R/32][R/16] (permuted).
  * cond rows are cond_row_stride elements apart (one [B*frames, L*R] product serves every layer). */
@@ -160,6 +163,9 @@ int srwn_reduce_partials(const float* partials, int32_t nslabs, int64_t n, int32
                          float scale, float* out, int64_t out_batch_stride, void* stream);
 
 /* ---- adjoint of ResizeEmbeddingNearestNeighbor (ops.py:64-74): out[b,e,c] = sum_{t in frame e} g[b,t,c] */
+/* x[b,t,c] += bias[b, t/pool_stride, c] in place (h = h + upsampled, model.py:181-183, for the first layer) */
+int srwn_add_frame_bias(void* x, const void* bias, int64_t bias_row_stride, int32_t B, int32_t T, int32_t C,
+                        int32_t frames, int32_t pool_stride, int32_t dtype, void* stream);
 int srwn_frame_sum(const void* g, void* out, int32_t B, int32_t T, int32_t C, int32_t frames, int32_t pool_stride,
                    int32_t dtype, void* stream);
 /* the same for `nbatch` layers in one launch: g + l*g_batch_stride -> out + l*out_batch_stride (elements), times

@@ -716,3 +716,42 @@ extern "C" int srwn_frame_sum(const void* g, void* out, int32_t B, int32_t T, in
                               int32_t pool_stride, int32_t dtype, void* stream) {
   return srwn_frame_sum_batched(g, 0, out, 0, 1, B, T, C, frames, pool_stride, 1.0f, dtype, stream);
 }
+
+// x[b,t,c] += bias[b, t/pool, c] in place: the first layer's conditioning bias on the input conv's output
+// (model.py:181-183); every later layer receives its bias from the layer below (srwn_residual_layer_fwd).
+template <typename T>
+__global__ __launch_bounds__(256) void add_frame_bias_kernel(T* __restrict__ x, const T* __restrict__ bias,
+                                                             int64_t bias_row_stride, int Tlen, int C, int frames,
+                                                             int pool, int64_t rows) {
+  const int lpr = C / 8;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t row = idx / lpr;
+  const int sub = (int)(idx % lpr);
+  if (row >= rows) return;
+  const int64_t b = row / Tlen;
+  const int t = (int)(row - b * Tlen);
+  float v[8], c[8];
+  FsRow<T>::load(x + row * C + 8 * sub, v);
+  FsRow<T>::load(bias + (b * frames + min(t / pool, frames - 1)) * bias_row_stride + 8 * sub, c);
+  T* d = x + row * C + 8 * sub;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) d[j] = (T)(v[j] + c[j]);
+}
+
+extern "C" int srwn_add_frame_bias(void* x, const void* bias, int64_t bias_row_stride, int32_t B, int32_t T, int32_t C,
+                                   int32_t frames, int32_t pool_stride, int32_t dtype, void* stream) {
+  if (B == 0 || T == 0) return 0;
+  if (!x || !bias) return set_error(SRWN_E_NULL, "add_frame_bias: null pointer");
+  if (B < 0 || T < 0 || C < 8 || C % 8 || frames < 1 || pool_stride < 1 || bias_row_stride < C)
+    return set_error(SRWN_E_SHAPE, "add_frame_bias: B=%d T=%d C=%d frames=%d pool=%d", B, T, C, frames, pool_stride);
+  const int64_t rows = (int64_t)B * T;
+  dim3 grid((unsigned)((rows * (C / 8) + 255) / 256)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SRWN_BF16)
+    hipLaunchKernelGGL(add_frame_bias_kernel<bf16_t>, grid, block, 0, st, (bf16_t*)x, (const bf16_t*)bias, bias_row_stride, T, C, frames, pool_stride, rows);
+  else if (dtype == SRWN_F32)
+    hipLaunchKernelGGL(add_frame_bias_kernel<float>, grid, block, 0, st, (float*)x, (const float*)bias, bias_row_stride, T, C, frames, pool_stride, rows);
+  else
+    return set_error(SRWN_E_DTYPE, "add_frame_bias: dtype %d", dtype);
+  return check_launch("add_frame_bias");
+}

@@ -121,13 +121,7 @@ __global__ __launch_bounds__(256) void layer_fwd_kernel(const T* __restrict__ x,
       const T* img = ximg + (buf * K + k) * TILE_E;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        Frag<T> f = xfrag<R>(img, col, ks, half);
-        if (COND) {
-          const T* cr = cb + (size_t)((valid ? tk : 0) / pool) * cond_stride;
-          const Frag<T> c = load_nat(cr + 16 * ks + 8 * half);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) f.set(j, f.get(j) + c.get(j));
-        }
+        const Frag<T> f = xfrag<R>(img, col, ks, half);
         cur[k][ks] = valid ? f : zero_frag<T>();
       }
     }
@@ -185,15 +179,12 @@ __global__ __launch_bounds__(256) void layer_fwd_kernel(const T* __restrict__ x,
       for (int mt = 0; mt < RT; ++mt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          f32x4 xv = xquad<R>(img, col, 32 * mt + 8 * g + 4 * half);
-          if (COND) {
-            const f32x4 cv = load4(cb + (size_t)((ok ? tc : 0) / pool) * cond_stride + 32 * mt + 8 * g + 4 * half);
-            // match the fragment path: x + cond rounded to T before use
+          const f32x4 xv = xquad<R>(img, col, 32 * mt + 8 * g + 4 * half);
+          f32x4 cv = {0.f, 0.f, 0.f, 0.f};
+          if (COND)   // the NEXT layer's conditioning bias, so that the stored row is that layer's complete input
+            cv = load4(cb + (size_t)((ok ? tc : 0) / pool) * cond_stride + 32 * mt + 8 * g + 4 * half);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) xv[e] = (float)(T)(xv[e] + cv[e]);
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) hv[mt][4 * g + e] = (xv[e] + accR[mt][4 * g + e]) * kSqrtHalf;
+          for (int e = 0; e < 4; ++e) hv[mt][4 * g + e] = (xv[e] + accR[mt][4 * g + e]) * kSqrtHalf + cv[e];
         }
       store_rows_via_lds<T, RT>(stage, htile, R, hv, rows_valid, lane);
     }

@@ -59,7 +59,7 @@ __device__ __forceinline__ float gen_uniform(unsigned long long seed, unsigned u
   return (float)((x >> 40) + 0.5) * (1.0f / 16777216.0f);   // (0,1)
 }
 
-template <typename T> struct GenCond { Frag<T> cd[4]; f32x4 cc[2][4]; };
+template <typename T> struct GenCond { f32x4 cc[2][4]; };
 struct GenNoCond {};
 
 template <typename T, int NBUF, bool COND>
@@ -121,12 +121,9 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a) {
     const T* rp = ring + a.ring_off[l] + ((size_t)slot * 32 + col) * R + 8 * half;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) p.xd[ks] = load_nat(rp + 16 * ks);
-    if constexpr (COND) {   // cb_l of the delayed tap's frame (fragment layout) and of the current frame (accumulator layout)
-      const int fd = min((td >= 0 ? td : 0) / a.pool, a.cond_frames - 1), fc = min(t / a.pool, a.cond_frames - 1);
-      const T* cdp = condp + ((size_t)ucl * a.cond_frames + fd) * a.cond_ld + (size_t)l * R + 8 * half;
+    if constexpr (COND) {   // cb_l of the current frame (accumulator layout); the ring holds conditioned inputs
+      const int fc = min(t / a.pool, a.cond_frames - 1);
       const T* ccp = condp + ((size_t)ucl * a.cond_frames + fc) * a.cond_ld + (size_t)l * R + 4 * half;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) p.cd[ks] = load_nat(cdp + 16 * ks);
 #pragma unroll
       for (int mt = 0; mt < RT; ++mt)
 #pragma unroll
@@ -177,13 +174,17 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a) {
       Frag<T> xd[KS];
       const bool tap0 = (t - d) >= 0;   // zero before the clip starts
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        Frag<T> f = p.xd[ks];
-        if constexpr (COND) {
+      for (int ks = 0; ks < KS; ++ks) xd[ks] = tap0 ? p.xd[ks] : zero_frag<T>();
+      if constexpr (COND) {
+        // the layer's complete input = output of the layer below + cb_l, rounded once (srwn_residual_layer_fwd adds
+        // the next layer's bias before storing); below layer 0 the input conv's output was stored (rounded) first
 #pragma unroll
-          for (int j = 0; j < 8; ++j) f.set(j, f.get(j) + p.cd[ks].get(j));   // T(x + cb) as in layer_fwd_kernel
-        }
-        xd[ks] = tap0 ? f : zero_frag<T>();
+        for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const float base = (l == 0) ? (float)(T)h[mt][q] : h[mt][q];
+            h[mt][q] = base + p.cc[mt][q >> 2][q & 3];
+          }
       }
       // x_l[t] -> ring (one writer), and as the permuted-order B fragments of tap 1
       Frag<T> xc[KS];
@@ -204,15 +205,6 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a) {
       for (int mt = 0; mt < RT; ++mt)
 #pragma unroll
         for (int q = 0; q < 16; ++q) h[mt][q] = xc[2 * mt + (q >> 3)].get(q & 7);
-      if constexpr (COND) {   // conv operand and residual base are T(x + cb) (the ring keeps the unconditioned x)
-#pragma unroll
-        for (int mt = 0; mt < RT; ++mt)
-#pragma unroll
-          for (int q = 0; q < 16; ++q) {
-            h[mt][q] = (float)(T)(h[mt][q] + p.cc[mt][q >> 2][q & 3]);
-            xc[2 * mt + (q >> 3)].set(q & 7, h[mt][q]);
-          }
-      }
 
       const Frag<T>* lw = reinterpret_cast<const Frag<T>*>(wbuf + buf * LAYER_B) + lane;
       f32x16 accF[RT];

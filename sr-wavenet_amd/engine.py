@@ -429,8 +429,7 @@ class WaveNetEngine:
         K.causal_conv1d_fwd(self.audio.view(B, T, 1), v("init_w"), v("init_b"), 1,
                             1 if self.cfg.shift_input else 0, out=self.xs[0])
         if self.E:
-            K.pw_linear(self.cond_in.data_ptr(), self.Ep, 0, self.Ep, self.Ep, self.wptr(self.o_wc),
-                        v("BC").reshape(-1), self.cond_all, L * R, L * R, B * self.frames)
+            self._cond_bias_to_input()
         with _Span(self, "fwd_layers"):
             for l in range(L):
                 self._layer_fwd(l, self.cond_all if self.E else None)   # layer l reads columns [l*R, (l+1)*R)
@@ -478,12 +477,24 @@ class WaveNetEngine:
              self.dmean.data_ptr(), B, S, C, Cp, st)
         return None
 
+    def _cond_bias_to_input(self):
+        """cb_l = 1x1(encoding_w_condition) of every layer as one product (model.py:180), and the first layer's bias
+        onto the input conv's output (model.py:181-183).  Every later layer receives its bias from the layer below:
+        xs[l] always holds layer l's complete input, so taps, residual base and weight gradients never re-add it."""
+        from ._lib import call
+        L, R = self.L, self.R
+        K.pw_linear(self.cond_in.data_ptr(), self.Ep, 0, self.Ep, self.Ep, self.wptr(self.o_wc),
+                    self.view("BC").reshape(-1), self.cond_all, L * R, L * R, self.B * self.frames)
+        call("srwn_add_frame_bias", self.xs[0].data_ptr(), self.cond_all.data_ptr(), L * R, self.B, self.T, R,
+             self.frames, self.cfg.pool_stride, K.abi_dtype(self.dt), torch.cuda.current_stream().cuda_stream)
+
     def _layer_fwd(self, l: int, cond_all: Optional[torch.Tensor]):
         v = self.view
-        cond3 = None if cond_all is None else cond_all.view(self.B, self.frames, self.L * self.R)
+        nxt = cond_all is not None and l + 1 < self.L      # the NEXT layer's conditioning bias goes onto the output
+        cond3 = cond_all.view(self.B, self.frames, self.L * self.R) if nxt else None
         K.residual_layer_fwd(self.xs[l], cond3, self.wptr(self.o_conv[l]), self.wptr(self.o_res[l]), v("BF")[l],
                              v("BR")[l], self.xs[l + 1], self.zs[l], self.Kw, self.dil[l], self.cfg.pool_stride,
-                             cond_channel_offset=l * self.R)
+                             cond_channel_offset=(l + 1) * self.R if nxt else 0)
 
     # ------------------------------------------------------------------------------------------
     # backward
@@ -563,10 +574,7 @@ class WaveNetEngine:
         N, L, R, T, ns = self.N, self.L, self.R, self.T, self.nslabs
         es = self.xs.element_size()
         NR = N * R
-        ckw = {}
-        if self.E:
-            ckw = dict(cond_ptr=self.cond_all.data_ptr() + l0 * R * es, cond_layer_stride=R,
-                       cond_frames=self.frames, pool_stride=self.cfg.pool_stride, cond_row_stride=L * R)
+        ckw = {}   # (xs already holds the conditioned inputs)
         with _Span(self, "wgrad_layers"):
             K.wgrad_layers(self.xs.view(L + 1, N, R)[l0:l1], self.zs.view(L, N, R)[l0:l1],
                            self.dfs.view(L, N, R)[l0:l1], self.gs.data_ptr() + (l0 + 1) * NR * es, self.dil[l0:l1],
@@ -588,12 +596,8 @@ class WaveNetEngine:
         for k in range(Kw):                                                          # dilated conv taps (legacy)
             shifts = [(Kw - 1 - k) * d for d in self.dil]
             last = k == Kw - 1
-            ckw = {}
-            if self.E:   # the conv input is the conditioned x + cb (model.py:183)
-                ckw = dict(cond_ptr=self.cond_all.data_ptr(), cond_batch_stride=R, cond_frames=self.frames,
-                           pool_stride=self.cfg.pool_stride, cond_row_stride=L * R)
             K.wgrad(xs_p, NR, R, dfs_p, NR, R, shifts, L, self.wg_parts, self.wg_bparts if last else None, N, T, ns,
-                    dt, **ckw)
+                    dt)                                  # (xs holds the conditioned conv inputs, model.py:183)
             K.reduce_partials(self.wg_parts, ns, R * R, L, True, 1.0, gp + 4 * (sec["WF"].offset + k * R * R),
                               Kw * R * R)
             if last:

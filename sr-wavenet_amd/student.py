@@ -181,8 +181,7 @@ class FlowStack(WaveNetEngine):
             self.audio = x_in
         x = self.audio
         K.causal_conv1d_fwd(x.view(B, T, 1), v("init_w"), v("init_b"), 1, 1, out=self.xs[0])   # model.py:423-424
-        K.pw_linear(self.cond_in.data_ptr(), self.Ep, 0, self.Ep, self.Ep, self.wptr(self.o_wc),
-                    v("BC").reshape(-1), self.cond_all, L * R, L * R, B * self.frames)           # model.py:431
+        self._cond_bias_to_input()                                                               # model.py:431-435
         with _Span(self, "flow_fwd_layers"):
             for l in range(L):
                 self._layer_fwd(l, self.cond_all)

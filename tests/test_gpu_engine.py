@@ -32,10 +32,7 @@ def _bwd_oracle_on_engine_forward(eng, sp, cond=None, pool=1):
     B, T, L = eng.B, eng.T, eng.L
     layers = []
     for l in range(L):
-        x = f(eng.xs[l])
-        if cond is not None:
-            cb = f(eng.cond_all).reshape(B, eng.frames, L, eng.R)[:, :, l, :]
-            x = x + np.repeat(cb, pool, axis=1)
+        x = f(eng.xs[l])          # the layer's complete input: the conditioning bias is already in it
         z = f(eng.zs[l]); sg = 1 / (1 + np.exp(-z))
         layers.append(dict(x=x, z=z, s=sg, c=z * sg, g=None))
     x0 = f(eng.audio)[:, :, None]

@@ -120,13 +120,20 @@ def test_residual_layer_fwd_cond(dt):
     rng = np.random.default_rng(2)
     xq = dev(rng.standard_normal((B, T, R)), dt)
     cbq = dev(rng.standard_normal((B, T // pool, R)), dt)
-    xin = xq.double().cpu().numpy() + np.repeat(cbq.double().cpu().numpy(), pool, axis=1)
-    dense, _, cache = O.residual_dilation_layer(xin, l, d)
+    # the kernel takes the layer's complete input and adds the NEXT layer's conditioning bias (model.py:181-183) to
+    # the row it stores; srwn_add_frame_bias puts the first layer's bias onto the input conv's output
+    dense, _, cache = O.residual_dilation_layer(xq.double().cpu().numpy(), l, d)
     buf, pc, pr = _pack_layer(K, l, R, dt)
     h = torch.empty((B, T, R), dtype=dt, device=DEV); z = torch.empty_like(h)
     K.residual_layer_fwd(xq, cbq, pc, pr, dev(l.bf), dev(l.br), h, z, 2, d, pool)
+    up = np.repeat(cbq.double().cpu().numpy(), pool, axis=1)
     assert rel_err(z.float().cpu().numpy(), cache["z"]) < TOL[dt]
-    assert rel_err(h.float().cpu().numpy(), dense) < TOL[dt]
+    assert rel_err(h.float().cpu().numpy(), dense + up) < TOL[dt]
+    x2 = xq.clone()
+    sub("_lib").call("srwn_add_frame_bias", x2.data_ptr(), cbq.data_ptr(), R, B, T, R, T // pool, pool, K.abi_dtype(dt),
+                     torch.cuda.current_stream().cuda_stream)
+    want = torch.tensor(xq.double().cpu().numpy() + up).to(dt).double().numpy()
+    assert np.array_equal(x2.double().cpu().numpy(), want)
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
