@@ -188,8 +188,10 @@ class FlowStack(WaveNetEngine):
         K.flow_affine_fwd(self.xs[L].view(N, R), v("flow_w"), v("flow_b"), x.view(N), self.prm, self.x_out,
                           self.ent_parts)                                                       # model.py:451-483
 
-    def backward(self, dx_out: torch.Tensor, ent_grad: float):
-        """dx_out [B*T] = d loss / d x_out; leaves d loss / d x_in in self.dx_in and parameter gradients."""
+    def backward(self, dx_out: torch.Tensor, ent_grad: float, join: bool = True):
+        """dx_out [B*T] = d loss / d x_out; leaves d loss / d x_in in self.dx_in and parameter gradients.
+        join=False leaves the weight-gradient work running on the side stream (the caller joins ``self.side`` later):
+        the flow below only needs dx_in, so its dgrad chain starts while this flow's weight gradients finish."""
         B, T, N, L, R, Kw = self.B, self.T, self.N, self.L, self.R, self.Kw
         dt = self.dt
         gp, sec = self.grads.data_ptr(), self.sections
@@ -219,12 +221,16 @@ class FlowStack(WaveNetEngine):
                         self._wgrad_layers_group(*group_lo[l])
             K.residual_layer_bwd(self.gs[1], self.dfs[0], self.wptr(self.o_convT[0]), self.gs[0],
                                  None, None, None, None, None, B, T, R, 0, Kw, self.dil[0], 1, False, dt)
+        if overlap:   # gs[0] (and every G_l for the conditioning gradients) is complete
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
         with torch.cuda.stream(side):
             self._wgrad_layers_finish()
-        self._wgrad_input_and_cond()
+            self._wgrad_input_and_cond()
         # through the input conv and RightShift to the flow input (model.py:423-424)
         K.causal_conv1d_dgrad(self.gs[0], self.view("init_w"), self.dx_in.view(B, T, 1), 1, shift=1, accumulate=True)
-        if overlap:
+        if overlap and join:
             main.wait_stream(side)
 
 
@@ -263,6 +269,8 @@ class StudentEngine:
         self.ce, self.power, self.logs = z(1), z(1), z(1)
         self.sq_parts = z(K.sumsq_partials(self.storage.grads.numel()))
         self.clip = z(2)                   # [combined gradient scale, global norm]
+        import os as _os
+        self.tstream = torch.cuda.Stream() if _os.environ.get("SRWN_OVERLAP", "1") != "0" else None
         self.ent_all = z(self.F, K.flow_partials(N))
         for i, f in enumerate(self.flows):  # flow i reads flow i-1's output in place
             f.audio = self.noise if i == 0 else self.flows[i - 1].x_out.view(B, T)
@@ -290,11 +298,19 @@ class StudentEngine:
         """Teacher logits on the truth clip, the flows, and the three loss terms (model.py:356-379)."""
         B, T, N = self.B, self.T, self.N
         tch = self.teacher
-        tch.forward(with_loss=False)                                   # logits32 [N, 4M] on RightShift(truth)
+        main = torch.cuda.current_stream()
+        if self.tstream is not None:   # the frozen teacher depends on (truth, encoding) only: run it beside the flows
+            self.tstream.wait_stream(main)
+            with torch.cuda.stream(self.tstream):
+                tch.forward(with_loss=False)                           # logits32 [N, 4M] on RightShift(truth)
+        else:
+            tch.forward(with_loss=False)
         self.forward_flows()
         K.stft_power(self.truth, None, self.fpow, self.pow_truth)      # model.py:360,367
         K.stft_power(self.out.view(B, T), self.spec, self.fpow, self.pow_out)
         K.power_loss(self.pow_truth, self.pow_out, self.gamma, 1.0 / B, self.dpow, self.power)
+        if self.tstream is not None:
+            main.wait_stream(self.tstream)
         K.mol_loss_dx(tch.logits32, self.out, tch.C // 4, self.ce_parts, self.dx, self.beta / B)   # model.py:374
         K.reduce_loss(self.ce_parts, self.ce_parts.numel(), 1.0, self.ce)
 
@@ -313,8 +329,12 @@ class StudentEngine:
              K._stream())
         g = self.dx
         for f in reversed(self.flows):
-            f.backward(g, -self.alpha / B)
+            f.backward(g, -self.alpha / B, join=False)
             g = f.dx_in
+        main = torch.cuda.current_stream()
+        for f in self.flows:   # every flow's weight gradients must be in before the norm / update
+            if f.side is not None and f.overlap and not f.timing and f.use_wl:
+                main.wait_stream(f.side)
 
     def allreduce_grads(self):
         dp.allreduce_sum_(self.storage.grads, self.pg)
