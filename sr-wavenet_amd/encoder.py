@@ -333,12 +333,13 @@ class AutoEncoderEngine:
 
     def backward(self):
         d, e = self.dec, self.enc
-        d.backward()
+        d.backward(join=False)   # its weight-gradient tail runs beside the encoder's backward
         # d loss / d encoding = sum_l dcb_l Wc_l^T restricted to the latent columns (model.py:180)
         call("srwn_small_gemm", d.dcb.data_ptr(), d.R, d.R, e.rows_c * d.R, K.abi_dtype(d.dt),
              d.view("WC").data_ptr(), 1, d.R, d.R, d.E * d.R, None, self.denc.data_ptr(), self.lat, K.F32, e.rows_c,
              self.lat, d.L * d.R, 0, K._stream())
         e.backward(self.denc)
+        d.join_side()
 
     def allreduce_grads(self):
         self.dec.allreduce_grads()

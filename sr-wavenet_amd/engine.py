@@ -499,8 +499,10 @@ class WaveNetEngine:
     # ------------------------------------------------------------------------------------------
     # backward
     # ------------------------------------------------------------------------------------------
-    def backward(self):
-        """Data gradients top-down on the current stream; weight gradients on a side stream as soon as their
+    def backward(self, join: bool = True):
+        """join=False leaves the weight-gradient passes running on ``self.side`` (the caller joins it before the
+        optimizer): work that only needs the data gradients can start right away.
+        Data gradients top-down on the current stream; weight gradients on a side stream as soon as their
         operands exist (skip/head kernels right after the head data gradients, per-layer kernels in groups
         behind the dgrad chain), so the bandwidth-bound wgrad passes fill the ramp/tail bubbles of the
         short per-layer dgrad kernels.  Joined before the optimizer.  SRWN_OVERLAP=0 serialises everything."""
@@ -548,8 +550,12 @@ class WaveNetEngine:
         with torch.cuda.stream(side):
             self._wgrad_layers_finish()
         self._wgrad_input_and_cond()
-        if overlap:
+        if overlap and join:
             main.wait_stream(side)
+
+    def join_side(self):
+        if self.side is not None and self.overlap and not self.timing:
+            torch.cuda.current_stream().wait_stream(self.side)
 
     def _wl_groups(self):
         import os as _os
