@@ -151,9 +151,11 @@ class WaveNetEngine:
         add("init_w", (Kw, 1, R)); add("init_b", (R,))
         add("WF", (L, Kw, R, R)); add("BF", (L, R))
         add("WR", (L, R, R)); add("BR", (L, R))
-        add("WS", (L, R, S)); add("BS", (L, S))
         if E:
             add("WC", (L, E, R)); add("BC", (L, R))
+        # the skip and head kernels come last: their gradients are final early in the backward pass and form the
+        # first all-reduce bucket (everything from WS to the end), the per-layer gradients above form the second
+        add("WS", (L, R, S)); add("BS", (L, S))
         add("head_w1", (S, S)); add("head_b1", (S,))
         add("head_w2", (S, Cp)); add("head_b2", (Cp,))   # padded to Cp columns (pad stays exactly zero)
         self.sections = secs
@@ -499,9 +501,12 @@ class WaveNetEngine:
     # ------------------------------------------------------------------------------------------
     # backward
     # ------------------------------------------------------------------------------------------
-    def backward(self, join: bool = True):
+    def backward(self, join: bool = True, part: int = 0):
         """join=False leaves the weight-gradient passes running on ``self.side`` (the caller joins it before the
         optimizer): work that only needs the data gradients can start right away.
+        part: 0 = the whole pass; 1 = head + dgrad chain down to layer ``self.split_layer`` and, on return, the skip /
+        head gradients are FINAL (first all-reduce bucket, ``grads[bucket_off:]``); 2 = the rest.  Splitting lets the
+        data-parallel step all-reduce the first bucket while part 2 runs.
         Data gradients top-down on the current stream; weight gradients on a side stream as soon as their
         operands exist (skip/head kernels right after the head data gradients, per-layer kernels in groups
         behind the dgrad chain), so the bandwidth-bound wgrad passes fill the ramp/tail bubbles of the
@@ -511,19 +516,22 @@ class WaveNetEngine:
         main = torch.cuda.current_stream()
         overlap = self.overlap and not self.timing
         side = self.side if overlap else main
-        self._bwd_head()
-        if overlap:
-            side.wait_stream(main)
-        with torch.cuda.stream(side):
-            self._wgrad_skip_and_head()
-        if self.use_dcs:
-            with _Span(self, "skip_dgrad_all"):
-                K.skip_dgrad_all(self.dtotal, self.wptr(self.o_skipT_all), self.dcs.view(L, N, R), R, S)
+        if part in (0, 1):
+            self._bwd_head()
+            if overlap:
+                side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._wgrad_skip_and_head()
+            if self.use_dcs:
+                with _Span(self, "skip_dgrad_all"):
+                    K.skip_dgrad_all(self.dtotal, self.wptr(self.o_skipT_all), self.dcs.view(L, N, R), R, S)
         # ---- residual stack, top down
         groups = self._wl_groups() if self.use_wl else []
         group_lo = {g[0]: g for g in groups}
-        span = _Span(self, "bwd_layers").__enter__()
-        for l in range(L - 1, -1, -1):
+        l_hi = self.split_layer - 1 if part == 2 else L - 1
+        l_lo = self.split_layer if part == 1 else 0
+        span = _Span(self, "bwd_layers" if part == 0 else "bwd_layers_part%d" % part).__enter__()
+        for l in range(l_hi, l_lo - 1, -1):
             has_up = l < L - 1
             g_in = self.gs[l + 2] if (has_up and l + 2 < L) else None
             K.residual_layer_bwd(g_in, self.dfs[l + 1] if has_up else None,
@@ -541,6 +549,11 @@ class WaveNetEngine:
                     side.wait_event(ev)
                 with torch.cuda.stream(side):
                     self._wgrad_layers_group(*group_lo[l])
+        if part == 1:
+            span.__exit__()
+            if overlap:
+                main.wait_stream(side)   # skip/head gradients (and the layer groups launched so far) are in
+            return
         K.residual_layer_bwd(self.gs[1] if L > 1 else None, self.dfs[0], self.wptr(self.o_convT[0]), self.gs[0],
                              None, None, None, None, None, B, T, R, S, Kw, self.dil[0], True, False, dt)
         span.__exit__()
@@ -561,6 +574,31 @@ class WaveNetEngine:
         import os as _os
         per = int(_os.environ.get("SRWN_WL_GROUP", "6"))
         return [(l0, min(l0 + per, self.L)) for l0 in range(0, self.L, per)]
+
+    @property
+    def split_layer(self) -> int:
+        """Where the two-part backward is cut: the layer-group boundary nearest 40 % of the depth (the part above it
+        outlasts the skip/head weight-gradient kernels running beside it)."""
+        los = [g[0] for g in self._wl_groups() if 0 < g[0] < self.L]
+        return min(los, key=lambda v: abs(v - 0.4 * self.L)) if los else 0
+
+    @property
+    def bucket_off(self) -> int:
+        return self.sections["WS"].offset
+
+    @property
+    def bucketed(self) -> bool:
+        """Two all-reduce buckets, the first overlapped with the lower part of the backward pass (needs the grouped
+        weight-gradient path and a deep enough stack)."""
+        import os as _os
+        forced = _os.environ.get("SRWN_FORCE_DIST") == "1"
+        mode = _os.environ.get("SRWN_BUCKETS", "auto")   # "0" off, "1" on, "auto": on for RCCL only (gloo's
+        if mode == "0" or not ((self.world > 1 or forced) and self.use_wl and self.split_layer > 0 and not self.pooled):
+            return False                                 # asynchronous CUDA all-reduce stalls for tens of ms)
+        if mode == "1":
+            return True
+        import torch.distributed as dist
+        return dist.is_initialized() and dist.get_backend(self.pg) == "nccl"
 
     def _bwd_head(self):
         B, T, N, S, Cp = self.B, self.T, self.N, self.S, self.Cp
@@ -686,11 +724,28 @@ class WaveNetEngine:
                     grad_scale=1.0 if self.mol else 1.0 / self.world)
         self.repack()
 
+    def _allreduce_bucket_a(self):
+        """Skip + head gradients: issued while the lower part of the backward pass runs."""
+        return dp.allreduce_sum_(self.grads[self.bucket_off:], self.pg, async_op=True)
+
+    def _allreduce_bucket_b(self, pending):
+        dp.allreduce_sum_(self.grads[:self.bucket_off], self.pg)
+        if pending is not None:
+            pending.wait()
+
     def train_step(self) -> torch.Tensor:
-        """fwd + bwd + (all-reduce) + Adam on the staged inputs; returns the device loss scalar."""
+        """fwd + bwd + (all-reduce) + Adam on the staged inputs; returns the device loss scalar.
+        With several ranks the gradient all-reduce runs in two buckets, the first (skip + head kernels, 65 % of the
+        bytes) overlapped with the lower part of the backward pass."""
         self.forward()
-        self.backward()
-        self.allreduce_grads()
+        if self.bucketed and not self.timing:
+            self.backward(part=1)
+            h = self._allreduce_bucket_a()
+            self.backward(part=2)
+            self._allreduce_bucket_b(h)
+        else:
+            self.backward()
+            self.allreduce_grads()
         self.optimizer_step()
         return self.loss
 
@@ -758,9 +813,14 @@ class WaveNetEngine:
         same launch-free kernel sequence.  Call after at least one eager train_step (warm-up)."""
         torch.cuda.synchronize()
         self._g_fb = torch.cuda.CUDAGraph()
+        self._g_b2 = None
         with torch.cuda.graph(self._g_fb):
             self.forward()
-            self.backward()
+            self.backward(part=1 if self.bucketed else 0)
+        if self.bucketed:   # {forward, upper backward} | bucket A in flight | {lower backward} | bucket B | {Adam}
+            self._g_b2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._g_b2, pool=self._g_fb.pool()):
+                self.backward(part=2)
         self._g_opt = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g_opt, pool=self._g_fb.pool()):
             self.optimizer_step()
@@ -768,6 +828,11 @@ class WaveNetEngine:
 
     def train_step_graphed(self) -> torch.Tensor:
         self._g_fb.replay()
-        self.allreduce_grads()
+        if self._g_b2 is not None:
+            h = self._allreduce_bucket_a()
+            self._g_b2.replay()
+            self._allreduce_bucket_b(h)
+        else:
+            self.allreduce_grads()
         self._g_opt.replay()
         return self.loss

@@ -250,3 +250,44 @@ def test_mol_kernel_branches():
     ref = O.mol_dlogits(x[None], l[None])[0]
     assert rel_err(dl[:, :4 * M].cpu().numpy(), ref) < 1e-3
     assert torch.all(dl[:, 3 * M:] == 0)
+
+
+def test_bucketed_allreduce_schedule_matches_plain_step(monkeypatch):
+    """Data-parallel schedule: {forward, upper backward} | all-reduce of the skip+head bucket in flight |
+    {lower backward} | all-reduce of the layer bucket | {Adam}.  With one rank the collectives are identities, so the
+    split schedule (eager and as three hipGraphs) must reproduce the plain step bit for bit."""
+    import socket
+    import torch.distributed as dist
+    EG = sub("engine")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("gloo", rank=0, world_size=1, init_method="tcp://127.0.0.1:%d" % port)
+    try:
+        dil = [1, 2, 4, 8, 16, 32] * 3
+        B, T, R, S, C = 2, 400, 64, 256, 256
+        audio = O.synthetic_audio(B, T, seed=3)
+        codes = O.mu_law_encode(audio, C)
+
+        def run(buckets, graph):
+            monkeypatch.setenv("SRWN_FORCE_DIST", "1")
+            monkeypatch.setenv("SRWN_BUCKETS", buckets)
+            cfg = EG.StackConfig(dilations=dil, dilation_channels=R, skip_channels=S, output_channels=C, shift_input=True,
+                                 dtype=torch.bfloat16, learning_rate=1e-3)
+            eng = EG.WaveNetEngine(cfg, B, T, DEV, seed=5)
+            assert eng.bucketed == (buckets == "1")
+            eng.set_inputs(dev(audio), dev(codes, torch.int32))
+            eng.train_step()
+            if graph:
+                eng.capture_graphs()
+                assert (eng._g_b2 is not None) == (buckets == "1")
+            for _ in range(3):
+                (eng.train_step_graphed if graph else eng.train_step)()
+            torch.cuda.synchronize()
+            return eng.params.clone(), float(eng.loss.item()), eng
+
+        p_plain, l_plain, e0 = run("0", False)
+        assert 0 < e0.split_layer < len(dil) and e0.bucket_off == e0.sections["WS"].offset
+        for graph in (False, True):
+            p, l, _ = run("1", graph)
+            assert torch.equal(p, p_plain) and l == l_plain, graph
+    finally:
+        dist.destroy_process_group()
