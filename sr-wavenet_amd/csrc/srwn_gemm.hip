@@ -348,7 +348,9 @@ namespace srwn {
 template <typename T, int MT, int KSC, int NT>
 static int launch_rg(const RgArgs& a, int pro, int epi, hipStream_t st) {
   constexpr int CHUNK_B = MT * KSC * (int)sizeof(Frag<T>) * 64;
-  const size_t sh = 2 * (size_t)CHUNK_B;
+  // the weight double buffer is reused as 4 private row stages in the epilogue: take the larger of the two
+  const size_t stage_b = (size_t)4 * 32 * RowStage<T>::stride(64) * sizeof(T);
+  const size_t sh = 2 * (size_t)CHUNK_B > stage_b ? 2 * (size_t)CHUNK_B : stage_b;
   constexpr int NTS = 1;   // softmax epilogue always one column tile per wave
   const int rows_per_block = 128 * ((epi == SRWN_EPI_SOFTMAX_CE) ? NTS : NT);
   dim3 grid((unsigned)((a.rows + rows_per_block - 1) / rows_per_block)), block(256);
@@ -402,8 +404,17 @@ int rowgemm_dispatch(const void* x, int64_t x_row_stride, int64_t x_chunk_stride
                      int cout_valid, int64_t rows, const void* aux, int64_t aux_row_stride, const int32_t* targets,
                      float* loss_partials, float* logits_out, float grad_scale, int pro, int epi, int dtype,
                      hipStream_t st, int* rc) {
-  if (cout_pad != 256 || (Cin % 64) != 0 || rows < 1) return 0;
+  if ((cout_pad != 256 && cout_pad != 128) || (Cin % 64) != 0 || rows < 1) return 0;
   if (epi != SRWN_EPI_SOFTMAX_CE && (cout_valid % 64) != 0) return 0;
+  if (cout_pad == 128) {   // 128-wide products (the reference scripts' skip_channels=128): 4 row tiles per wave
+    if (epi == SRWN_EPI_SOFTMAX_CE) return 0;
+    RgArgs a4{x, x_row_stride, x_chunk_stride, chunk_len, Cin / 16, wpack, bias, y, y_row_stride, cout_valid, rows,
+              aux, aux_row_stride, targets, loss_partials, logits_out, grad_scale, 0, 0, nullptr, 0, 0, 1, 0.0f};
+    if (dtype == SRWN_BF16) *rc = launch_rg<bf16_t, 4, 4, 1>(a4, pro, epi, st);
+    else if (dtype == SRWN_F32) *rc = launch_rg<float, 4, 2, 1>(a4, pro, epi, st);
+    else return 0;
+    return 1;
+  }
   RgArgs a{x, x_row_stride, x_chunk_stride, chunk_len, Cin / 16, wpack, bias, y, y_row_stride, cout_valid, rows,
            aux, aux_row_stride, targets, loss_partials, logits_out, grad_scale, 0, 0, nullptr, 0, 0, 1, 0.0f};
   static const int nt_bf16 = [] { const char* e = getenv("SRWN_RG_NT"); return (e && atoi(e) == 2) ? 2 : 1; }();

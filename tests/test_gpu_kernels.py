@@ -137,7 +137,8 @@ def test_residual_layer_fwd_cond(dt):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("Cin,Cout,rows", [(64, 256, 200), (256, 256, 70), (256, 32, 129), (32, 64, 64), (64, 96, 31)])
+@pytest.mark.parametrize("Cin,Cout,rows", [(64, 256, 200), (256, 256, 70), (256, 32, 129), (32, 64, 64), (64, 96, 31),
+                                           (128, 128, 300), (256, 128, 129), (64, 128, 1)])
 def test_pw_linear_relu(dt, Cin, Cout, rows):
     K = sub("kernels"); P = sub("packing")
     rng = np.random.default_rng(Cin + Cout)
