@@ -257,41 +257,54 @@ struct WgLArgs {
 
 namespace {
 
-constexpr int kLA = 192 + 16;   // LDS row stride of the A tile [x(t-d) | x(t) | c] in elements (16-B multiple)
-constexpr int kLD = 128 + 16;   // LDS row stride of the D tile [df | G]
-
-template <typename T, bool COND>
+// RC = residual channels (64, or 32 -- the width the reference's own scripts use): A tile [x(t-d) | x(t) | c], each
+// RC wide; D tile [df | G].  RC = 64: wave w owns conv row tile w (rows 32w.. of [xd|xc]) x both df column tiles and
+// dWr tile (w>>1, w&1).  RC = 32: waves 0/1 own the two conv row tiles, wave 2 the single dWr tile (the pass is
+// HBM-bound; the idle wave costs nothing), and 64 rows are staged per step so every thread still moves one vector.
+template <typename T, bool COND, int RC>
 __global__ __launch_bounds__(256) void wgrad_layer_kernel(WgLArgs a) {
+  constexpr int KR = (RC == 64) ? 32 : 64;      // rows staged per step
+  constexpr int LA = 3 * RC + 16, LD = 2 * RC + 16;   // LDS row strides (elements, 16-byte multiples)
+  constexpr int CT = RC / 32;                   // column tiles of df / G
   constexpr int VEC = 16 / sizeof(T);
-  constexpr int VPC = 64 / VEC;                 // 16-byte vectors per 64-channel row
-  constexpr int NV = kRows * VPC / 256;         // vectors per thread per 64-wide tensor tile (1 bf16, 2 f32)
+  constexpr int VPC = RC / VEC;                 // 16-byte vectors per RC-channel row
+  constexpr int NV = KR * VPC / 256;            // vectors per thread per tensor tile (1 bf16, 2 f32)
+  static_assert(NV >= 1, "staging shape");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  T* lds = reinterpret_cast<T*>(smem);          // [2 buffers][A tile kRows x kLA | D tile kRows x kLD]
-  auto tileA = [&](int buf) { return lds + (size_t)buf * kRows * (kLA + kLD); };
-  auto tileD = [&](int buf) { return lds + (size_t)buf * kRows * (kLA + kLD) + kRows * kLA; };
+  T* lds = reinterpret_cast<T*>(smem);          // [2 buffers][A tile KR x LA | D tile KR x LD]
+  auto tileA = [&](int buf) { return lds + (size_t)buf * KR * (LA + LD); };
+  auto tileD = [&](int buf) { return lds + (size_t)buf * KR * (LA + LD) + KR * LA; };
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int slab = blockIdx.x, layer = blockIdx.y;
   const int d = a.dil[layer];
   const int64_t r_begin = (int64_t)slab * a.rows_per_slab;
   const int64_t r_end = (r_begin + a.rows_per_slab < a.rows) ? r_begin + a.rows_per_slab : a.rows;
-  const int nit = (r_end > r_begin) ? (int)((r_end - r_begin + kRows - 1) / kRows) : 0;
+  const int nit = (r_end > r_begin) ? (int)((r_end - r_begin + KR - 1) / KR) : 0;
   const T* xb = reinterpret_cast<const T*>(a.x) + (int64_t)layer * a.layer_stride;
   const T* zb = reinterpret_cast<const T*>(a.z) + (int64_t)layer * a.layer_stride;
   const T* fb = reinterpret_cast<const T*>(a.df) + (int64_t)layer * a.layer_stride;
   const T* gb = reinterpret_cast<const T*>(a.g) + (int64_t)layer * a.layer_stride;
   const T* cb = COND ? reinterpret_cast<const T*>(a.cond) + (int64_t)layer * a.cond_layer_stride : nullptr;
+  // tile ownership
+  const bool has_conv = wave < 2 * CT;                       // conv row tile `wave` of [xd|xc]
+  const bool has_res = (RC == 64) ? true : (wave == 2);      // dWr tile (rt, ct)
+  const int res_rt = (RC == 64) ? (wave >> 1) : 0, res_ct = (RC == 64) ? (wave & 1) : 0;
 
-  f32x16 accF[2], accR;
+  f32x16 accF[CT], accR;
 #pragma unroll
-  for (int q = 0; q < 16; ++q) { accF[0][q] = 0.0f; accF[1][q] = 0.0f; accR[q] = 0.0f; }
-  float bsum = 0.0f;   // threads 0..63: colsum(df); 64..127: colsum(G)
+  for (int q = 0; q < 16; ++q) {
+#pragma unroll
+    for (int n = 0; n < CT; ++n) accF[n][q] = 0.0f;
+    accR[q] = 0.0f;
+  }
+  float bsum = 0.0f;   // threads 0..RC-1: colsum(df); RC..2RC-1: colsum(G)
 
   f32x4 rxd[NV], rxc[NV], rz[NV], rf[NV], rg[NV];
   f32x4 rcd[COND ? NV : 1], rcc[COND ? NV : 1];
   bool okd[NV];
   auto gload = [&](int it) {
-    const int64_t r0 = r_begin + (int64_t)it * kRows;
+    const int64_t r0 = r_begin + (int64_t)it * KR;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       const int idx = tid + v * 256;
@@ -303,11 +316,11 @@ __global__ __launch_bounds__(256) void wgrad_layer_kernel(WgLArgs a) {
       okd[v] = okr && (t - d >= 0);
       const int64_t rowd = (t - d >= 0) ? rowc - d : rowc;
       const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-      rxd[v] = *reinterpret_cast<const f32x4*>(xb + rowd * 64 + cv);
-      rxc[v] = *reinterpret_cast<const f32x4*>(xb + rowc * 64 + cv);
-      rz[v] = *reinterpret_cast<const f32x4*>(zb + rowc * 64 + cv);
-      rf[v] = *reinterpret_cast<const f32x4*>(fb + rowc * 64 + cv);
-      rg[v] = *reinterpret_cast<const f32x4*>(gb + rowc * 64 + cv);
+      rxd[v] = *reinterpret_cast<const f32x4*>(xb + rowd * RC + cv);
+      rxc[v] = *reinterpret_cast<const f32x4*>(xb + rowc * RC + cv);
+      rz[v] = *reinterpret_cast<const f32x4*>(zb + rowc * RC + cv);
+      rf[v] = *reinterpret_cast<const f32x4*>(fb + rowc * RC + cv);
+      rg[v] = *reinterpret_cast<const f32x4*>(gb + rowc * RC + cv);
       if (COND) {
         const int64_t bidx = rowc / a.Tlen;
         const int td = (t - d >= 0) ? t - d : t;
@@ -345,11 +358,11 @@ __global__ __launch_bounds__(256) void wgrad_layer_kernel(WgLArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) zc[e] = gate_of_z<T>(zc[e]);
       }
-      *reinterpret_cast<f32x4*>(ta + rr * kLA + cv) = xd;
-      *reinterpret_cast<f32x4*>(ta + rr * kLA + 64 + cv) = xc;
-      *reinterpret_cast<f32x4*>(ta + rr * kLA + 128 + cv) = zc;
-      *reinterpret_cast<f32x4*>(td + rr * kLD + cv) = rf[v];
-      *reinterpret_cast<f32x4*>(td + rr * kLD + 64 + cv) = rg[v];
+      *reinterpret_cast<f32x4*>(ta + rr * LA + cv) = xd;
+      *reinterpret_cast<f32x4*>(ta + rr * LA + RC + cv) = xc;
+      *reinterpret_cast<f32x4*>(ta + rr * LA + 2 * RC + cv) = zc;
+      *reinterpret_cast<f32x4*>(td + rr * LD + cv) = rf[v];
+      *reinterpret_cast<f32x4*>(td + rr * LD + RC + cv) = rg[v];
     }
   };
 
@@ -359,20 +372,21 @@ __global__ __launch_bounds__(256) void wgrad_layer_kernel(WgLArgs a) {
     const int buf = it & 1;
     if (it + 1 < nit) gload(it + 1);
     const T* ta = tileA(buf); const T* td = tileD(buf);
-    if (tid < 128) {
+    if (tid < 2 * RC) {
 #pragma unroll 8
-      for (int rr = 0; rr < kRows; ++rr) bsum += (float)td[rr * kLD + tid];
+      for (int rr = 0; rr < KR; ++rr) bsum += (float)td[rr * LD + tid];
     }
 #pragma unroll
-    for (int ks = 0; ks < kRows / 16; ++ks) {
-      const Frag<T> a_conv = Ld2<T>::load(ta, kLA, 16 * ks, 32 * wave, lane);           // rows 32w.. of [xd|xc]
-      const Frag<T> a_c = Ld2<T>::load(ta, kLA, 16 * ks, 128 + 32 * (wave >> 1), lane);  // c row tile
-      const Frag<T> b_f0 = Ld2<T>::load(td, kLD, 16 * ks, 0, lane);
-      const Frag<T> b_f1 = Ld2<T>::load(td, kLD, 16 * ks, 32, lane);
-      const Frag<T> b_g = Ld2<T>::load(td, kLD, 16 * ks, 64 + 32 * (wave & 1), lane);
-      mma(accF[0], a_conv, b_f0);
-      mma(accF[1], a_conv, b_f1);
-      mma(accR, a_c, b_g);
+    for (int ks = 0; ks < KR / 16; ++ks) {
+      if (has_conv) {
+        const Frag<T> a_conv = Ld2<T>::load(ta, LA, 16 * ks, 32 * wave, lane);          // rows 32w.. of [xd|xc]
+#pragma unroll
+        for (int n = 0; n < CT; ++n) mma(accF[n], a_conv, Ld2<T>::load(td, LD, 16 * ks, 32 * n, lane));
+      }
+      if (has_res) {
+        const Frag<T> a_c = Ld2<T>::load(ta, LA, 16 * ks, 2 * RC + 32 * res_rt, lane);  // c row tile
+        mma(accR, a_c, Ld2<T>::load(td, LD, 16 * ks, RC + 32 * res_ct, lane));
+      }
     }
     if (it + 1 < nit) lstore(buf ^ 1);
     __syncthreads();
@@ -380,16 +394,20 @@ __global__ __launch_bounds__(256) void wgrad_layer_kernel(WgLArgs a) {
 
   const int col = lane & 31, half = lane >> 5;
   const int64_t ls = (int64_t)layer * a.nslabs + slab;
-  float* pf = a.part_f + ls * (2 * 64 * 64);   // [k*64 + i][o]: conv row tile w covers rows 32w..32w+31
-  float* pr = a.part_r + ls * (64 * 64);
+  float* pf = a.part_f + ls * (2 * RC * RC);   // [k*RC + i][o]: conv row tile w covers rows 32w..32w+31
+  float* pr = a.part_r + ls * (RC * RC);
+  if (has_conv) {
 #pragma unroll
-  for (int n = 0; n < 2; ++n)
+    for (int n = 0; n < CT; ++n)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) pf[(int64_t)(32 * wave + crow(q, half)) * 64 + 32 * n + col] = accF[n][q];
+      for (int q = 0; q < 16; ++q) pf[(int64_t)(32 * wave + crow(q, half)) * RC + 32 * n + col] = accF[n][q];
+  }
+  if (has_res) {
 #pragma unroll
-  for (int q = 0; q < 16; ++q) pr[(int64_t)(32 * (wave >> 1) + crow(q, half)) * 64 + 32 * (wave & 1) + col] = accR[q];
-  if (tid < 64) a.part_bf[ls * 64 + tid] = bsum;
-  else if (tid < 128) a.part_br[ls * 64 + (tid - 64)] = bsum;
+    for (int q = 0; q < 16; ++q) pr[(int64_t)(32 * res_rt + crow(q, half)) * RC + 32 * res_ct + col] = accR[q];
+  }
+  if (tid < RC) a.part_bf[ls * RC + tid] = bsum;
+  else if (tid < 2 * RC) a.part_br[ls * RC + (tid - RC)] = bsum;
 }
 
 }  // namespace
@@ -403,10 +421,11 @@ extern "C" int srwn_wgrad_layers(const void* x, const void* z, const void* df, c
   if (rows == 0 || nlayers == 0) return 0;
   if (!x || !z || !df || !g || !dilations || !part_f || !part_r || !part_bf || !part_br)
     return set_error(SRWN_E_NULL, "wgrad_layers: null pointer");
-  if (R != 64 || K != 2) return set_error(SRWN_E_UNSUPPORTED, "wgrad_layers: built for R=64, K=2 (got R=%d K=%d)", R, K);
+  if ((R != 64 && R != 32) || K != 2)
+    return set_error(SRWN_E_UNSUPPORTED, "wgrad_layers: built for R=64 or 32, K=2 (got R=%d K=%d)", R, K);
   if (nlayers < 0 || nlayers > 64 || rows < 0 || T < 1 || rows % T || nslabs < 1)
     return set_error(SRWN_E_SHAPE, "wgrad_layers: nlayers=%d rows=%lld T=%d nslabs=%d", nlayers, (long long)rows, T, nslabs);
-  if (cond && (pool_stride < 1 || cond_row_stride < 64 || (int64_t)cond_frames * pool_stride < T))
+  if (cond && (pool_stride < 1 || cond_row_stride < R || (int64_t)cond_frames * pool_stride < T))
     return set_error(SRWN_E_SHAPE, "wgrad_layers: cond frames %d x pool %d < T %d", cond_frames, pool_stride, T);
   WgLArgs a;
   a.x = x; a.z = z; a.df = df; a.g = g; a.layer_stride = layer_stride;
@@ -414,8 +433,9 @@ extern "C" int srwn_wgrad_layers(const void* x, const void* z, const void* df, c
   a.pool = pool_stride > 0 ? pool_stride : 1; a.cond_stride = cond_row_stride;
   a.part_f = part_f; a.part_r = part_r; a.part_bf = part_bf; a.part_br = part_br;
   a.rows = rows; a.Tlen = T; a.nslabs = nslabs;
+  const int kr = (R == 64) ? 32 : 64;
   int64_t rps = (rows + nslabs - 1) / nslabs;
-  rps = (rps + kRows - 1) / kRows * kRows;
+  rps = (rps + kr - 1) / kr * kr;
   a.rows_per_slab = (int)rps;
   for (int i = 0; i < 64; ++i) a.dil[i] = (i < nlayers) ? dilations[i] : 1;
   for (int i = 0; i < nlayers; ++i)
@@ -424,8 +444,8 @@ extern "C" int srwn_wgrad_layers(const void* x, const void* z, const void* df, c
   hipStream_t st = (hipStream_t)stream;
 #define SRWN_WL(TT, C)                                                                                         \
   {                                                                                                            \
-    auto kfn = wgrad_layer_kernel<TT, C>;                                                                      \
-    const size_t sh = (size_t)2 * kRows * (kLA + kLD) * sizeof(TT);                                            \
+    auto kfn = (R == 64) ? wgrad_layer_kernel<TT, C, 64> : wgrad_layer_kernel<TT, C, 32>;                      \
+    const size_t sh = (size_t)2 * kr * (5 * R + 32) * sizeof(TT);                                              \
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
     if (e != hipSuccess) return set_error((int)e, "wgrad_layers: LDS %zu: %s", sh, hipGetErrorString(e));      \
     hipLaunchKernelGGL(kfn, grid, block, sh, st, a);                                                           \

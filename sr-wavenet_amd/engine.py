@@ -356,7 +356,7 @@ class WaveNetEngine:
         self.dfs = z(L, B, T, R)
         self.gs = z(L + 1, B, T, R)   # gs[L] is never written by the teacher: its last dense output is unused
         self.nslabs = K.wgrad_slabs(N)
-        self.use_wl = (R == 64 and self.Kw == 2)
+        self.use_wl = (R in (32, 64) and self.Kw == 2)
         if self.use_wl:
             ns = self.nslabs
             self.pl_f = z(L * ns * 2 * R * R, dt=torch.float32); self.pl_r = z(L * ns * R * R, dt=torch.float32)

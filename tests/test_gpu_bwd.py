@@ -213,10 +213,11 @@ def test_wgrad256(dt, mode, rows):
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("with_cond", [False, True])
-def test_wgrad_layers_fused(dt, with_cond):
+@pytest.mark.parametrize("R", [64, 32])
+def test_wgrad_layers_fused(dt, with_cond, R):
     """conv taps + 1x1 residual gradients of several layers in one pass (srwn_wgrad_layers)."""
     K = sub("kernels")
-    L, B, T, R, pool = 3, 2, 352, 64, 32
+    L, B, T, pool = 3, 2, 352, 32
     rows = B * T
     dil = [1, 16, 300]
     rng = np.random.default_rng(7)
