@@ -326,6 +326,9 @@ int srwn_stft_power_bwd(const float* spec, const float* dpower, float* dx, int32
  *                     out[1] = norm   (pre_scale = 1/world when the buffers hold an all-reduced SUM)
  *   srwn_adam_step_scaled: srwn_adam_step with grad_scale read from device memory; tick=0 shares one step
  *                     counter between several parameter buffers (tick it on the first call of a step only) */
+/* y += alpha * scale_dev[0] * x: accumulates per-row clipped gradients of the slow path ParallelWaveNet.train
+ * (model.py:599-632) with the clip factor of srwn_clip_scale left on the device */
+int srwn_axpy_dev(float* y, const float* x, const float* scale_dev, float alpha, int64_t n, void* stream);
 int64_t srwn_sumsq_partials(int64_t n);
 int srwn_sumsq(const float* g, int64_t n, float* partials, void* stream);
 int srwn_clip_scale(const float* partials, int64_t n, float clip_norm, float pre_scale, float* out, void* stream);

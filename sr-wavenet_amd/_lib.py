@@ -79,6 +79,7 @@ SIGNATURES = {
     "srwn_stft_power": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _p]),
     "srwn_power_loss": (C.c_int, [_p, _p, _i64, _f32, _f32, _p, _p, _p]),
     "srwn_stft_power_bwd": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _p]),
+    "srwn_axpy_dev": (C.c_int, [_p, _p, _p, _f32, _i64, _p]),
     "srwn_sumsq_partials": (_i64, [_i64]),
     "srwn_sumsq": (C.c_int, [_p, _i64, _p, _p]),
     "srwn_clip_scale": (C.c_int, [_p, _i64, _f32, _f32, _p, _p]),

@@ -362,7 +362,23 @@ __global__ __launch_bounds__(256) void clamp_bwd_kernel(const float* __restrict_
   if (i < n) dx[i] = (x[i] >= lo && x[i] <= hi) ? dy[i] : 0.0f;
 }
 
+// y += alpha * scale_dev[0] * x  (averaging per-row clipped gradients, model.py:614-618: the clip factor is on device)
+__global__ __launch_bounds__(256) void axpy_dev_kernel(float* __restrict__ y, const float* __restrict__ x,
+                                                       const float* __restrict__ scale_dev, float alpha, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) y[i] = fmaf(alpha * scale_dev[0], x[i], y[i]);
+}
+
 }  // namespace
+
+extern "C" int srwn_axpy_dev(float* y, const float* x, const float* scale_dev, float alpha, int64_t n, void* stream) {
+  if (n == 0) return 0;
+  if (!y || !x || !scale_dev) return set_error(SRWN_E_NULL, "axpy_dev: null pointer");
+  if (n < 0) return set_error(SRWN_E_SHAPE, "axpy_dev: n=%lld", (long long)n);
+  hipLaunchKernelGGL(axpy_dev_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, x,
+                     scale_dev, alpha, n);
+  return check_launch("axpy_dev");
+}
 
 extern "C" int srwn_clamp(const float* x, float* y, int64_t n, float lo, float hi, void* stream) {
   if (n == 0) return 0;

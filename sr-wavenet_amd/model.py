@@ -449,8 +449,8 @@ class ParallelWaveNet(object):
     the directory one was saved to (the reference takes the checkpoint directory and imports its meta graph,
     model.py:313-324).  The ``sess`` argument of
     every method is accepted for call compatibility with student.py and ignored (there is no session).
-    ``encode`` / ``reconstruct`` run the teacher auto-encoder (model.py:644-656).  ``train`` (the per-sample-clipped
-    slow path, model.py:603-632) is not built: student.py:107 uses ``train_fast``."""
+    ``encode`` / ``reconstruct`` run the teacher auto-encoder (model.py:644-656); ``train`` is the per-row-clipped
+    slow path (model.py:599-632), ``train_fast`` the one student.py:107 uses."""
 
     def __init__(self, input_size, condition_size, dilations, teacher, num_flows=2, filter_width=2,
                  dilation_channels=32, skip_channels=256, latent_channels=16, pool_stride=512,
@@ -610,8 +610,11 @@ class ParallelWaveNet(object):
         return np.float32(l["loss"]), np.float32(l["power_loss"])
 
     def train(self, sess, inputs, truth, encoding, conditions=None):
-        raise NotImplementedError("ParallelWaveNet.train (per-sample clipping, model.py:603-632) is not built; "
-                                  "student.py:107 trains with train_fast")
+        """The slow path (model.py:599-632): per-noise-row gradients, each clipped to norm 1, then averaged and
+        applied; returns (mean loss, mean power loss).  student.py:107 trains with ``train_fast``."""
+        eng = self._stage(inputs, truth, encoding, conditions)
+        l, p = eng.train_per_sample()
+        return np.float32(l), np.float32(p)
 
     def _ae_teacher(self, inputs):
         if self._teacher is None:

@@ -246,6 +246,7 @@ class StudentEngine:
             raise ValueError("flows and teacher share encoding_w_condition (model.py:318-324): cond_channels/pool_stride differ")
         self.teacher = teacher
         self.B, self.T, self.N = teacher.B, teacher.T, teacher.N
+        self.loss_div = float(self.B)      # the loss divides by the number of noise rows fed (model.py:379)
         self.dev = teacher.dev
         if K.stft_frames(self.T) < 1:
             raise ValueError("clips must hold at least one 512-sample STFT frame (model.py:360)")
@@ -308,17 +309,17 @@ class StudentEngine:
         self.forward_flows()
         K.stft_power(self.truth, None, self.fpow, self.pow_truth)      # model.py:360,367
         K.stft_power(self.out.view(B, T), self.spec, self.fpow, self.pow_out)
-        K.power_loss(self.pow_truth, self.pow_out, self.gamma, 1.0 / B, self.dpow, self.power)
+        K.power_loss(self.pow_truth, self.pow_out, self.gamma, 1.0 / self.loss_div, self.dpow, self.power)
         if self.tstream is not None:
             main.wait_stream(self.tstream)
-        K.mol_loss_dx(tch.logits32, self.out, tch.C // 4, self.ce_parts, self.dx, self.beta / B)   # model.py:374
+        K.mol_loss_dx(tch.logits32, self.out, tch.C // 4, self.ce_parts, self.dx, self.beta / self.loss_div)   # model.py:374
         K.reduce_loss(self.ce_parts, self.ce_parts.numel(), 1.0, self.ce)
 
     def losses(self) -> Dict[str, float]:
         """Host-side combination of the device scalars (model.py:356,371,375-379)."""
         ce, power, logs = float(self.ce.item()), float(self.power.item()), float(self.logs.item())
         entropy = logs + 2.0 * self.N
-        return dict(loss=(self.beta * ce - self.alpha * entropy + power) / self.B, power_loss=power,
+        return dict(loss=(self.beta * ce - self.alpha * entropy + power) / self.loss_div, power_loss=power,
                     entropy=entropy, cross_entropy=self.beta * ce)
 
     def backward(self):
@@ -329,7 +330,7 @@ class StudentEngine:
              K._stream())
         g = self.dx
         for f in reversed(self.flows):
-            f.backward(g, -self.alpha / B, join=False)
+            f.backward(g, -self.alpha / self.loss_div, join=False)
             g = f.dx_in
         main = torch.cuda.current_stream()
         for f in self.flows:   # every flow's weight gradients must be in before the norm / update
@@ -354,6 +355,41 @@ class StudentEngine:
         self.backward()
         self.allreduce_grads()
         self.optimizer_step()
+
+    def train_per_sample(self):
+        """``ParallelWaveNet.train`` (model.py:599-632), the slow path: for every noise row i the graph is run with
+        ``inputs = [noise_i]`` against the WHOLE batch of encodings and truths (the 1-row noise broadcasts over them,
+        ``h + upsampled`` at model.py:435), its loss divided by 1 row, its gradient clipped to norm 1 on its own;
+        the clipped gradients are averaged and applied without further clipping.  Returns (mean loss, mean power)."""
+        st = self.storage
+        if not hasattr(self, "_acc"):
+            self._acc = torch.zeros_like(st.grads)
+            self._noise_all = torch.zeros_like(self.noise)
+        self._noise_all.copy_(self.noise)
+        self._acc.zero_()
+        losses, powers = [], []
+        keep = self.loss_div
+        self.loss_div = 1.0
+        try:
+            for i in range(self.B):
+                self.noise.copy_(self._noise_all[i:i + 1].expand(self.B, -1))
+                self.forward()
+                self.backward()
+                K.sumsq(st.grads, self.sq_parts)
+                K.clip_scale(self.sq_parts, 1.0, 1.0, self.clip)
+                call("srwn_axpy_dev", self._acc.data_ptr(), st.grads.data_ptr(), self.clip.data_ptr(), 1.0 / self.B,
+                     st.grads.numel(), K._stream())
+                l = self.losses()
+                losses.append(l["loss"]); powers.append(l["power_loss"])
+        finally:
+            self.loss_div = keep
+            self.noise.copy_(self._noise_all)
+        st.grads.copy_(self._acc)
+        self.allreduce_grads()
+        K.adam_step(st.params, st.grads, st.adam_m, st.adam_v, st.adam_step, self.lr, grad_scale=1.0 / self.world)
+        for f in self.flows:
+            f.repack()
+        return float(np.mean(losses)), float(np.mean(powers))
 
     def capture_graphs(self):
         torch.cuda.synchronize()

@@ -249,3 +249,34 @@ def test_student_trains_and_graph_replay():
     torch.cuda.synchronize()
     assert torch.equal(a.storage.params, b.storage.params)
     assert a.losses()["loss"] == b.losses()["loss"]
+
+
+def test_student_slow_train_path():
+    """ParallelWaveNet.train (model.py:599-632): per noise row, the 1-row noise broadcasts over the whole batch of
+    encodings/truths, the loss divides by 1, the gradient is clipped on its own; the mean of the clipped gradients is
+    applied.  Checked against the oracle run the same way."""
+    stu, flows, noise, cond, truth, tl, pool, abg = _setup(torch.float32, 64, 256, 2)
+    B = noise.shape[0]
+    acc = None
+    ref_losses = []
+    for i in range(B):
+        ts = [OT.TorchStack(p) for p in flows]
+        ni = np.repeat(noise[i:i + 1], B, axis=0)
+        res = OT.student_loss(ts, torch.tensor(ni), torch.tensor(cond), pool, torch.tensor(tl), torch.tensor(truth), *abg)
+        loss = res["loss"] * B                       # the oracle divides by its batch; the reference by 1 row
+        loss.backward()
+        g = [v.grad.numpy() for st in ts for _, v in OT.flow_named(st)]
+        c, _ = O.clip_by_global_norm(g, 1.0)
+        acc = [a / B for a in c] if acc is None else [x + a / B for x, a in zip(acc, c)]
+        ref_losses.append(float(loss))
+    before = [{n: t.float().cpu().numpy().copy() for n, t in f.named_tensors().items()} for f in stu.flows]
+    l, p = stu.train_per_sample()
+    assert abs(l - np.mean(ref_losses)) < 1e-3 * abs(np.mean(ref_losses))
+    it = iter(acc)
+    for f, b in zip(stu.flows, before):
+        now = f.named_tensors()
+        for n, _ in OT.flow_named(OT.TorchStack(flows[0])):
+            gref = next(it)
+            want, _, _ = O.adam_step_tf(b[n], gref, np.zeros_like(gref), np.zeros_like(gref), 1, lr=1e-3)
+            assert np.abs(now[n].float().cpu().numpy() - want).max() < 3e-5, n
+    assert torch.equal(stu.noise, dev(noise))        # the staged batch is restored
