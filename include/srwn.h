@@ -203,6 +203,13 @@ int srwn_bcast_mask(const float* dmean, const void* r1, void* out, int32_t B, in
  * bias_partials[slab][n] = column sums of D (may be NULL).  nslabs = srwn_wgrad256_slabs(rows, m_chunks);
  * finish with srwn_reduce_partials. */
 int32_t srwn_wgrad256_slabs(int64_t rows, int32_t m_chunks);
+/* the same GEMM for the reference scripts' widths: A chunks of `chunk_width` = 64 or 32 channels
+ * (dilation_channels), D of `d_width` = 256 or 128 columns (skip_channels); m_chunks*chunk_width must be a
+ * multiple of 64; partials [slab][m_chunks*chunk_width][d_width]. */
+int32_t srwn_wgrad_wide_slabs(int64_t rows, int32_t m_chunks, int32_t chunk_width);
+int srwn_wgrad_wide(const void* a, int64_t a_chunk_stride, int64_t a_row_stride, int32_t m_chunks, int32_t chunk_width,
+                    const void* d, int64_t d_row_stride, int32_t d_width, float* partials, float* bias_partials,
+                    int64_t rows, int32_t nslabs, int32_t pro, int32_t dtype, void* stream);
 int srwn_wgrad256(const void* a, int64_t a_chunk_stride, int64_t a_row_stride, int32_t m_chunks, const void* d,
                   int64_t d_row_stride, float* partials, float* bias_partials, int64_t rows, int32_t nslabs,
                   int32_t pro, int32_t dtype, void* stream);

@@ -61,6 +61,8 @@ SIGNATURES = {
     "srwn_mol_loss": (C.c_int, [_p, _i64, _p, _i32, _p, _p, _i64, _i64, _f32, _i32, _p]),
     "srwn_wgrad256_slabs": (_i32, [_i64, _i32]),
     "srwn_wgrad256": (C.c_int, [_p, _i64, _i64, _i32, _p, _i64, _p, _p, _i64, _i32, _i32, _i32, _p]),
+    "srwn_wgrad_wide_slabs": (_i32, [_i64, _i32, _i32]),
+    "srwn_wgrad_wide": (C.c_int, [_p, _i64, _i64, _i32, _i32, _p, _i64, _i32, _p, _p, _i64, _i32, _i32, _i32, _p]),
     "srwn_tap_linear": (C.c_int, [_p, _i64, _i32, _i32, _i32, _i32, _p, _p, _p, _i64, _i32, _i64, _p, _i64, _p, _i64,
                                   _i32, _i32, _f32, _i32, _i32, _p]),
     "srwn_nc_input_fwd": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),

@@ -50,12 +50,14 @@ template <> struct Ld2<float> {
 };
 
 constexpr int kRows = 32;      // rows per staged chunk
-constexpr int kW = 256;        // tile width (channels) of both operands
 constexpr int kStride = 288;   // LDS row stride in elements: 576 B (bf16) puts 4 consecutive rows on disjoint banks
 
-template <typename T, int PRO, int MB>
+// DW = width of D (256, or 128 for the reference scripts' skip_channels); CW = width of one A chunk (64, or 32 for
+// their dilation_channels): the block still stages MB*64 A columns, i.e. MB*64/CW chunks.
+template <typename T, int PRO, int MB, int DW, int CW>
 __global__ __launch_bounds__(512) void wgrad256_kernel(Wg2Args a) {
-  constexpr int NTW = (MB == 4) ? 4 : 1;   // n-tiles per wave
+  constexpr int kW = DW;
+  constexpr int NTW = (MB == 4) ? DW / 64 : 1;   // n-tiles per wave (MB = 1: one tile per wave, waves >= DW/32 idle)
   constexpr int AW = MB * 64;                // staged A tile width (channels)
   constexpr int VEC = 16 / sizeof(T);
   constexpr int VPR = kW / VEC;                  // 16-byte vectors per D tile row
@@ -70,6 +72,7 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(Wg2Args a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (MB == 4) ? (wave >> 1) : 0;    // wave -> A chunk
   const int wn = (MB == 4) ? (wave & 1) : wave;  // wave -> group of NTW n-tiles
+  const bool wave_live = (MB == 4) || (wave < DW / 32);
   const int slab = blockIdx.x, mblk = blockIdx.y;
   const int64_t r_begin = (int64_t)slab * a.rows_per_slab;
   const int64_t r_end = (r_begin + a.rows_per_slab < a.rows) ? r_begin + a.rows_per_slab : a.rows;
@@ -95,9 +98,9 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(Wg2Args a) {
       const int idx = tid + v * 512;
       const int rr = idx / VPRA, cv = (idx % VPRA) * VEC;
       const int64_t row = r0 + rr;
-      const int chunk = mblk * MB + cv / 64;
+      const int chunk = (mblk * AW + cv) / CW;
       const bool ok = (idx < kRows * VPRA) && (row < r_end) && (chunk < a.m_chunks);
-      ra[v] = ok ? *reinterpret_cast<const f32x4*>(abase + (int64_t)chunk * a.a_chunk_stride + row * a.a_row_stride + (cv & 63))
+      ra[v] = ok ? *reinterpret_cast<const f32x4*>(abase + (int64_t)chunk * a.a_chunk_stride + row * a.a_row_stride + (cv % CW))
                  : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(Wg2Args a) {
       for (int rr = 0; rr < kRows; ++rr) bsum += (float)td[rr * kStride + tid];
     }
 #pragma unroll
-    for (int ks = 0; ks < kRows / 16; ++ks) {
+    for (int ks = 0; ks < (wave_live ? kRows / 16 : 0); ++ks) {
       Frag<T> af[2], bf[NTW];
 #pragma unroll
       for (int m = 0; m < 2; ++m) af[m] = Ld2<T>::load(ta, kStride, 16 * ks, wm * 64 + 32 * m, lane);
@@ -167,9 +170,10 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(Wg2Args a) {
   }
 
   const int col = lane & 31, half = lane >> 5;
-  const int chunk = mblk * MB + wm;
-  if (chunk < a.m_chunks) {
-    float* pbase = a.partials + ((int64_t)slab * a.m_chunks * 64 + (int64_t)chunk * 64) * kW;
+  const int64_t mrow0 = (int64_t)mblk * AW + wm * 64;          // first output row (flat A column) of this wave
+  const int64_t mtotal = (int64_t)a.m_chunks * CW;
+  if (wave_live && mrow0 < mtotal) {                             // (m_chunks*CW is a multiple of 64: host check)
+    float* pbase = a.partials + ((int64_t)slab * mtotal + mrow0) * kW;
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -184,11 +188,12 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(Wg2Args a) {
 
 }  // namespace
 
-static int wg2_chunks_per_block(int m_chunks) { return m_chunks >= 8 ? 4 : 1; }
+static int wg2_chunks_per_block(int m64) { return m64 >= 8 ? 4 : 1; }   // m64 = A width in units of 64 columns
 
-extern "C" int32_t srwn_wgrad256_slabs(int64_t rows, int32_t m_chunks) {
-  const int mb = wg2_chunks_per_block(m_chunks);
-  const int mblocks = (m_chunks + mb - 1) / mb;
+extern "C" int32_t srwn_wgrad_wide_slabs(int64_t rows, int32_t m_chunks, int32_t chunk_width) {
+  const int m64 = (int)(((int64_t)m_chunks * chunk_width + 63) / 64);
+  const int mb = wg2_chunks_per_block(m64);
+  const int mblocks = (m64 + mb - 1) / mb;
   int64_t target = 256 / (mblocks > 0 ? mblocks : 1);
   if (target < 1) target = 1;
   int64_t maxs = (rows + 255) / 256;   // at least 256 rows per slab
@@ -196,26 +201,47 @@ extern "C" int32_t srwn_wgrad256_slabs(int64_t rows, int32_t m_chunks) {
   return (int32_t)(target < maxs ? target : maxs);
 }
 
+extern "C" int32_t srwn_wgrad256_slabs(int64_t rows, int32_t m_chunks) { return srwn_wgrad_wide_slabs(rows, m_chunks, 64); }
+
 extern "C" int srwn_wgrad256(const void* a, int64_t a_chunk_stride, int64_t a_row_stride, int32_t m_chunks,
                              const void* d, int64_t d_row_stride, float* partials, float* bias_partials,
                              int64_t rows, int32_t nslabs, int32_t pro, int32_t dtype, void* stream) {
+  return srwn_wgrad_wide(a, a_chunk_stride, a_row_stride, m_chunks, 64, d, d_row_stride, 256, partials, bias_partials,
+                         rows, nslabs, pro, dtype, stream);
+}
+
+extern "C" int srwn_wgrad_wide(const void* a, int64_t a_chunk_stride, int64_t a_row_stride, int32_t m_chunks,
+                               int32_t chunk_width, const void* d, int64_t d_row_stride, int32_t d_width,
+                               float* partials, float* bias_partials, int64_t rows, int32_t nslabs, int32_t pro,
+                               int32_t dtype, void* stream) {
   if (rows == 0 || m_chunks == 0) return 0;
-  if (!a || !d || !partials) return set_error(SRWN_E_NULL, "wgrad256: null pointer");
-  if (rows < 0 || m_chunks < 0 || nslabs < 1 || d_row_stride < 256 || a_row_stride < 64)
-    return set_error(SRWN_E_SHAPE, "wgrad256: rows=%lld m_chunks=%d nslabs=%d strides a=%lld d=%lld", (long long)rows,
+  if (!a || !d || !partials) return set_error(SRWN_E_NULL, "wgrad_wide: null pointer");
+  if ((chunk_width != 64 && chunk_width != 32) || (d_width != 256 && d_width != 128))
+    return set_error(SRWN_E_UNSUPPORTED, "wgrad_wide: chunk_width %d (64, 32) / d_width %d (256, 128)", chunk_width, d_width);
+  if (rows < 0 || m_chunks < 0 || nslabs < 1 || d_row_stride < d_width || a_row_stride < chunk_width ||
+      ((int64_t)m_chunks * chunk_width) % 64)
+    return set_error(SRWN_E_SHAPE, "wgrad_wide: rows=%lld m_chunks=%d nslabs=%d strides a=%lld d=%lld", (long long)rows,
                      m_chunks, nslabs, (long long)a_row_stride, (long long)d_row_stride);
   Wg2Args g{a, a_chunk_stride, a_row_stride, m_chunks, d, d_row_stride, partials, bias_partials, rows, 0, nslabs};
   int64_t rps = (rows + nslabs - 1) / nslabs;
   rps = (rps + kRows - 1) / kRows * kRows;
   g.rows_per_slab = (int)rps;
-  const int mb = wg2_chunks_per_block(m_chunks);
-  dim3 grid((unsigned)nslabs, (unsigned)((m_chunks + mb - 1) / mb)), block(512);
+  const int m64 = (int)((int64_t)m_chunks * chunk_width / 64);
+  const int mb = wg2_chunks_per_block(m64);
+  dim3 grid((unsigned)nslabs, (unsigned)((m64 + mb - 1) / mb)), block(512);
   hipStream_t st = (hipStream_t)stream;
 #define SRWN_W2(TT, P)                                                                                        \
-  if (mb == 4) SRWN_W2B(TT, P, 4) else SRWN_W2B(TT, P, 1)
-#define SRWN_W2B(TT, P, MBV)                                                                                  \
+  if (mb == 4) SRWN_W2C(TT, P, 4) else SRWN_W2C(TT, P, 1)
+#define SRWN_W2C(TT, P, MBV)                                                                                  \
   {                                                                                                           \
-    auto kfn = wgrad256_kernel<TT, P, MBV>;                                                                   \
+    if (d_width == 256 && chunk_width == 64) SRWN_W2B(TT, P, MBV, 256, 64)                                    \
+    if (d_width == 256 && chunk_width == 32) SRWN_W2B(TT, P, MBV, 256, 32)                                    \
+    if (d_width == 128 && chunk_width == 64) SRWN_W2B(TT, P, MBV, 128, 64)                                    \
+    SRWN_W2B(TT, P, MBV, 128, 32)                                                                             \
+  }
+#define SRWN_W2B(TT, P, MBV, DWV, CWV)                                                                        \
+  {                                                                                                           \
+    auto kfn = wgrad256_kernel<TT, P, MBV, DWV, CWV>;                                                         \
     const size_t sh = (size_t)4 * kRows * kStride * sizeof(TT);                                               \
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
     if (e != hipSuccess) return set_error((int)e, "wgrad256: LDS %zu: %s", sh, hipGetErrorString(e));         \
@@ -233,7 +259,8 @@ extern "C" int srwn_wgrad256(const void* a, int64_t a_chunk_stride, int64_t a_ro
   }
 #undef SRWN_W2
 #undef SRWN_W2B
-  return set_error(SRWN_E_UNSUPPORTED, "wgrad256: pro %d", pro);
+#undef SRWN_W2C
+  return set_error(SRWN_E_UNSUPPORTED, "wgrad_wide: pro %d", pro);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -396,9 +396,9 @@ class WaveNetEngine:
             self.dmean = z(B, S, dt=torch.float32)
             self.tm_parts = z(B * int(_l.load().srwn_time_mean_slabs(T)) * S, dt=torch.float32)
         big = max(L * R * S, S * S, S * Cp, L * self.Kw * R * R)
-        self.use_w256 = (S == 256 and R == 64)
+        self.use_w256 = (S in (128, 256) and R in (32, 64) and (L * R) % 64 == 0)
         if self.use_w256:
-            self.ns_skip = K.wgrad256_slabs(N, L)
+            self.ns_skip = K.wgrad256_slabs(N, L, R)
             self.ns_head = K.wgrad256_slabs(N, S // 64)
             big = max(big, -(-max(self.ns_skip * L * R * S, self.ns_head * S * 256) // self.nslabs))
         self.wg_parts = z(self.nslabs * big, dt=torch.float32)
@@ -661,7 +661,7 @@ class WaveNetEngine:
             # every skip 1x1 at once: out[L*R, S] = c_all^T . dtotal (dtotal re-read once per 4 layers)
             with _Span(self, "wgrad_skip"):
                 K.wgrad256(zs_p, NR, R, L, self.dtotal, self.wg_parts, self.wg_bparts, N, self.ns_skip,
-                           pro=K.PRO_GATE)
+                           pro=K.PRO_GATE, chunk_width=R)
             K.reduce_partials(self.wg_parts, self.ns_skip, L * R * S, 1, True, 1.0, gp + 4 * sec["WS"].offset, 0)
             K.reduce_partials(self.wg_bparts, self.ns_skip, S, L, False, 1.0, gp + 4 * sec["BS"].offset, S)
             K.wgrad256(self.r0.data_ptr(), 64, S, S // 64, self.da1, self.wg_parts, self.wg_bparts, N, self.ns_head)

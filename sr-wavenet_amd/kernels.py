@@ -324,27 +324,30 @@ def wgrad_layers(x: torch.Tensor, z: torch.Tensor, df: torch.Tensor, g_ptr: int,
          abi_dtype(z.dtype), _stream())
 
 
-def wgrad256_slabs(rows: int, m_chunks: int) -> int:
-    return int(_lib.load().srwn_wgrad256_slabs(int(rows), int(m_chunks)))
+def wgrad256_slabs(rows: int, m_chunks: int, chunk_width: int = 64) -> int:
+    return int(_lib.load().srwn_wgrad_wide_slabs(int(rows), int(m_chunks), int(chunk_width)))
 
 
 def wgrad256(a_ptr: int, a_chunk_stride: int, a_row_stride: int, m_chunks: int, d: torch.Tensor,
              partials: torch.Tensor, bias_partials: Optional[torch.Tensor], rows: int, nslabs: int,
-             pro: int = PRO_NONE):
-    """d: [rows, 256] tensor; a: raw pointer to 64-channel chunks (see srwn.h)."""
+             pro: int = PRO_NONE, chunk_width: int = 64):
+    """d: [rows, 256 or 128] tensor; a: raw pointer to chunks of `chunk_width` (64 or 32) channels (see srwn.h)."""
     pd = _chk(d, "d")
-    if d.shape[0] != rows or d.shape[-1] != 256:
-        raise ValueError("wgrad256: d must be [rows, 256], got %s" % (tuple(d.shape),))
+    dw = d.shape[-1]
+    if d.shape[0] != rows or dw not in (128, 256):
+        raise ValueError("wgrad256: d must be [rows, 256 or 128], got %s" % (tuple(d.shape),))
+    if chunk_width not in (32, 64) or (m_chunks * chunk_width) % 64:
+        raise ValueError("wgrad256: %d chunks of %d channels" % (m_chunks, chunk_width))
     pp = _chk(partials, "partials", torch.float32)
-    if partials.numel() < nslabs * m_chunks * 64 * 256:
-        raise ValueError("wgrad256: partials needs %d floats" % (nslabs * m_chunks * 64 * 256))
+    if partials.numel() < nslabs * m_chunks * chunk_width * dw:
+        raise ValueError("wgrad256: partials needs %d floats" % (nslabs * m_chunks * chunk_width * dw))
     pb = None
     if bias_partials is not None:
         pb = _chk(bias_partials, "bias_partials", torch.float32)
-        if bias_partials.numel() < nslabs * 256:
-            raise ValueError("wgrad256: bias_partials needs %d floats" % (nslabs * 256))
-    call("srwn_wgrad256", a_ptr, int(a_chunk_stride), int(a_row_stride), int(m_chunks), pd, 256, pp, pb, int(rows),
-         int(nslabs), int(pro), abi_dtype(d.dtype), _stream())
+        if bias_partials.numel() < nslabs * dw:
+            raise ValueError("wgrad256: bias_partials needs %d floats" % (nslabs * dw))
+    call("srwn_wgrad_wide", a_ptr, int(a_chunk_stride), int(a_row_stride), int(m_chunks), int(chunk_width), pd, dw, dw,
+         pp, pb, int(rows), int(nslabs), int(pro), abi_dtype(d.dtype), _stream())
 
 
 def reduce_partials(partials: torch.Tensor, nslabs: int, n: int, nbatch: int, partials_batched: bool, scale: float,

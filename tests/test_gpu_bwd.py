@@ -252,3 +252,38 @@ def test_wgrad_layers_fused(dt, with_cond, R):
         assert rel_err(of[l].cpu().numpy(), dw) < TOL[dt], l
         assert rel_err(orr[l].cpu().numpy(), np.einsum("btn,btm->nm", c, gl)) < TOL[dt], l
         assert rel_err(obf[l].cpu().numpy(), dfl.sum((0, 1))) < TOL[dt] and rel_err(obr[l].cpu().numpy(), gl.sum((0, 1))) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("R,S,L,rows", [(32, 128, 30, 3000), (32, 128, 6, 331), (64, 128, 5, 700), (32, 256, 10, 1500)])
+def test_wgrad_wide_reference_widths(dt, R, S, L, rows):
+    """The wide weight-gradient GEMM at the widths the reference's scripts use (dilation_channels=32,
+    skip_channels=128): A in chunks of R channels, D of S columns."""
+    K = sub("kernels")
+    rng = np.random.default_rng(rows + R + S)
+    d = dev(rng.standard_normal((rows, S)), dt)
+    a = dev(np.tanh(rng.standard_normal((L, rows, R))), dt)
+    ns = K.wgrad256_slabs(rows, L, R)
+    parts = torch.full((ns * L * R * S,), float("nan"), dtype=torch.float32, device=DEV)
+    bparts = torch.full((ns * S,), float("nan"), dtype=torch.float32, device=DEV)
+    K.wgrad256(a.data_ptr(), rows * R, R, L, d, parts, bparts, rows, ns, pro=K.PRO_GATE, chunk_width=R)
+    out = torch.empty((L * R, S), dtype=torch.float32, device=DEV)
+    K.reduce_partials(parts, ns, L * R * S, 1, True, 1.0, out.data_ptr(), 0)
+    az = a.double().cpu().numpy()
+    c = az * (1 / (1 + np.exp(-az)))
+    if dt == torch.bfloat16:
+        c = dev(c, dt).double().cpu().numpy()
+    ref = np.einsum("lrm,rn->lmn", c, d.double().cpu().numpy()).reshape(L * R, S)
+    bout = torch.empty(S, dtype=torch.float32, device=DEV)
+    K.reduce_partials(bparts, ns, S, 1, True, 1.0, bout.data_ptr(), 0)
+    assert rel_err(out.cpu().numpy(), ref) < TOL[dt]
+    assert rel_err(bout.cpu().numpy(), d.double().cpu().numpy().sum(0)) < TOL[dt]
+    # a [rows, S] tensor against a [rows, 128] one (the head 1x1 of a 128-channel skip path)
+    if S == 128:
+        x = dev(rng.standard_normal((rows, 128)), dt)
+        ns2 = K.wgrad256_slabs(rows, 2)
+        p2 = torch.full((ns2 * 128 * 128,), float("nan"), dtype=torch.float32, device=DEV)
+        K.wgrad256(x.data_ptr(), 64, 128, 2, d, p2, None, rows, ns2)
+        o2 = torch.empty((128, 128), dtype=torch.float32, device=DEV)
+        K.reduce_partials(p2, ns2, 128 * 128, 1, True, 1.0, o2.data_ptr(), 0)
+        assert rel_err(o2.cpu().numpy(), x.double().cpu().numpy().T @ d.double().cpu().numpy()) < TOL[dt]
