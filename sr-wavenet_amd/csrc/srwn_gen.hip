@@ -59,12 +59,12 @@ __device__ __forceinline__ float gen_uniform(unsigned long long seed, unsigned u
   return (float)((x >> 40) + 0.5) * (1.0f / 16777216.0f);   // (0,1)
 }
 
-template <typename T> struct GenCond { f32x4 cc[2][4]; };
+template <typename T, int RT> struct GenCond { f32x4 cc[RT][4]; };
 struct GenNoCond {};
 
-template <typename T, int NBUF, bool COND>
+template <typename T, int NBUF, bool COND, int RT>
 __global__ __launch_bounds__(256) void generate_kernel(GenArgs a) {
-  constexpr int RT = 2, R = 64, KS = 4, S = 256, SQ = 64;       // SQ: skip/head channels per wave
+  constexpr int R = 32 * RT, KS = R / 16, S = 256, SQ = 64;     // SQ: skip/head channels per wave
   constexpr int FB = sizeof(Frag<T>) * 64;
   constexpr int LAYER_FR = RT * 2 * KS + RT * KS;                // 24 fragment images per layer (conv + res)
   constexpr int LAYER_B = LAYER_FR * FB;
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a) {
   // the ring (written d >= 1 steps ago) and this wave's skip-weight fragments (from L2).  Loaded two
   // layers ahead, unconditionally (clamped), so their latency hides behind the dependent MFMA chain.
   // (the conditioning operands exist only in the COND instantiation: they cost 32 VGPRs per operand set)
-  struct Pre : std::conditional<COND, GenCond<T>, GenNoCond>::type { Frag<T> xd[KS]; Frag<T> ws[2][KS]; };
+  struct Pre : std::conditional<COND, GenCond<T, RT>, GenNoCond>::type { Frag<T> xd[KS]; Frag<T> ws[2][KS]; };
   const T* condp = COND ? reinterpret_cast<const T*>(a.cond) : nullptr;
   const int ucl = uok ? ug : (a.B - 1);                          // clamped utterance for conditioning loads
   auto preload = [&](int l_, int t, Pre& p) {
@@ -422,8 +422,8 @@ static int generate_impl(const void* wcr, const void* wskip, const void* w1, con
   if (!wcr || !wskip || !w1 || !w2 || !bias_f || !bias_r || !bs_sum || !b1 || !b2 || !init_w || !init_b || !ring ||
       !audio_out || !codes_out || !dilations)
     return set_error(SRWN_E_NULL, "generate: null pointer");
-  if (R != 64 || S != 256 || K != 2 || C < 2 || C > 256)
-    return set_error(SRWN_E_UNSUPPORTED, "generate: built for R=64, S=256, K=2, C<=256 (got R=%d S=%d K=%d C=%d)", R, S, K, C);
+  if ((R != 64 && R != 32) || S != 256 || K != 2 || C < 2 || C > 256)
+    return set_error(SRWN_E_UNSUPPORTED, "generate: built for R=64 or 32, S=256, K=2, C<=256 (got R=%d S=%d K=%d C=%d)", R, S, K, C);
   if (B < 0 || nsteps < 0 || nsteps > Tout || nlayers < 1 || nlayers > kGenMaxLayers || (mode != 0 && mode != 1))
     return set_error(SRWN_E_SHAPE, "generate: B=%d nsteps=%d Tout=%d layers=%d mode=%d", B, nsteps, Tout, nlayers, mode);
   GenArgs a;
@@ -444,17 +444,20 @@ static int generate_impl(const void* wcr, const void* wskip, const void* w1, con
   a.ring_group_elems = off;
   const unsigned groups = (unsigned)((B + 31) / 32);
   hipStream_t st = (hipStream_t)stream;
+  const size_t lfr = (size_t)(R / 32) * 3 * (R / 16);   // fragment images per layer: conv RT x 2KS + residual RT x KS
   if (dtype == SRWN_BF16) {
-    auto kfn = cond ? generate_kernel<bf16_t, 2, true> : generate_kernel<bf16_t, 2, false>;
-    const size_t sh = 2 * 24 * sizeof(Frag<bf16_t>) * 64 + 32 * 256 * sizeof(bf16_t) + 32 * 256 * 4 + 64 * 4 +
-                      (size_t)(2 * nlayers * 64 + 3 * 256 + 3 * 64) * 4;
+    auto kfn = (R == 64) ? (cond ? generate_kernel<bf16_t, 2, true, 2> : generate_kernel<bf16_t, 2, false, 2>)
+                         : (cond ? generate_kernel<bf16_t, 2, true, 1> : generate_kernel<bf16_t, 2, false, 1>);
+    const size_t sh = 2 * lfr * sizeof(Frag<bf16_t>) * 64 + 32 * 256 * sizeof(bf16_t) + 32 * 256 * 4 + 64 * 4 +
+                      (size_t)(2 * nlayers * R + 3 * 256 + 3 * R) * 4;
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     if (e != hipSuccess) return set_error((int)e, "generate: LDS %zu: %s", sh, hipGetErrorString(e));
     hipLaunchKernelGGL(kfn, dim3(groups), dim3(256), sh, st, a);
   } else if (dtype == SRWN_F32) {
-    auto kfn = cond ? generate_kernel<float, 1, true> : generate_kernel<float, 1, false>;
-    const size_t sh = 1 * 24 * sizeof(Frag<float>) * 64 + 32 * 256 * sizeof(float) + 32 * 256 * 4 + 64 * 4 +
-                      (size_t)(2 * nlayers * 64 + 3 * 256 + 3 * 64) * 4;
+    auto kfn = (R == 64) ? (cond ? generate_kernel<float, 1, true, 2> : generate_kernel<float, 1, false, 2>)
+                         : (cond ? generate_kernel<float, 1, true, 1> : generate_kernel<float, 1, false, 1>);
+    const size_t sh = 1 * lfr * sizeof(Frag<float>) * 64 + 32 * 256 * sizeof(float) + 32 * 256 * 4 + 64 * 4 +
+                      (size_t)(2 * nlayers * R + 3 * 256 + 3 * R) * 4;
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     if (e != hipSuccess) return set_error((int)e, "generate: LDS %zu: %s", sh, hipGetErrorString(e));
     hipLaunchKernelGGL(kfn, dim3(groups), dim3(256), sh, st, a);
