@@ -10,6 +10,10 @@ Run from the repo root: ``python tests/golden/make_golden.py``.
 * layer_small.npz / stack_small.npz -- seeded outputs of oracle (i) in float64
   (``oracle/wavenet_np.py``); "parity unpinned" by the reference, see that header.
 
+* student_small.npz / autoencoder_small.npz -- seeded outputs of oracle (i) for the Parallel-WaveNet student
+  (model.py:290-535: flows, clipped output, entropy / power / cross-entropy / loss) and for the auto-encoder
+  (model.py:136-216: encoding, logits, loss, the sampler ops.py:178-201 on fixed draws); "parity unpinned".
+
 Nothing here reads /root/reference; fixtures are data only.
 """
 import json
@@ -104,6 +108,43 @@ def stack_small():
     np.savez_compressed(os.path.join(HERE, "stack_small.npz"), **out)
 
 
+def student_small():
+    B, T, R, S, E, pool, F, M = 2, 768, 32, 128, 5, 64, 3, 5      # widths the GPU engine is built for
+    dil = [1, 2, 4]
+    rng = np.random.default_rng(21)
+    noise = rng.logistic(0, 1, (B, T)) * 0.15
+    cond = rng.standard_normal((B, T // pool, E))
+    truth = O.synthetic_audio(B, T, seed=22).astype(np.float64)
+    tl = rng.standard_normal((B, T, 4 * M)) * 0.5
+    flows = [O.init_flow_params(30 + i, dil, 2, R, S, E, bias_scale=0.1) for i in range(F)]
+    for p in flows:
+        p.head_w2 = p.head_w2 * 0.3
+    fw = O.student_forward(flows, noise, cond, pool)
+    ls = O.student_loss(fw, tl, truth, 0.8, 1.2, 0.05)
+    out = dict(noise=noise, cond=cond, truth=truth, teacher_logits=tl, dilations=np.array(dil), pool=np.int64(pool),
+               seeds=np.array([30 + i for i in range(F)]), widths=np.array([R, S]), abg=np.array([0.8, 1.2, 0.05]), out=fw["out"],
+               s_tot=fw["s_tot"], mu_tot=fw["mu_tot"], stft_power_truth=O.stft_power(truth),
+               mol_dx=O.mol_dx(fw["out"], tl), **{k: np.float64(v) for k, v in ls.items()})
+    np.savez_compressed(os.path.join(HERE, "student_small.npz"), **out)
+
+
+def autoencoder_small():
+    B, T, pool, EC, S, lat, cs, M, R = 2, 256, 32, 128, 128, 3, 2, 5, 32
+    dil = [1, 2, 4]
+    ep = O.init_encoder_params(41, len(dil), 2, EC, S, lat, bias_scale=0.1)
+    dp_ = O.init_stack_params(42, dil, 2, R, S, 4 * M, cond_channels=lat + cs, bias_scale=0.1)
+    x = O.synthetic_audio(B, T, seed=43).astype(np.float64)
+    c = np.eye(cs)[[0, 1]]
+    r = O.autoencoder_forward(ep, dp_, x, pool, c)
+    rng = np.random.default_rng(44)
+    u1 = rng.uniform(1e-5, 1 - 1e-5, (B, T, M)); u2 = rng.uniform(1e-5, 1 - 1e-5, (B, T))
+    out = dict(x=x, conditions=c, dilations=np.array(dil), pool=np.int64(pool), seeds=np.array([41, 42]),
+               widths=np.array([EC, S, R]),
+               encoding=r["encoding"], logits=r["logits"], loss=np.float64(r["loss"]), u1=u1, u2=u2,
+               sample=O.mol_sample(r["logits"], u1, u2))
+    np.savez_compressed(os.path.join(HERE, "autoencoder_small.npz"), **out)
+
+
 if __name__ == "__main__":
-    selfcheck(); mulaw(); layer_small(); stack_small()
+    selfcheck(); mulaw(); layer_small(); stack_small(); student_small(); autoencoder_small()
     print("golden fixtures written to", HERE)

@@ -171,3 +171,29 @@ def test_autoencoder_trains():
     for _ in range(10):
         ae.train_step()
     assert float(ae.loss.item()) < l0
+
+
+def test_autoencoder_engine_vs_committed_golden(golden_dir):
+    """The auto-encoder engine (fp32) and the sampler kernel against tests/golden/autoencoder_small.npz."""
+    import os
+    EG = sub("engine"); EN = sub("encoder"); L = sub("_lib")
+    g = np.load(os.path.join(golden_dir, "autoencoder_small.npz"))
+    dil = g["dilations"].tolist(); pool = int(g["pool"]); EC, S, R = (int(v) for v in g["widths"])
+    B, T = g["x"].shape; lat = g["encoding"].shape[-1]; cs = g["conditions"].shape[-1]; M = g["logits"].shape[-1] // 4
+    ep = O.init_encoder_params(int(g["seeds"][0]), len(dil), 2, EC, S, lat, bias_scale=0.1)
+    dp_ = O.init_stack_params(int(g["seeds"][1]), dil, 2, R, S, 4 * M, cond_channels=lat + cs, bias_scale=0.1)
+    cfg = EG.StackConfig(dilations=dil, dilation_channels=R, skip_channels=S, output_channels=4 * M, cond_channels=lat + cs,
+                         pool_stride=pool, shift_input=True, head_mode="mol", dtype=torch.float32)
+    ae = EN.AutoEncoderEngine(cfg, B, T, EC, lat, cs, DEV)
+    ae.enc.load_oracle_params(ep); ae.dec.load_oracle_params(dp_)
+    ae.set_inputs(dev(g["x"]), dev(g["conditions"]))
+    lg = ae.forward(want_logits=True)
+    assert rel_err(ae.enc.enc.cpu().numpy().reshape(g["encoding"].shape), g["encoding"]) < 1e-3
+    assert rel_err(lg.cpu().numpy(), g["logits"]) < 1e-3
+    assert abs(float(ae.loss.item()) - float(g["loss"])) < 1e-3 * abs(float(g["loss"]))
+    # sampler on the fixture's logits and draws (ops.py:178-201)
+    lgd = dev(g["logits"].reshape(B * T, 4 * M)); u1 = dev(g["u1"].reshape(B * T, M)); u2 = dev(g["u2"].reshape(B * T))
+    out = torch.zeros(B * T, device=DEV)
+    L.call("srwn_mol_sample", lgd.data_ptr(), 4 * M, M, u1.data_ptr(), u2.data_ptr(), out.data_ptr(), B * T,
+           torch.cuda.current_stream().cuda_stream)
+    assert (np.abs(out.cpu().numpy().reshape(B, T) - g["sample"]) < 1e-3).mean() > 0.995

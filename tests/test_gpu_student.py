@@ -280,3 +280,36 @@ def test_student_slow_train_path():
             want, _, _ = O.adam_step_tf(b[n], gref, np.zeros_like(gref), np.zeros_like(gref), 1, lr=1e-3)
             assert np.abs(now[n].float().cpu().numpy() - want).max() < 3e-5, n
     assert torch.equal(stu.noise, dev(noise))        # the staged batch is restored
+
+
+def test_student_engine_vs_committed_golden(golden_dir):
+    """The student engine (fp32) against the committed fixture tests/golden/student_small.npz."""
+    import os
+    EG = sub("engine"); ST = sub("student")
+    g = np.load(os.path.join(golden_dir, "student_small.npz"))
+    dil = g["dilations"].tolist(); pool = int(g["pool"]); R, S = (int(v) for v in g["widths"])
+    B, T = g["noise"].shape; E = g["cond"].shape[-1]; M = g["teacher_logits"].shape[-1] // 4
+    flows = [O.init_flow_params(int(s), dil, 2, R, S, E, bias_scale=0.1) for s in g["seeds"]]
+    for p in flows:
+        p.head_w2 = p.head_w2 * 0.3
+    tcfg = EG.StackConfig(dilations=dil, dilation_channels=64, skip_channels=256, output_channels=4 * M, cond_channels=E,
+                          pool_stride=pool, shift_input=True, dtype=torch.float32, head_mode="mol")
+    teacher = EG.WaveNetEngine(tcfg, B, T, DEV)
+    fcfg = EG.StackConfig(dilations=dil, dilation_channels=R, skip_channels=S, cond_channels=E, pool_stride=pool,
+                          dtype=torch.float32)
+    a, b, c = (float(v) for v in g["abg"])
+    stu = ST.StudentEngine(teacher, fcfg, len(flows), alpha=a, beta=b, gamma=c)
+    for f, p in zip(stu.flows, flows):
+        f.load_oracle_params(p)
+    stu.set_inputs(dev(g["noise"]), dev(g["truth"]), dev(g["cond"]))
+    stu.forward()
+    # the fixture's teacher logits are given data: overwrite what the (random) teacher engine produced and redo the loss
+    K = sub("kernels")
+    teacher.logits32.zero_(); teacher.logits32[:, :4 * M].copy_(dev(g["teacher_logits"].reshape(B * T, 4 * M)))
+    K.mol_loss_dx(teacher.logits32, stu.out, M, stu.ce_parts, stu.dx, stu.beta / B)
+    K.reduce_loss(stu.ce_parts, stu.ce_parts.numel(), 1.0, stu.ce)
+    assert rel_err(stu.out.cpu().numpy().reshape(B, T), g["out"]) < 1e-3
+    got = stu.losses()
+    for k in ("entropy", "power_loss", "cross_entropy", "loss"):
+        assert abs(got[k] - float(g[k])) < 1e-3 * max(abs(float(g[k])), 1.0), k
+    assert rel_err(stu.dx.cpu().numpy().reshape(B, T) * B / b, g["mol_dx"]) < 1e-3

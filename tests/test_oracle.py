@@ -359,3 +359,40 @@ def test_mol_sample_closed_forms():
     l[..., :M] = 0.0
     u1[0, 0] = [0.2, 0.3, 0.9]
     assert O.mol_sample(l, u1, np.full((1, 4), 0.5))[0, 0] == pytest.approx(0.7)
+
+
+def test_student_and_autoencoder_goldens(golden_dir):
+    """The committed student / auto-encoder fixtures (tests/golden/make_golden.py) are reproduced by both oracles."""
+    g = np.load(os.path.join(golden_dir, "student_small.npz"))
+    dil = g["dilations"].tolist(); pool = int(g["pool"])
+    E = g["cond"].shape[-1]
+    R, S = (int(v) for v in g["widths"])
+    flows = [O.init_flow_params(int(s), dil, 2, R, S, E, bias_scale=0.1) for s in g["seeds"]]
+    for p in flows:
+        p.head_w2 = p.head_w2 * 0.3
+    fw = O.student_forward(flows, g["noise"], g["cond"], pool)
+    assert np.allclose(fw["out"], g["out"], rtol=1e-12, atol=1e-12) and np.allclose(fw["s_tot"], g["s_tot"], rtol=1e-12)
+    a, b, c = g["abg"]
+    ls = O.student_loss(fw, g["teacher_logits"], g["truth"], a, b, c)
+    for k in ("loss", "power_loss", "entropy", "cross_entropy"):
+        assert ls[k] == pytest.approx(float(g[k]), rel=1e-12), k
+    ts = [OT.TorchStack(p) for p in flows]
+    lt = OT.student_loss(ts, torch.tensor(g["noise"]), torch.tensor(g["cond"]), pool, torch.tensor(g["teacher_logits"]),
+                         torch.tensor(g["truth"]), a, b, c)
+    assert float(lt["loss"].detach()) == pytest.approx(float(g["loss"]), rel=1e-7)
+    assert np.allclose(O.stft_power(g["truth"]), g["stft_power_truth"], rtol=1e-12)
+    assert np.allclose(O.mol_dx(g["out"], g["teacher_logits"]), g["mol_dx"], rtol=1e-10, atol=1e-12)
+
+    g = np.load(os.path.join(golden_dir, "autoencoder_small.npz"))
+    dil = g["dilations"].tolist(); pool = int(g["pool"])
+    lat = g["encoding"].shape[-1]; cs = g["conditions"].shape[-1]; M = g["logits"].shape[-1] // 4
+    EC, S, R = (int(v) for v in g["widths"])
+    ep = O.init_encoder_params(int(g["seeds"][0]), len(dil), 2, EC, S, lat, bias_scale=0.1)
+    dp_ = O.init_stack_params(int(g["seeds"][1]), dil, 2, R, S, 4 * M, cond_channels=lat + cs, bias_scale=0.1)
+    r = O.autoencoder_forward(ep, dp_, g["x"], pool, g["conditions"])
+    assert np.allclose(r["encoding"], g["encoding"], rtol=1e-12, atol=1e-14)
+    assert np.allclose(r["logits"], g["logits"], rtol=1e-11, atol=1e-13) and r["loss"] == pytest.approx(float(g["loss"]), rel=1e-12)
+    te, td = OT.TorchEncoder(ep), OT.TorchStack(dp_)
+    lo, _, lg = OT.autoencoder_loss(te, td, torch.tensor(g["x"]), pool, torch.tensor(g["conditions"]))
+    assert float(lo.detach()) == pytest.approx(float(g["loss"]), rel=1e-9)
+    assert np.array_equal(O.mol_sample(g["logits"], g["u1"], g["u2"]), g["sample"])
