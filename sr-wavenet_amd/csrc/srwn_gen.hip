@@ -62,24 +62,26 @@ __device__ __forceinline__ float gen_uniform(unsigned long long seed, unsigned u
 template <typename T, int RT> struct GenCond { f32x4 cc[RT][4]; };
 struct GenNoCond {};
 
-template <typename T, int NBUF, bool COND, int RT>
+template <typename T, int NBUF, bool COND, int RT, int SS>
 __global__ __launch_bounds__(256) void generate_kernel(GenArgs a) {
-  constexpr int R = 32 * RT, KS = R / 16, S = 256, SQ = 64;     // SQ: skip/head channels per wave
+  constexpr int R = 32 * RT, KS = R / 16, S = SS, SQ = S / 4;   // SQ: skip/head-1 channels per wave
+  constexpr int MQ = SQ / 32;                                    // ... = MQ 32-row tiles per wave
+  constexpr int LGS = 256;                                       // row stride of the logits exchange (C <= 256)
   constexpr int FB = sizeof(Frag<T>) * 64;
   constexpr int LAYER_FR = RT * 2 * KS + RT * KS;                // 24 fragment images per layer (conv + res)
   constexpr int LAYER_B = LAYER_FR * FB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* wbuf = smem;                                             // [NBUF][LAYER_B]
   T* xch = reinterpret_cast<T*>(smem + NBUF * LAYER_B);          // [32][S] activation exchange (r0 / r1)
-  float* lgl = reinterpret_cast<float*>(xch + 32 * S);           // [32][S] logits
-  float* prev = lgl + 32 * S;                                    // [2][32] last two samples
+  float* lgl = reinterpret_cast<float*>(xch + 32 * S);           // [32][LGS] logits
+  float* prev = lgl + 32 * LGS;                                  // [2][32] last two samples
   float* cst = prev + 64;                                        // constants: biases of every layer + head + input conv
   float* c_bf = cst;                 // [L][R]
   float* c_br = c_bf + a.L * R;      // [L][R]
   float* c_bs = c_br + a.L * R;      // [S]
   float* c_b1 = c_bs + S;            // [S]
-  float* c_b2 = c_b1 + S;            // [S]
-  float* c_iw = c_b2 + S;            // [2][R]
+  float* c_b2 = c_b1 + S;            // [LGS]
+  float* c_iw = c_b2 + LGS;          // [2][R]
   float* c_ib = c_iw + 2 * R;        // [R]
 
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -96,10 +98,9 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a) {
   int par = 0;   // which weight buffer holds the layer being computed (toggles every layer, across steps)
 
   for (int i = threadIdx.x; i < a.L * R; i += 256) { c_bf[i] = a.bias_f[i]; c_br[i] = a.bias_r[i]; }
-  for (int i = threadIdx.x; i < S; i += 256) {
-    c_bs[i] = a.bs_sum[i]; c_b1[i] = a.b1[i];
+  for (int i = threadIdx.x; i < S; i += 256) { c_bs[i] = a.bs_sum[i]; c_b1[i] = a.b1[i]; }
+  for (int i = threadIdx.x; i < LGS; i += 256)
     c_b2[i] = (i < (a.C + 31) / 32 * 32) ? a.b2[i] : 0.0f;     // the last 1x1 has ceil(C/32)*32 rows
-  }
   if (threadIdx.x < 2 * R) c_iw[threadIdx.x] = a.init_w[threadIdx.x];
   if (threadIdx.x < R) c_ib[threadIdx.x] = a.init_b[threadIdx.x];
   if (threadIdx.x < 64) prev[threadIdx.x] = 0.0f;
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a) {
   // the ring (written d >= 1 steps ago) and this wave's skip-weight fragments (from L2).  Loaded two
   // layers ahead, unconditionally (clamped), so their latency hides behind the dependent MFMA chain.
   // (the conditioning operands exist only in the COND instantiation: they cost 32 VGPRs per operand set)
-  struct Pre : std::conditional<COND, GenCond<T, RT>, GenNoCond>::type { Frag<T> xd[KS]; Frag<T> ws[2][KS]; };
+  struct Pre : std::conditional<COND, GenCond<T, RT>, GenNoCond>::type { Frag<T> xd[KS]; Frag<T> ws[MQ][KS]; };
   const T* condp = COND ? reinterpret_cast<const T*>(a.cond) : nullptr;
   const int ucl = uok ? ug : (a.B - 1);                          // clamped utterance for conditioning loads
   auto preload = [&](int l_, int t, Pre& p) {
@@ -130,9 +131,9 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a) {
         for (int g = 0; g < 4; ++g) p.cc[mt][g] = load4(ccp + 32 * mt + 8 * g);
     }
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MQ; ++m)
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) p.ws[m][ks] = wskip[((size_t)(2 * wave + m) * ks_skip + l * KS + ks) * 64 + lane];
+      for (int ks = 0; ks < KS; ++ks) p.ws[m][ks] = wskip[((size_t)(MQ * wave + m) * ks_skip + l * KS + ks) * 64 + lane];
   };
 
   for (int t = 0; t < a.nsteps; ++t) {
@@ -155,9 +156,9 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a) {
         const int n = 32 * mt + crow(q, half);
         h[mt][q] = fmaf(c_iw[n], a2, fmaf(c_iw[R + n], a1, c_ib[n]));
       }
-    f32x16 accS[2];
+    f32x16 accS[MQ];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MQ; ++m)
 #pragma unroll
       for (int q = 0; q < 16; ++q) accS[m][q] = c_bs[SQ * wave + 32 * m + crow(q, half)];
 
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a) {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-        for (int m = 0; m < 2; ++m) mma(accS[m], p.ws[m][ks], cf[ks]);
+        for (int m = 0; m < MQ; ++m) mma(accS[m], p.ws[m][ks], cf[ks]);
       __syncthreads();   // next layer's weights landed; ring write of this layer ordered before later reads
       if (NBUF == 1) {
         const int ln = (l + 1 < a.L) ? l + 1 : 0;
@@ -268,26 +269,26 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a) {
 
     // ---- head: relu(sum skip) -> 1x1 + relu -> 1x1 (model.py:51-56); quarters exchanged through LDS
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MQ; ++m)
 #pragma unroll
       for (int g = 0; g < 4; ++g)
         store4(xch + col * S + SQ * wave + 32 * m + 8 * g + 4 * half, fmaxf(accS[m][4 * g], 0.f),
                fmaxf(accS[m][4 * g + 1], 0.f), fmaxf(accS[m][4 * g + 2], 0.f), fmaxf(accS[m][4 * g + 3], 0.f));
     __syncthreads();
-    f32x16 acc1[2];
+    f32x16 acc1[MQ];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MQ; ++m)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc1[m][q] = c_b1[SQ * wave + 32 * m + crow(q, half)];
 #pragma unroll
     for (int ks = 0; ks < S / 16; ++ks) {
       const Frag<T> bf = load_nat(xch + col * S + 16 * ks + 8 * half);
 #pragma unroll
-      for (int m = 0; m < 2; ++m) mma(acc1[m], w1[((size_t)(2 * wave + m) * (S / 16) + ks) * 64 + lane], bf);
+      for (int m = 0; m < MQ; ++m) mma(acc1[m], w1[((size_t)(MQ * wave + m) * (S / 16) + ks) * 64 + lane], bf);
     }
     __syncthreads();   // everyone has read r0
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MQ; ++m)
 #pragma unroll
       for (int g = 0; g < 4; ++g)
         store4(xch + col * S + SQ * wave + 32 * m + 8 * g + 4 * half, fmaxf(acc1[m][4 * g], 0.f),
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a) {
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) acc2[m][q] = c_b2[SQ * wave + 32 * m + crow(q, half)];
+      for (int q = 0; q < 16; ++q) acc2[m][q] = c_b2[64 * wave + 32 * m + crow(q, half)];   // 2 class tiles per wave
 #pragma unroll
     for (int ks = 0; ks < S / 16; ++ks) {
       const Frag<T> bf = load_nat(xch + col * S + 16 * ks + 8 * half);
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a) {
     for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<f32x4*>(lgl + col * S + SQ * wave + 32 * m + 8 * g + 4 * half) =
+        *reinterpret_cast<f32x4*>(lgl + col * LGS + 64 * wave + 32 * m + 8 * g + 4 * half) =
             f32x4{acc2[m][4 * g], acc2[m][4 * g + 1], acc2[m][4 * g + 2], acc2[m][4 * g + 3]};
     __syncthreads();
 
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a) {
       // ---- mixture-of-logistics head (model.py:196-198): sample_from_discretized_mix_logistic (ops.py:178-201) with
       //      counter-based uniforms; lanes = utterances (M <= 16 mixtures: a short serial loop)
       if (wave == 0 && half == 0) {
-        const float* l = lgl + col * S;
+        const float* l = lgl + col * LGS;
         int sel = 0;
         float best = -INFINITY;
         for (int m = 0; m < a.M; ++m) {
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a) {
       if (a.logits_out) {
         for (int i = threadIdx.x; i < 32 * a.C; i += 256) {
           const int ul = i / a.C, c = i - ul * a.C;
-          if (u0 + ul < a.B) a.logits_out[((size_t)(u0 + ul) * a.Tout + t) * a.C + c] = lgl[ul * S + c];
+          if (u0 + ul < a.B) a.logits_out[((size_t)(u0 + ul) * a.Tout + t) * a.C + c] = lgl[ul * LGS + c];
         }
       }
       __syncthreads();
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a) {
     for (int i = 0; i < 8; ++i) {
       const int ul = 8 * wave + i;                        // wave-uniform, local to the group
       const int u = u0 + ul;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(lgl + ul * S + 4 * lane);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(lgl + ul * LGS + 4 * lane);
       float m = -INFINITY; int am = 0;
 #pragma unroll
       for (int e = 0; e < 4; ++e)
@@ -422,8 +423,8 @@ static int generate_impl(const void* wcr, const void* wskip, const void* w1, con
   if (!wcr || !wskip || !w1 || !w2 || !bias_f || !bias_r || !bs_sum || !b1 || !b2 || !init_w || !init_b || !ring ||
       !audio_out || !codes_out || !dilations)
     return set_error(SRWN_E_NULL, "generate: null pointer");
-  if ((R != 64 && R != 32) || S != 256 || K != 2 || C < 2 || C > 256)
-    return set_error(SRWN_E_UNSUPPORTED, "generate: built for R=64 or 32, S=256, K=2, C<=256 (got R=%d S=%d K=%d C=%d)", R, S, K, C);
+  if ((R != 64 && R != 32) || (S != 256 && S != 128) || K != 2 || C < 2 || C > 256)
+    return set_error(SRWN_E_UNSUPPORTED, "generate: built for R=64 or 32, S=256 or 128, K=2, C<=256 (got R=%d S=%d K=%d C=%d)", R, S, K, C);
   if (B < 0 || nsteps < 0 || nsteps > Tout || nlayers < 1 || nlayers > kGenMaxLayers || (mode != 0 && mode != 1))
     return set_error(SRWN_E_SHAPE, "generate: B=%d nsteps=%d Tout=%d layers=%d mode=%d", B, nsteps, Tout, nlayers, mode);
   GenArgs a;
@@ -445,19 +446,23 @@ static int generate_impl(const void* wcr, const void* wskip, const void* w1, con
   const unsigned groups = (unsigned)((B + 31) / 32);
   hipStream_t st = (hipStream_t)stream;
   const size_t lfr = (size_t)(R / 32) * 3 * (R / 16);   // fragment images per layer: conv RT x 2KS + residual RT x KS
+  // widths: (64, 256) the north-star stack, (32, 256) generator.py's default teacher, (32, 128) teacher.py's
+#define SRWN_GEN_PICK(TT, NB)                                                                                   \
+  ((R == 64 && S == 256) ? (cond ? generate_kernel<TT, NB, true, 2, 256> : generate_kernel<TT, NB, false, 2, 256>)  \
+   : (R == 32 && S == 256) ? (cond ? generate_kernel<TT, NB, true, 1, 256> : generate_kernel<TT, NB, false, 1, 256>) \
+   : (R == 32 && S == 128) ? (cond ? generate_kernel<TT, NB, true, 1, 128> : generate_kernel<TT, NB, false, 1, 128>) \
+                           : (cond ? generate_kernel<TT, NB, true, 2, 128> : generate_kernel<TT, NB, false, 2, 128>))
   if (dtype == SRWN_BF16) {
-    auto kfn = (R == 64) ? (cond ? generate_kernel<bf16_t, 2, true, 2> : generate_kernel<bf16_t, 2, false, 2>)
-                         : (cond ? generate_kernel<bf16_t, 2, true, 1> : generate_kernel<bf16_t, 2, false, 1>);
-    const size_t sh = 2 * lfr * sizeof(Frag<bf16_t>) * 64 + 32 * 256 * sizeof(bf16_t) + 32 * 256 * 4 + 64 * 4 +
-                      (size_t)(2 * nlayers * R + 3 * 256 + 3 * R) * 4;
+    auto kfn = SRWN_GEN_PICK(bf16_t, 2);
+    const size_t sh = 2 * lfr * sizeof(Frag<bf16_t>) * 64 + 32 * S * sizeof(bf16_t) + 32 * 256 * 4 + 64 * 4 +
+                      (size_t)(2 * nlayers * R + 2 * S + 256 + 3 * R) * 4;
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     if (e != hipSuccess) return set_error((int)e, "generate: LDS %zu: %s", sh, hipGetErrorString(e));
     hipLaunchKernelGGL(kfn, dim3(groups), dim3(256), sh, st, a);
   } else if (dtype == SRWN_F32) {
-    auto kfn = (R == 64) ? (cond ? generate_kernel<float, 1, true, 2> : generate_kernel<float, 1, false, 2>)
-                         : (cond ? generate_kernel<float, 1, true, 1> : generate_kernel<float, 1, false, 1>);
-    const size_t sh = 1 * lfr * sizeof(Frag<float>) * 64 + 32 * 256 * sizeof(float) + 32 * 256 * 4 + 64 * 4 +
-                      (size_t)(2 * nlayers * R + 3 * 256 + 3 * R) * 4;
+    auto kfn = SRWN_GEN_PICK(float, 1);
+    const size_t sh = 1 * lfr * sizeof(Frag<float>) * 64 + 32 * S * sizeof(float) + 32 * 256 * 4 + 64 * 4 +
+                      (size_t)(2 * nlayers * R + 2 * S + 256 + 3 * R) * 4;
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     if (e != hipSuccess) return set_error((int)e, "generate: LDS %zu: %s", sh, hipGetErrorString(e));
     hipLaunchKernelGGL(kfn, dim3(groups), dim3(256), sh, st, a);

@@ -306,7 +306,7 @@ class WaveNetEngine:
         self.o_skipT = []
         # generation images: per layer [conv (last tap permuted) | residual], back to back (srwn_generate)
         self.o_gen = self.o_skip_gen = None
-        if R in (32, 64) and S == 256 and Kw == 2:
+        if R in (32, 64) and S in (128, 256) and Kw == 2:
             for l in range(L):
                 o = P.pack_conv_gen(pk, sec["WF"].offset + l * Kw * R * R, Kw, R)
                 P.pack_res(pk, sec["WR"].offset + l * R * R, R)
@@ -758,7 +758,7 @@ class WaveNetEngine:
         import ctypes as C
         from . import _lib
         if self.o_gen is None or self.pooled:
-            raise NotImplementedError("generate: built for R=64 or 32, S=256, K=2 stacks with a per-time-step head")
+            raise NotImplementedError("generate: built for R=64 or 32, S=256 or 128, K=2 stacks with a per-time-step head")
         B = int(batch or self.B)
         dl = (C.c_int32 * self.L)(*self.dil)
         relems = int(_lib.load().srwn_generate_ring_elems(dl, self.L, self.R))

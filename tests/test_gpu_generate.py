@@ -13,10 +13,10 @@ from tests.test_gpu_kernels import DEV, dev, rel_err
 pytestmark = pytest.mark.gpu
 
 
-def _engine(dt, dil, B, T, C=256, seed=4, R=64):
+def _engine(dt, dil, B, T, C=256, seed=4, R=64, S=256):
     EG = sub("engine")
-    sp = O.init_stack_params(seed, dil, 2, R, 256, C, bias_scale=0.05)
-    cfg = EG.StackConfig(dilations=dil, dilation_channels=R, skip_channels=256, output_channels=C, shift_input=True,
+    sp = O.init_stack_params(seed, dil, 2, R, S, C, bias_scale=0.05)
+    cfg = EG.StackConfig(dilations=dil, dilation_channels=R, skip_channels=S, output_channels=C, shift_input=True,
                          dtype=dt)
     eng = EG.WaveNetEngine(cfg, B, T, DEV)
     eng.load_oracle_params(sp)
@@ -24,11 +24,12 @@ def _engine(dt, dil, B, T, C=256, seed=4, R=64):
 
 
 @pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-3), (torch.bfloat16, 6e-2)])
-@pytest.mark.parametrize("B,T,C,R", [(3, 300, 256, 64), (32, 70, 256, 64), (1, 130, 100, 64), (70, 40, 256, 64),
-                                     (3, 300, 256, 32), (40, 70, 100, 32)])
-def test_incremental_logits_equal_full_forward(dt, tol, B, T, C, R):
+@pytest.mark.parametrize("B,T,C,R,S", [(3, 300, 256, 64, 256), (32, 70, 256, 64, 256), (1, 130, 100, 64, 256),
+                                       (70, 40, 256, 64, 256), (3, 300, 256, 32, 256), (40, 70, 100, 32, 256),
+                                       (3, 300, 256, 32, 128), (33, 70, 256, 64, 128)])
+def test_incremental_logits_equal_full_forward(dt, tol, B, T, C, R, S):
     dil = [1, 2, 4, 8, 16, 32, 64, 128, 1, 2, 5]
-    eng, sp = _engine(dt, dil, B, T, C, R=R)
+    eng, sp = _engine(dt, dil, B, T, C, R=R, S=S)
     audio = O.synthetic_audio(B, T, seed=9)
     codes = O.mu_law_encode(audio, C)
     eng.set_inputs(dev(audio), dev(codes, torch.int32))
@@ -109,16 +110,17 @@ def _gen_uniform(seed, u, t):
 
 
 @pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-3), (torch.bfloat16, 6e-2)])
-@pytest.mark.parametrize("B,T,M,E,pool,R", [(3, 256, 5, 6, 32, 64), (33, 96, 10, 20, 16, 64), (2, 200, 5, 0, 1, 64),
-                                           (3, 256, 5, 16, 32, 32)])
-def test_mol_decoder_incremental_equals_full_forward(dt, tol, B, T, M, E, pool, R):
+@pytest.mark.parametrize("B,T,M,E,pool,R,S", [(3, 256, 5, 6, 32, 64, 256), (33, 96, 10, 20, 16, 64, 256),
+                                             (2, 200, 5, 0, 1, 64, 256), (3, 256, 5, 16, 32, 32, 256),
+                                             (3, 256, 5, 16, 32, 32, 128)])
+def test_mol_decoder_incremental_equals_full_forward(dt, tol, B, T, M, E, pool, R, S):
     """The conditioned mixture-of-logistics decoder (model.py:158-200): teacher-forced incremental logits equal the
     full forward's; the emitted samples are sample_from_discretized_mix_logistic of those logits draw for draw."""
     EG = sub("engine")
     dil = [1, 2, 4, 8, 16, 32, 64, 1, 2, 5]
     C = 4 * M
-    sp = O.init_stack_params(7, dil, 2, R, 256, C, cond_channels=E, bias_scale=0.05)
-    cfg = EG.StackConfig(dilations=dil, dilation_channels=R, skip_channels=256, output_channels=C, cond_channels=E,
+    sp = O.init_stack_params(7, dil, 2, R, S, C, cond_channels=E, bias_scale=0.05)
+    cfg = EG.StackConfig(dilations=dil, dilation_channels=R, skip_channels=S, output_channels=C, cond_channels=E,
                          pool_stride=pool if E else 1, shift_input=True, head_mode="mol", dtype=dt)
     eng = EG.WaveNetEngine(cfg, B, T, DEV)
     eng.load_oracle_params(sp)

@@ -226,5 +226,5 @@ def test_teacher_mixture_of_logistics_head():
     lg = m.get_logits(x)
     assert lg.shape == (2, 256, 20)
     assert abs(float(m.loss(x)) - O.mol_loss(x.astype(np.float64), lg.astype(np.float64))) < 1e-3 * abs(float(m.loss(x)))
-    with pytest.raises(NotImplementedError):
-        m.generate(1, 10)
+    g = m.generate(3, 40, seed=2)                      # skip_channels=128: generated incrementally as well
+    assert g.shape == (3, 40) and np.abs(g).max() <= 1.0 and np.array_equal(g, m.generate(3, 40, seed=2))
