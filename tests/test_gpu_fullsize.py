@@ -107,3 +107,23 @@ def test_full_size_mu_law_round_trip():
     assert torch.equal(K.mu_law_encode(K.mu_law_decode(allc, C), C), allc)
     # companded error bound: |x - decode(encode(x))| <= half a bin of the expanded grid (at most ~2.2 % of full scale)
     assert float((dec.view(-1) - audio.view(-1)).abs().max()) < 0.0222
+
+
+def test_full_size_training_is_stable_and_bf16_tracks_fp32():
+    """150 graph-replayed steps on one fixed batch: losses fall, stay finite, and the bf16 curve tracks the fp32 one."""
+    K = sub("kernels")
+    audio, codes = _inputs()
+    final = {}
+    for dt in (torch.bfloat16, torch.float32):
+        eng = _engine(dt)
+        eng.set_inputs(audio, codes)
+        eng.train_step()
+        l0 = float(eng.loss.item())
+        eng.capture_graphs()
+        for _ in range(150):
+            eng.train_step_graphed()
+        torch.cuda.synchronize()
+        final[dt] = float(eng.loss.item())
+        assert np.isfinite(final[dt]) and final[dt] < 0.6 * l0 and bool(torch.isfinite(eng.params).all())
+        del eng
+    assert abs(final[torch.bfloat16] - final[torch.float32]) < 0.02 * final[torch.float32], final
