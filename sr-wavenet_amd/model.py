@@ -25,6 +25,24 @@ from . import kernels as K
 from .engine import StackConfig, WaveNetEngine
 
 
+def _train_step(eng):
+    """One training step of an engine: the first two run as eager launches, then the step is captured as hipGraphs
+    (inputs live in persistent device buffers, so replays see each new batch) -- at the reference scripts' small
+    shapes the ~100-400 launches of a step cost more than the kernels.  SRWN_MODEL_GRAPHS=0 keeps eager launches."""
+    if getattr(eng, "_graph_ready", False):
+        return eng.train_step_graphed()
+    out = eng.train_step()
+    eng._eager_steps = getattr(eng, "_eager_steps", 0) + 1
+    if eng._eager_steps >= 2 and os.environ.get("SRWN_MODEL_GRAPHS", "1") != "0" and not getattr(eng, "_graph_failed", False):
+        try:
+            eng.capture_graphs()
+            eng._graph_ready = True
+        except Exception as e:   # keep training with eager launches, say why once
+            eng._graph_failed = True
+            print("hipGraph capture failed (%s); continuing with eager launches" % e)
+    return out
+
+
 def _default_dtype():
     return torch.float32 if os.environ.get("SRWN_DTYPE", "bf16").lower() in ("f32", "fp32", "float32") else torch.bfloat16
 
@@ -125,7 +143,7 @@ class WaveNet(_EngineOwner):
 
     def train(self, inputs, targets):
         eng = self._stage(inputs, targets)
-        eng.train_step()
+        _train_step(eng)
         return np.float32(eng.loss.item())
 
     def predict(self, inputs):
@@ -217,7 +235,7 @@ class WaveNetTeacher(_EngineOwner):
 
     def train(self, inputs, encoding=None, conditions=None):
         eng = self._stage(inputs, encoding, conditions)
-        eng.train_step()
+        _train_step(eng)
         return np.float32(eng.loss.item())
 
     def get_logits(self, inputs, encoding=None, conditions=None):
@@ -392,7 +410,7 @@ class WaveNetAutoEncoder(object):
 
     def train(self, inputs, conditions=None):
         eng = self._stage(inputs, conditions)
-        eng.train_step()
+        _train_step(eng)
         return np.float32(eng.loss.item())
 
     def encode(self, inputs, conditions=None):
@@ -605,7 +623,7 @@ class ParallelWaveNet(object):
     def train_fast(self, sess, inputs, truth, encoding, conditions=None):
         """One distillation step (model.py:634-642): returns (loss, power_loss)."""
         eng = self._stage(inputs, truth, encoding, conditions)
-        eng.train_step()
+        _train_step(eng)
         l = eng.losses()
         return np.float32(l["loss"]), np.float32(l["power_loss"])
 
