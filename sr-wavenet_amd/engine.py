@@ -811,9 +811,19 @@ class WaveNetEngine:
         """Captures the step as two hipGraphs -- {forward, backward} and {Adam, re-pack} -- with the
         gradient all-reduce left between them as an ordinary RCCL call, so one and many GPUs replay the
         same launch-free kernel sequence.  Call after at least one eager train_step (warm-up)."""
+        import os as _os
         torch.cuda.synchronize()
         self._g_fb = torch.cuda.CUDAGraph()
         self._g_b2 = None
+        if self.world == 1 and _os.environ.get("SRWN_FORCE_DIST") != "1":
+            # no collective to leave between the graphs: the whole step is one replay
+            with torch.cuda.graph(self._g_fb):
+                self.forward()
+                self.backward()
+                self.optimizer_step()
+            self._g_opt = None
+            torch.cuda.synchronize()
+            return
         with torch.cuda.graph(self._g_fb):
             self.forward()
             self.backward(part=1 if self.bucketed else 0)
@@ -828,6 +838,8 @@ class WaveNetEngine:
 
     def train_step_graphed(self) -> torch.Tensor:
         self._g_fb.replay()
+        if self._g_opt is None:
+            return self.loss
         if self._g_b2 is not None:
             h = self._allreduce_bucket_a()
             self._g_b2.replay()
