@@ -127,3 +127,20 @@ def test_full_size_training_is_stable_and_bf16_tracks_fp32():
         assert np.isfinite(final[dt]) and final[dt] < 0.6 * l0 and bool(torch.isfinite(eng.params).all())
         del eng
     assert abs(final[torch.bfloat16] - final[torch.float32]) < 0.02 * final[torch.float32], final
+
+
+def test_full_size_bf16_forward_tracks_exact_fp32_mode():
+    """Config 2: the bf16 engine's logits and loss against the exact-fp32 MFMA mode of the same engine (which the
+    small-shape tests tie to the oracle at 1e-3)."""
+    audio, codes = _inputs()
+    out = {}
+    for dt in (torch.float32, torch.bfloat16):
+        eng = _engine(dt, seed=3)
+        eng.set_inputs(audio, codes)
+        out[dt] = (eng.forward(want_logits=True).float().cpu().numpy(), float(eng.loss.item()))
+        del eng
+    ref, lref = out[torch.float32]
+    got, lgot = out[torch.bfloat16]
+    err = np.abs(got - ref).max() / np.abs(ref).max()
+    assert err < 5e-2, err
+    assert abs(lgot - lref) < 2e-3 * abs(lref), (lgot, lref)
