@@ -201,3 +201,25 @@ def test_corruption_is_detected(nsynth_file, tmp_path):
     g = NS.TFRecordFile(str(garbage))
     with pytest.raises(RuntimeError, match="malformed"):
         g.feature(0, "audio")
+
+
+def test_simple_audio_wave_batches():
+    """generator.py's synthetic data source (simple_audio.py:40-66): shapes, range, label convention, wave shapes."""
+    SA = sub("simple_audio")
+    rs = np.random.RandomState(0)
+    x, y = SA.generate_wave_batch(6, 5120, rng=rs)
+    assert x.shape == (6, 5120) and y.shape == (6, 10)
+    assert np.allclose(x.min(1), -1) and np.allclose(x.max(1), 1)
+    assert (y.sum(1) == 1).all() and set(np.unique(y)) == {0.0, 1.0}
+    t = SA.CreateTicks(1, 1000)
+    assert len(t) == 1000 and t[0] == 0 and t[-1] == 1
+    s = SA.Sine(5, 1, 1000); q = SA.Square(5, 1, 1000); w = SA.Sawtooth(5, 1, 1000); tr = SA.Triangle(5, 1, 1000)
+    for v in (s, q, w, tr):
+        assert v.shape == (1000,) and v.min() >= -1 - 1e-12 and v.max() <= 1 + 1e-12
+    assert abs(s[50] - np.sin(2 * np.pi * 5 * t[50])) < 1e-12
+    assert set(np.unique(q)) == {-1.0, 1.0} and q[10] == 1 and q[150] == -1          # first half-period high
+    assert w[1] > w[0] and abs(w[0] + 1) < 1e-12                                     # ramps up from -1
+    assert abs(tr[0] + 1) < 1e-12 and abs(tr.max() - 1) < 0.05 and tr[50] > tr[0]    # -1 -> 1 -> -1 per period
+    # label = one-hot of int(f/2 - 1) - 10 for f in 22..39  ->  indices 0..8
+    assert y.argmax(1).min() >= 0 and y.argmax(1).max() <= 8
+    assert np.allclose(SA.Normalize(np.array([2.0, 4.0, 3.0]), -1, 1), [-1, 1, 0])
