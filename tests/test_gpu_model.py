@@ -228,3 +228,30 @@ def test_teacher_mixture_of_logistics_head():
     assert abs(float(m.loss(x)) - O.mol_loss(x.astype(np.float64), lg.astype(np.float64))) < 1e-3 * abs(float(m.loss(x)))
     g = m.generate(3, 40, seed=2)                      # skip_channels=128: generated incrementally as well
     assert g.shape == (3, 40) and np.abs(g).max() <= 1.0 and np.array_equal(g, m.generate(3, 40, seed=2))
+
+
+def test_example_drivers_end_to_end(tmp_path):
+    """examples/teacher.py then examples/student.py (the parallel drivers to the reference's scripts) on synthetic
+    waves: a few steps each, checkpoints written, the student rebuilds the teacher from its directory."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def load(name):
+        spec = importlib.util.spec_from_file_location("example_" + name, os.path.join(root, "examples", name + ".py"))
+        m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+        return m
+
+    common = ["--batch-size", "2", "--num-samples", "1024", "--pool-stride", "64", "--latent-channels", "8", "--layers", "6",
+              "--print-steps", "3"]
+    tdir, sdir = str(tmp_path / "t"), str(tmp_path / "s")
+    try:
+        lt = load("teacher").main(["--teacher", tdir, "--steps", "6"] + common)
+        assert np.isfinite(lt) and os.path.exists(os.path.join(tdir, "checkpoint")) and os.path.exists(os.path.join(tdir, "config.json"))
+        ls = load("student").main(["--teacher", tdir, "--student", sdir, "--steps", "6", "--flows", "2"] + common)
+        assert np.isfinite(ls) and os.path.exists(os.path.join(sdir, "checkpoint"))
+    finally:
+        for m in ("model", "ops", "nsynth", "simple_audio"):
+            sys.modules.pop(m, None)
+        d = os.path.join(root, "sr-wavenet_amd", "dropin")
+        while d in sys.path:
+            sys.path.remove(d)
