@@ -359,6 +359,14 @@ int srwn_tap_linear(const void* x, int64_t x_row_stride, int32_t ntaps, int32_t 
                     const void* aux, int64_t aux_row_stride, const float* frame_add, int64_t frame_add_ld,
                     int32_t frames, int32_t pool_stride, float frame_add_scale, int32_t epi, int32_t dtype,
                     void* stream);
+/* weight gradients of the encoder's ResidualDilationLayerNC chain (ops.py:48-58), all layers in one pass over the saved
+ * tensors ([L][rows][128] stacks, `layer_stride` elements apart; 128 channels, K = 2 taps at t and t+1):
+ *   part_w [l][slab][k*128+i][o] = sum r_l[t+k, i] * dpre_l[t, o]   (taps beyond the clip contribute 0)
+ *   part_r [l][slab][n][m]       = sum a_l[t, n] * dh_l[t, m];  part_b / part_br = column sums of dpre_l / dh_l
+ * Finish with srwn_reduce_partials. */
+int srwn_wgrad_nc_layers(const void* r, const void* a, const void* dpre, const void* dh, int64_t layer_stride,
+                         int32_t nlayers, float* part_w, float* part_r, float* part_b, float* part_br, int64_t rows,
+                         int32_t T, int32_t nslabs, int32_t C, int32_t K, int32_t dtype, void* stream);
 /* first encoder layer on the raw clip (model.py:141-142): a[b,t,c] = relu(bias[c] + sum_k w[k][c]*relu(x[b,t+k])) */
 int srwn_nc_input_fwd(const float* x, const float* w, const float* bias, void* a, int32_t B, int32_t T, int32_t C,
                       int32_t K, int32_t dtype, void* stream);

@@ -486,3 +486,166 @@ extern "C" int srwn_wgrad_layers(const void* x, const void* z, const void* df, c
 #undef SRWN_WL
   return set_error(SRWN_E_DTYPE, "wgrad_layers: dtype %d", dtype);
 }
+
+// ------------------------------------------------------------------------------------------
+// Weight gradients of the encoder's ResidualDilationLayerNC chain (ops.py:48-58) in ONE pass over the saved tensors,
+// batched over layers (grid.y), 128 channels, K = 2 taps at t and t+1 (SAME padding):
+//   dW_l[k]  = r_l[t+k]^T . dpre_l[t]        (r_l = relu'd layer input; rows beyond the clip contribute 0)
+//   db_l     = colsum(dpre_l)
+//   dWr_l    = a_l^T . dh_l                   (a_l = relu(conv) of the layer; dh_l = gradient at the 1x1's output)
+//   dbr_l    = colsum(dh_l)
+// r, a, dpre, dh are each read once (three separate time-contraction launches read r and dpre twice).
+// One workgroup = 8 waves over one slab of rows of one layer; 32-row chunks register-staged into LDS, fragments by
+// transposing LDS reads.  Wave w owns conv row tile w (rows 32w.. of [r(t) | r(t+1)]) x the 4 dpre column tiles, and
+// dWr tiles (w>>1, 2(w&1)) and (w>>1, 2(w&1)+1).
+// ------------------------------------------------------------------------------------------
+struct WgNcArgs {
+  const void* r; const void* a; const void* dpre; const void* dh; int64_t layer_stride;   // [L][rows][128] each
+  float* part_w; float* part_r; float* part_b; float* part_br;   // [L][ns][2*128*128], [L][ns][128*128], [L][ns][128] x2
+  int64_t rows; int Tlen; int rows_per_slab; int nslabs;
+};
+
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(512) void wgrad_nc_kernel(WgNcArgs a) {
+  constexpr int C = 128, KR = 32;
+  constexpr int LA = 3 * C + 16, LD = 2 * C + 16;   // LDS row strides: A tile [r(t) | r(t+1) | a], D tile [dpre | dh]
+  constexpr int VEC = 16 / sizeof(T);
+  constexpr int VPC = C / VEC;                      // 16-byte vectors per 128-channel row
+  constexpr int NV = KR * VPC / 512;                // vectors per thread per tensor tile (1 bf16, 2 f32)
+  constexpr int NB = (sizeof(T) == 2) ? 2 : 1;      // LDS buffers (two fp32 tiles of this size exceed 160 KB)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* lds = reinterpret_cast<T*>(smem);
+  auto tileA = [&](int buf) { return lds + (size_t)buf * KR * (LA + LD); };
+  auto tileD = [&](int buf) { return lds + (size_t)buf * KR * (LA + LD) + KR * LA; };
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int slab = blockIdx.x, layer = blockIdx.y;
+  const int64_t r_begin = (int64_t)slab * a.rows_per_slab;
+  const int64_t r_end = (r_begin + a.rows_per_slab < a.rows) ? r_begin + a.rows_per_slab : a.rows;
+  const int nit = (r_end > r_begin) ? (int)((r_end - r_begin + KR - 1) / KR) : 0;
+  const T* rb = reinterpret_cast<const T*>(a.r) + (int64_t)layer * a.layer_stride;
+  const T* ab = reinterpret_cast<const T*>(a.a) + (int64_t)layer * a.layer_stride;
+  const T* pb = reinterpret_cast<const T*>(a.dpre) + (int64_t)layer * a.layer_stride;
+  const T* hb = reinterpret_cast<const T*>(a.dh) + (int64_t)layer * a.layer_stride;
+
+  f32x16 accW[4], accR[2];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+#pragma unroll
+    for (int n = 0; n < 4; ++n) accW[n][q] = 0.0f;
+    accR[0][q] = 0.0f; accR[1][q] = 0.0f;
+  }
+  float bsum = 0.0f;   // threads 0..127: colsum(dpre); 128..255: colsum(dh)
+
+  f32x4 r0v[NV], r1v[NV], av[NV], pv[NV], hv[NV];
+  auto gload = [&](int it) {
+    const int64_t base = r_begin + (int64_t)it * KR;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int idx = tid + v * 512;
+      const int rr = idx / VPC, cv = (idx % VPC) * VEC;
+      const int64_t row = base + rr;
+      const bool okr = row < r_end;
+      const int64_t rowc = okr ? row : (a.rows - 1);
+      const int t = (int)(rowc % a.Tlen);
+      const bool ok1 = okr && (t + 1 < a.Tlen);           // tap t+1 stays inside the clip
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+      r0v[v] = *reinterpret_cast<const f32x4*>(rb + rowc * C + cv);
+      r1v[v] = *reinterpret_cast<const f32x4*>(rb + (ok1 ? rowc + 1 : rowc) * C + cv);
+      av[v] = *reinterpret_cast<const f32x4*>(ab + rowc * C + cv);
+      pv[v] = *reinterpret_cast<const f32x4*>(pb + rowc * C + cv);
+      hv[v] = *reinterpret_cast<const f32x4*>(hb + rowc * C + cv);
+      if (!ok1) r1v[v] = zero;
+      if (!okr) { r0v[v] = zero; av[v] = zero; pv[v] = zero; hv[v] = zero; }
+    }
+  };
+  auto lstore = [&](int buf) {
+    T* ta = tileA(buf); T* td = tileD(buf);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int idx = tid + v * 512;
+      const int rr = idx / VPC, cv = (idx % VPC) * VEC;
+      *reinterpret_cast<f32x4*>(ta + rr * LA + cv) = r0v[v];
+      *reinterpret_cast<f32x4*>(ta + rr * LA + C + cv) = r1v[v];
+      *reinterpret_cast<f32x4*>(ta + rr * LA + 2 * C + cv) = av[v];
+      *reinterpret_cast<f32x4*>(td + rr * LD + cv) = pv[v];
+      *reinterpret_cast<f32x4*>(td + rr * LD + C + cv) = hv[v];
+    }
+  };
+
+  if (nit > 0) { gload(0); lstore(0); }
+  __syncthreads();
+  for (int it = 0; it < nit; ++it) {
+    const int buf = (NB == 2) ? (it & 1) : 0;
+    if (it + 1 < nit) gload(it + 1);
+    const T* ta = tileA(buf); const T* td = tileD(buf);
+    if (tid < 2 * C) {
+#pragma unroll 8
+      for (int rr = 0; rr < KR; ++rr) bsum += (float)td[rr * LD + tid];
+    }
+#pragma unroll
+    for (int ks = 0; ks < KR / 16; ++ks) {
+      const Frag<T> a_conv = Ld2<T>::load(ta, LA, 16 * ks, 32 * wave, lane);                  // rows 32w.. of [r(t)|r(t+1)]
+      const Frag<T> a_res = Ld2<T>::load(ta, LA, 16 * ks, 2 * C + 32 * (wave >> 1), lane);    // a row tile
+#pragma unroll
+      for (int n = 0; n < 4; ++n) mma(accW[n], a_conv, Ld2<T>::load(td, LD, 16 * ks, 32 * n, lane));
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+        mma(accR[n], a_res, Ld2<T>::load(td, LD, 16 * ks, C + 32 * (2 * (wave & 1) + n), lane));
+    }
+    if (NB == 1) __syncthreads();   // every wave is done reading the only buffer
+    if (it + 1 < nit) lstore((NB == 2) ? (buf ^ 1) : 0);
+    __syncthreads();
+  }
+
+  const int col = lane & 31, half = lane >> 5;
+  const int64_t ls = (int64_t)layer * a.nslabs + slab;
+  float* pw = a.part_w + ls * (2 * C * C);   // [k*C + i][o]
+  float* pr = a.part_r + ls * (C * C);
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) pw[(int64_t)(32 * wave + crow(q, half)) * C + 32 * n + col] = accW[n][q];
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      pr[(int64_t)(32 * (wave >> 1) + crow(q, half)) * C + 32 * (2 * (wave & 1) + n) + col] = accR[n][q];
+  if (tid < C) a.part_b[ls * C + tid] = bsum;
+  else if (tid < 2 * C) a.part_br[ls * C + (tid - C)] = bsum;
+}
+
+}  // namespace
+
+extern "C" int srwn_wgrad_nc_layers(const void* r, const void* a, const void* dpre, const void* dh, int64_t layer_stride,
+                                    int32_t nlayers, float* part_w, float* part_r, float* part_b, float* part_br,
+                                    int64_t rows, int32_t T, int32_t nslabs, int32_t C, int32_t K, int32_t dtype,
+                                    void* stream) {
+  if (rows == 0 || nlayers == 0) return 0;
+  if (!r || !a || !dpre || !dh || !part_w || !part_r || !part_b || !part_br)
+    return set_error(SRWN_E_NULL, "wgrad_nc_layers: null pointer");
+  if (C != 128 || K != 2) return set_error(SRWN_E_UNSUPPORTED, "wgrad_nc_layers: built for 128 channels, K=2 (got C=%d K=%d)", C, K);
+  if (nlayers < 0 || nlayers > 65535 || rows < 0 || T < 1 || rows % T || nslabs < 1)
+    return set_error(SRWN_E_SHAPE, "wgrad_nc_layers: nlayers=%d rows=%lld T=%d nslabs=%d", nlayers, (long long)rows, T, nslabs);
+  WgNcArgs g{r, a, dpre, dh, layer_stride, part_w, part_r, part_b, part_br, rows, T, 0, nslabs};
+  int64_t rps = (rows + nslabs - 1) / nslabs;
+  rps = (rps + 31) / 32 * 32;
+  g.rows_per_slab = (int)rps;
+  dim3 grid((unsigned)nslabs, (unsigned)nlayers), block(512);
+  hipStream_t st = (hipStream_t)stream;
+#define SRWN_WNC(TT)                                                                                           \
+  {                                                                                                            \
+    auto kfn = wgrad_nc_kernel<TT>;                                                                            \
+    const size_t sh = (size_t)(sizeof(TT) == 2 ? 2 : 1) * 32 * (5 * 128 + 32) * sizeof(TT);                    \
+    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+    if (e != hipSuccess) return set_error((int)e, "wgrad_nc_layers: LDS %zu: %s", sh, hipGetErrorString(e));   \
+    hipLaunchKernelGGL(kfn, grid, block, sh, st, g);                                                           \
+    return check_launch("wgrad_nc_layers");                                                                    \
+  }
+  if (dtype == SRWN_BF16) SRWN_WNC(bf16_t)
+  if (dtype == SRWN_F32) SRWN_WNC(float)
+#undef SRWN_WNC
+  return set_error(SRWN_E_DTYPE, "wgrad_nc_layers: dtype %d", dtype);
+}

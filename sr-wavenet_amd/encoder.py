@@ -196,8 +196,13 @@ class EncoderStack:
         self.da_all = f(self.rows_c, L * EC)
         self.nslabs = K.wgrad_slabs(N)
         self.nslabs_c = K.wgrad_slabs(self.rows_c)
-        self.wg_parts = f(max(self.nslabs * L * EC * EC, self.nslabs_c * L * EC * S))
-        self.wg_bparts = f(max(self.nslabs * L * EC, self.nslabs_c * L * S))
+        self.wg_parts = f(max(self.nslabs * EC * EC, self.nslabs_c * L * EC * S))
+        self.wg_bparts = f(max(self.nslabs * EC, self.nslabs_c * L * S))
+        # fused per-layer weight-gradient pass: about two 8-wave workgroups per CU over (slab, layer)
+        self.ns_enc = max(1, min(self.nslabs, max(4, 512 // max(L, 1))))
+        ne = self.ns_enc
+        self.pe_w = f(L * ne * self.Kw * EC * EC); self.pe_r = f(L * ne * EC * EC)
+        self.pe_b = f(L * ne * EC); self.pe_br = f(L * ne * EC)
         from . import _lib
         self.ic_ws = f(int(_lib.load().srwn_init_conv_wgrad_partials(B, T, EC, self.Kw)))
 
@@ -260,26 +265,24 @@ class EncoderStack:
                       aux=self.a[l + 1], fadd_ptr=self.da_all.data_ptr() + 4 * l * EC)
             self._tap(self.dpre[l + 1], Kw, -1, self.wptr(self.o_convT[l]), None, self.dh[l], K.EPI_MASK, aux=self.r[l])
         self._tap(self.dh[0], 1, 0, self.wptr(self.o_nc_wrT), None, self.dpre[0], K.EPI_MASK, aux=self.a[0])
-        # weight gradients: residual 1x1s ('nc_conv' + layers 0..L-2) in one batched pass
+        # weight gradients of the L layers -- both conv taps, the 1x1 residual and the two biases -- in ONE pass over
+        # r, a, dpre, dh (layer l: r[l], a[l+1], dpre[l+1], dh[l+1]; the last layer's residual 1x1 sees dh[L] = 0)
         NE = N * EC
-        K.wgrad(self.a.data_ptr(), NE, EC, self.dh.data_ptr(), NE, EC, None, L, self.wg_parts, self.wg_bparts, N, T,
-                self.nslabs, dt)
+        ne = self.ns_enc
+        call("srwn_wgrad_nc_layers", self.r.data_ptr(), self.a[1].data_ptr(), self.dpre[1].data_ptr(),
+             self.dh[1].data_ptr(), NE, L, self.pe_w.data_ptr(), self.pe_r.data_ptr(), self.pe_b.data_ptr(),
+             self.pe_br.data_ptr(), N, T, ne, EC, Kw, K.abi_dtype(dt), st)
+        K.reduce_partials(self.pe_w, ne, Kw * EC * EC, L, True, 1.0, gp + 4 * sec["EW"].offset, Kw * EC * EC)
+        K.reduce_partials(self.pe_b, ne, EC, L, True, 1.0, gp + 4 * sec["EB"].offset, EC)
+        K.reduce_partials(self.pe_r, ne, EC * EC, L, True, 1.0, gp + 4 * sec["EWR"].offset, EC * EC)
+        K.reduce_partials(self.pe_br, ne, EC, L, True, 1.0, gp + 4 * sec["EBR"].offset, EC)
+        # 'nc_conv': its residual 1x1 (a[0], dh[0]) ...
         ns = self.nslabs
+        K.wgrad(self.a.data_ptr(), NE, EC, self.dh.data_ptr(), NE, EC, None, 1, self.wg_parts, self.wg_bparts, N, T, ns,
+                dt)
         K.reduce_partials(self.wg_parts, ns, EC * EC, 1, True, 1.0, gp + 4 * sec["nc_wr"].offset, 0)
         K.reduce_partials(self.wg_bparts, ns, EC, 1, True, 1.0, gp + 4 * sec["nc_br"].offset, 0)
-        if L > 1:
-            K.reduce_partials(self.wg_parts[ns * EC * EC:], ns, EC * EC, L - 1, True, 1.0, gp + 4 * sec["EWR"].offset,
-                              EC * EC)
-            K.reduce_partials(self.wg_bparts[ns * EC:], ns, EC, L - 1, True, 1.0, gp + 4 * sec["EBR"].offset, EC)
-        # conv taps: dW_l[k] = sum_t r_l[t+k]^T dpre_{l+1}[t]
-        for k in range(Kw):
-            K.wgrad(self.r.data_ptr(), NE, EC, self.dpre[1].data_ptr(), NE, EC, [-(k - (Kw - 1) // 2)] * L, L,
-                    self.wg_parts, self.wg_bparts if k == 0 else None, N, T, ns, dt)
-            K.reduce_partials(self.wg_parts, ns, EC * EC, L, True, 1.0, gp + 4 * (sec["EW"].offset + k * EC * EC),
-                              Kw * EC * EC)
-            if k == 0:
-                K.reduce_partials(self.wg_bparts, ns, EC, L, True, 1.0, gp + 4 * sec["EB"].offset, EC)
-        # 'nc_conv' on the raw clip: taps relu(x)[t+k]
+        # ... and its K-tap conv on the raw clip: taps relu(x)[t+k]
         call("srwn_clamp", self.x.data_ptr(), self.xr.data_ptr(), N, 0.0, 3.0e38, st)
         K.init_conv_wgrad(self.xr, self.dpre[0].view(B, T, EC), v("nc_w", g).reshape(-1), v("nc_b", g), Kw,
                           -(Kw - 1) + (Kw - 1) // 2, self.ic_ws)
