@@ -197,3 +197,33 @@ def test_autoencoder_engine_vs_committed_golden(golden_dir):
     L.call("srwn_mol_sample", lgd.data_ptr(), 4 * M, M, u1.data_ptr(), u2.data_ptr(), out.data_ptr(), B * T,
            torch.cuda.current_stream().cuda_stream)
     assert (np.abs(out.cpu().numpy().reshape(B, T) - g["sample"]) < 1e-3).mean() > 0.995
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-4), (torch.bfloat16, 2e-2)])
+def test_wgrad_nc_layers_kernel(dt, tol):
+    """srwn_wgrad_nc_layers: both conv taps (t, t+1 inside the clip), the 1x1 and the two bias gradients of every
+    encoder layer in one pass."""
+    L_, K = sub("_lib"), sub("kernels")
+    rng = np.random.default_rng(12)
+    L, B, T, C, ns = 3, 2, 173, 128, 5
+    rows = B * T
+    mk = lambda: torch.tensor(rng.standard_normal((L, rows, C)), dtype=dt, device=DEV)
+    r, a, dp, dh = mk(), mk(), mk(), mk()
+    f = lambda *s: torch.full(s, float("nan"), dtype=torch.float32, device=DEV)
+    pw, pr, pb, pbr = f(L * ns * 2 * C * C), f(L * ns * C * C), f(L * ns * C), f(L * ns * C)
+    L_.call("srwn_wgrad_nc_layers", r.data_ptr(), a.data_ptr(), dp.data_ptr(), dh.data_ptr(), rows * C, L, pw.data_ptr(),
+            pr.data_ptr(), pb.data_ptr(), pbr.data_ptr(), rows, T, ns, C, 2, K.abi_dtype(dt),
+            torch.cuda.current_stream().cuda_stream)
+    ow, orr = torch.empty((L, 2, C, C), device=DEV), torch.empty((L, C, C), device=DEV)
+    ob, obr = torch.empty((L, C), device=DEV), torch.empty((L, C), device=DEV)
+    K.reduce_partials(pw, ns, 2 * C * C, L, True, 1.0, ow.data_ptr(), 2 * C * C)
+    K.reduce_partials(pr, ns, C * C, L, True, 1.0, orr.data_ptr(), C * C)
+    K.reduce_partials(pb, ns, C, L, True, 1.0, ob.data_ptr(), C); K.reduce_partials(pbr, ns, C, L, True, 1.0, obr.data_ptr(), C)
+    q = lambda t: t.double().cpu().numpy().reshape(L, B, T, C)
+    rq, aq, pq, hq = q(r), q(a), q(dp), q(dh)
+    for l in range(L):
+        w0 = np.einsum("bti,bto->io", rq[l], pq[l])
+        w1 = np.einsum("bti,bto->io", rq[l][:, 1:], pq[l][:, :-1])          # r[t+1]^T dpre[t], nothing across clips
+        assert rel_err(ow[l, 0].cpu().numpy(), w0) < tol and rel_err(ow[l, 1].cpu().numpy(), w1) < tol
+        assert rel_err(orr[l].cpu().numpy(), np.einsum("btn,btm->nm", aq[l], hq[l])) < tol
+        assert rel_err(ob[l].cpu().numpy(), pq[l].sum((0, 1))) < tol and rel_err(obr[l].cpu().numpy(), hq[l].sum((0, 1))) < tol
