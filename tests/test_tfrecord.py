@@ -223,3 +223,42 @@ def test_simple_audio_wave_batches():
     # label = one-hot of int(f/2 - 1) - 10 for f in 22..39  ->  indices 0..8
     assert y.argmax(1).min() >= 0 and y.argmax(1).max() <= 8
     assert np.allclose(SA.Normalize(np.array([2.0, 4.0, 3.0]), -1, 1), [-1, 1, 0])
+
+
+def test_parser_survives_mutated_payloads(nsynth_file, tmp_path):
+    """Robustness of the protobuf wire reader: random byte damage inside payloads (CRC checks off) must end in a
+    value or a RuntimeError, never in a crash or an out-of-bounds read (every length is checked against its span)."""
+    NS = sub("nsynth")
+    path, exs = nsynth_file
+    raw = open(path, "rb").read()
+    rng = np.random.default_rng(0)
+    bad = tmp_path / "fuzz.tfrecord"
+    first_len = struct.unpack("<Q", raw[:8])[0]
+    outcomes = {"ok": 0, "err": 0}
+    for trial in range(150):
+        buf = bytearray(raw)
+        for _ in range(int(rng.integers(1, 6))):
+            pos = 12 + int(rng.integers(0, first_len))           # inside the first record's payload
+            buf[pos] = int(rng.integers(0, 256))
+        bad.write_bytes(buf)
+        f = NS.TFRecordFile(str(bad), verify_crc=False)
+        for key in ("audio", "pitch", "note_str", "qualities"):
+            try:
+                v = f.feature(0, key)
+                assert v is not None
+                outcomes["ok"] += 1
+            except RuntimeError:
+                outcomes["err"] += 1
+        try:
+            f.batch([0, 1], 64, audio_len=640)
+        except RuntimeError:
+            pass
+        f.close()
+    assert outcomes["ok"] > 0 and outcomes["err"] > 0
+    # truncated varints / lengths running past the record
+    for payload in (b"\x0a\xff\xff\xff\xff\x0f", b"\x0a\x05\x0a\x03\x0a\x01", b"\x0a\x80", b"\x0a\x02\x0a\x7f"):
+        bad.write_bytes(record(payload))
+        g = NS.TFRecordFile(str(bad))
+        with pytest.raises(RuntimeError):
+            g.feature(0, "audio")
+        g.close()
