@@ -211,7 +211,7 @@ extern "C" int srwn_causal_conv1d_fwd(const float* x, const float* w, const floa
                                       int32_t shift, int32_t dtype_out, void* stream) {
   if (B == 0 || T == 0) return 0;
   if (!x || !w || !y) return set_error(SRWN_E_NULL, "causal_conv1d_fwd: null pointer");
-  if (B < 0 || T < 0 || Cin < 1 || Cout < 1 || K < 1 || dilation < 1 || shift <= -T || shift >= T)
+  if (B < 0 || T < 0 || Cin < 1 || Cout < 1 || K < 1 || dilation < 1 || shift < -(1 << 30) || shift > (1 << 30))
     return set_error(SRWN_E_SHAPE, "causal_conv1d_fwd: B=%d T=%d Cin=%d Cout=%d K=%d d=%d shift=%d", B, T, Cin, Cout,
                      K, dilation, shift);
   if (Cin == 1 && Cout % 8 == 0 && (dtype_out == SRWN_F32 || dtype_out == SRWN_BF16)) {

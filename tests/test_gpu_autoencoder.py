@@ -126,15 +126,16 @@ def _ae(dt, R, S, cs, B=2, T=256, pool=32, lat=8, M=5, dil=(1, 2, 4), lr=1e-3):
     ae = EN.AutoEncoderEngine(cfg, B, T, 128, lat, cs, DEV)
     ae.enc.load_oracle_params(ep); ae.dec.load_oracle_params(dp_)
     x = O.synthetic_audio(B, T, seed=21).astype(np.float64)
-    c = np.eye(max(cs, 1))[[0, cs - 1]][:, :cs] if cs else None
+    c = np.eye(max(cs, 1))[[(i * 7) % cs for i in range(B)]][:, :cs] if cs else None
     ae.set_inputs(dev(x), None if c is None else dev(c))
     return ae, ep, dp_, x, c, pool
 
 
 @pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-3), (torch.bfloat16, 6e-2)])
-@pytest.mark.parametrize("R,S,cs", [(64, 256, 3), (32, 128, 0)])
-def test_autoencoder_forward_backward(dt, tol, R, S, cs):
-    ae, ep, dp_, x, c, pool = _ae(dt, R, S, cs)
+@pytest.mark.parametrize("R,S,cs,B,T,pool", [(64, 256, 3, 2, 256, 32), (32, 128, 0, 2, 256, 32), (64, 256, 0, 1, 32, 32),
+                                             (32, 128, 2, 3, 96, 32), (64, 128, 0, 2, 50, 25)])
+def test_autoencoder_forward_backward(dt, tol, R, S, cs, B, T, pool):
+    ae, ep, dp_, x, c, pool = _ae(dt, R, S, cs, B=B, T=T, pool=pool)
     B, T = x.shape
     ref = O.autoencoder_forward(ep, dp_, x, pool, c)
     lg = ae.forward(want_logits=True)

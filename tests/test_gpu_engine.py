@@ -291,3 +291,39 @@ def test_bucketed_allreduce_schedule_matches_plain_step(monkeypatch):
             assert torch.equal(p, p_plain) and l == l_plain, graph
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 7), (1, 31), (2, 33), (5, 65)])
+@pytest.mark.parametrize("R,S", [(64, 256), (32, 128)])
+def test_stack_degenerate_clip_lengths(B, T, R, S):
+    """Clips shorter than one 32-step tile, shorter than the dilations, one sample long: forward, loss and every
+    gradient against the oracle (fp32), with canaries around the activation buffers to catch out-of-bounds stores."""
+    dil = [1, 2, 4, 8, 16, 32, 1, 2]
+    C = 256
+    sp = O.init_stack_params(33, dil, 2, R, S, C, bias_scale=0.05)
+    rng = np.random.default_rng(B * 100 + T)
+    audio = rng.uniform(-1, 1, (B, T))
+    codes = rng.integers(0, C, (B, T))
+    logits, cache = O.stack_forward(sp, audio, shift_input=True)
+    loss = O.softmax_ce_per_timestep(logits, codes)
+    grads, _ = O.stack_backward(sp, cache, O.dlogits_per_timestep(logits, codes))
+    eng = _engine(sp, B, T, R, S, C, torch.float32)
+    # re-home the big activation stacks inside canary-padded storage
+    pad = 4096
+    guards = []
+    for name in ("xs", "zs", "dfs", "gs", "dcs", "r0", "r1", "da1", "dtotal", "dlogits"):
+        if not hasattr(eng, name):
+            continue
+        t = getattr(eng, name)
+        big = torch.full((t.numel() + 2 * pad,), 12345.0, dtype=t.dtype, device=DEV)
+        big[pad:pad + t.numel()] = 0
+        setattr(eng, name, big[pad:pad + t.numel()].view(t.shape))
+        guards.append((name, big, t.numel()))
+    eng.set_inputs(dev(audio), dev(codes, torch.int32))
+    lg = eng.forward(want_logits=True)
+    assert rel_err(lg.cpu().numpy(), logits) < 1e-3
+    assert abs(float(eng.loss.item()) - loss) < 1e-3 * loss
+    eng.backward()
+    _check_grads(eng, grads, 1e-3)
+    for name, big, n in guards:
+        assert bool((big[:pad] == 12345.0).all()) and bool((big[pad + n:] == 12345.0).all()), name
