@@ -26,7 +26,8 @@ def _engine(dt, dil, B, T, C=256, seed=4, R=64, S=256):
 @pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-3), (torch.bfloat16, 6e-2)])
 @pytest.mark.parametrize("B,T,C,R,S", [(3, 300, 256, 64, 256), (32, 70, 256, 64, 256), (1, 130, 100, 64, 256),
                                        (70, 40, 256, 64, 256), (3, 300, 256, 32, 256), (40, 70, 100, 32, 256),
-                                       (3, 300, 256, 32, 128), (33, 70, 256, 64, 128)])
+                                       (3, 300, 256, 32, 128), (33, 70, 256, 64, 128), (2, 1, 256, 64, 256),
+                                       (1, 3, 256, 32, 128)])
 def test_incremental_logits_equal_full_forward(dt, tol, B, T, C, R, S):
     dil = [1, 2, 4, 8, 16, 32, 64, 128, 1, 2, 5]
     eng, sp = _engine(dt, dil, B, T, C, R=R, S=S)

@@ -188,9 +188,10 @@ def _oracle_grads(flows, noise, cond, pool, tl, truth, abg):
 
 
 @pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-3), (torch.bfloat16, 6e-2)])
-@pytest.mark.parametrize("R,S,F", [(64, 256, 2), (32, 128, 3)])
-def test_student_forward_backward_step(dt, tol, R, S, F):
-    stu, flows, noise, cond, truth, tl, pool, abg = _setup(dt, R, S, F)
+@pytest.mark.parametrize("R,S,F,B,T,pool", [(64, 256, 2, 2, 1024, 64), (32, 128, 3, 2, 1024, 64), (64, 256, 1, 1, 512, 64),
+                                            (32, 128, 2, 3, 640, 128)])
+def test_student_forward_backward_step(dt, tol, R, S, F, B, T, pool):
+    stu, flows, noise, cond, truth, tl, pool, abg = _setup(dt, R, S, F, B=B, T=T, pool=pool)
     B, T = noise.shape
     fw = O.student_forward(flows, noise, cond, pool)
     assert (np.abs(fw["out"]) < 1).mean() > 0.9
