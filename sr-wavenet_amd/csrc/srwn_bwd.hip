@@ -49,7 +49,7 @@ template <> struct Raw4<float> {
 };
 
 template <typename T, int RT, int K, int UPM, bool GIN, bool DOWN, int SK>
-__global__ __launch_bounds__(256) void layer_bwd_kernel(LayerBwdArgs a) {
+__global__ __launch_bounds__(256, (sizeof(T) == 2 && SK != 0) ? 2 : 1) void layer_bwd_kernel(LayerBwdArgs a) {
   constexpr int R = 32 * RT, KS = R / 16;
   constexpr bool UP = UPM == 1, HAVEG = UPM != 0, DCS = SK == 1, LEGACY = SK == 0;
   typedef typename Raw4<T>::type raw4;
@@ -59,8 +59,15 @@ __global__ __launch_bounds__(256) void layer_bwd_kernel(LayerBwdArgs a) {
   Frag<T>* lds_res = lds_conv + (UP ? RT * K * KS * 64 : 0);               // [RT*KS][64]     (HAVEG && DOWN)
   Frag<T>* lds_skip = lds_res + ((HAVEG && DOWN) ? RT * KS * 64 : 0);      // [RT*KSS][64]    (DOWN && LEGACY)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  T* stage = reinterpret_cast<T*>(lds_skip + ((DOWN && LEGACY) ? RT * KSS * 64 : 0)) +
-             wave * (32 * RowStage<T>::stride(R));
+  // ROWS (bf16, precomputed-dcs and flow paths): operands are fetched as WHOLE ROWS (16 B per lane, 8 lines per
+  // instruction) into registers two tiles ahead, dropped into a wave-private padded LDS tile and read back in
+  // fragment / accumulator layout.  Fetching them directly in those layouts touches 32 cache lines per
+  // instruction and caps the kernel at 3.9 TB/s (tools/micro/membench3.hip: 25.4 us vs 19.1 us per launch).
+  constexpr bool ROWS = sizeof(T) == 2 && !LEGACY;
+  constexpr int LS = RowStage<T>::stride(R), VEC = RowStage<T>::VEC;
+  constexpr int LPR = R / VEC, RPI = 64 / LPR, NI = 32 / RPI;
+  T* stage_all = reinterpret_cast<T*>(lds_skip + ((DOWN && LEGACY) ? RT * KSS * 64 : 0));
+  T* stage = stage_all + wave * (32 * LS);
   if (UP) lds_dma_copy(a.wconvT, lds_conv, RT * K * KS * 64 * (int)sizeof(Frag<T>), wave, lane, 4);
   if (HAVEG && DOWN) lds_dma_copy(a.wresT, lds_res, RT * KS * 64 * (int)sizeof(Frag<T>), wave, lane, 4);
   if (DOWN && LEGACY) lds_dma_copy(a.wskipT, lds_skip, RT * KSS * 64 * (int)sizeof(Frag<T>), wave, lane, 4);
@@ -119,6 +126,66 @@ __global__ __launch_bounds__(256) void layer_bwd_kernel(LayerBwdArgs a) {
       for (int mt = 0; mt < RT; ++mt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) t.zz[mt][g] = Raw4<T>::load(zr + 32 * mt + 8 * g + 4 * half);
+    }
+  };
+
+  struct RTile {
+    f32x4 gin[NI], dfu[K][NI], dcs[NI], zz[NI];
+  };
+  const int rsub = lane / LPR, piece = lane % LPR;
+  auto load_rows = [&](int tile_, RTile& t) {
+    const int tile = tile_ < a.ntiles ? tile_ : a.ntiles - 1;
+    const int b = tile / a.ntb;
+    const int t0 = (tile - b * a.ntb) * 32;
+    const size_t boff = (size_t)b * a.Tlen;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int tc = t0 + i * RPI + rsub;
+      const int tcc = tc < a.Tlen ? tc : a.Tlen - 1;
+      const size_t off = (boff + tcc) * R + piece * VEC;
+      if (UPM == 2) t.gin[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const T*>(a.g_out) + off);
+      if (UP) {
+        if (GIN) t.gin[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const T*>(a.g_in) + off);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const int tk = tcc + (K - 1 - k) * a.dil_up;
+          const int tkc = tk < a.Tlen ? tk : a.Tlen - 1;
+          t.dfu[k][i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const T*>(a.df_up) + (boff + tkc) * R + piece * VEC);
+        }
+      }
+      if (DOWN) {
+        if (DCS) t.dcs[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const T*>(a.dcs) + off);
+        t.zz[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const T*>(a.z) + off);
+      }
+    }
+  };
+  // registers (whole rows) -> the wave's LDS row tile -> registers in the layouts `process` consumes, one operand
+  // at a time through the same 32 x LS buffer the stores use (LDS runs one wave's instructions in order)
+  auto put_rows = [&](const f32x4 (&v)[NI]) {
+    wave_lds_order();                     // earlier reads of the buffer are done
+#pragma unroll
+    for (int i = 0; i < NI; ++i) *reinterpret_cast<f32x4*>(stage + (i * RPI + rsub) * LS + piece * VEC) = v[i];
+    wave_lds_order();
+  };
+  auto get_acc = [&](raw4 (&o)[RT][4]) {
+#pragma unroll
+    for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) o[mt][g] = Raw4<T>::load(stage + col * LS + 32 * mt + 8 * g + 4 * half);
+  };
+  auto fetch_tile = [&](const RTile& r, Tile& t) {
+    if (UPM == 2 || (UP && GIN)) { put_rows(r.gin); get_acc(t.gin); }
+    if (UP) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        put_rows(r.dfu[k]);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) t.dfu[k][ks] = load_nat(stage + col * LS + 16 * ks + 8 * half);
+      }
+    }
+    if (DOWN) {
+      if (DCS) { put_rows(r.dcs); get_acc(t.dcs); }
+      put_rows(r.zz); get_acc(t.zz);
     }
   };
 
@@ -214,28 +281,42 @@ __global__ __launch_bounds__(256) void layer_bwd_kernel(LayerBwdArgs a) {
   };
 
   const int stride = gridDim.x * 4;
-  Tile ta, tb;
   int tile = blockIdx.x * 4 + wave;
-  load_tile(tile, ta);
-  __syncthreads();
-  while (tile < a.ntiles) {
-    load_tile(tile + stride, tb);
-    process(tile, ta);
-    tile += stride;
-    if (tile >= a.ntiles) break;
-    load_tile(tile + stride, ta);
-    process(tile, tb);
-    tile += stride;
+  if constexpr (ROWS) {
+    // two waves per SIMD (<= 256 registers): the other wave's loads cover this one's LDS and MFMA phases
+    RTile r;
+    Tile t;
+    load_rows(tile, r);
+    __syncthreads();
+    while (tile < a.ntiles) {
+      fetch_tile(r, t);
+      if (tile + stride < a.ntiles) load_rows(tile + stride, r);
+      process(tile, t);
+      tile += stride;
+    }
+  } else {
+    Tile ta, tb;
+    load_tile(tile, ta);
+    __syncthreads();
+    while (tile < a.ntiles) {
+      load_tile(tile + stride, tb);
+      process(tile, ta);
+      tile += stride;
+      if (tile >= a.ntiles) break;
+      load_tile(tile + stride, ta);
+      process(tile, tb);
+      tile += stride;
+    }
   }
 }
 
-static int bwd_blocks_per_cu() {
+static int bwd_blocks_per_cu(int dflt) {
   static const int v = [] {
     const char* e = getenv("SRWN_BWD_BPC");
-    int x = e ? atoi(e) : 1;
-    return x < 1 ? 1 : (x > 8 ? 8 : x);
+    int x = e ? atoi(e) : 0;
+    return x < 0 ? 0 : (x > 8 ? 8 : x);
   }();
-  return v;
+  return v ? v : dflt;
 }
 
 template <typename T, int RT>
@@ -245,12 +326,14 @@ static int launch_layer_bwd(LayerBwdArgs a, int B, int up, bool gin, bool down, 
   if (up == 1) frags += RT * K * KS;
   if (up && down) frags += RT * KS;
   if (down && sk == 0) frags += (size_t)RT * (a.S / 16);
+  const bool rows = sizeof(T) == 2 && sk != 0;   // whole-row operand staging (kernel: ROWS)
   const size_t sh = frags * 64 * sizeof(Frag<T>) + (size_t)4 * 32 * RowStage<T>::stride(R) * sizeof(T);
   a.ntb = (a.Tlen + 31) / 32;
   const long long ntiles = (long long)B * a.ntb;
   a.ntiles = (int)ntiles;
   long long blocks = (ntiles + 3) / 4;
-  if (blocks > 256LL * bwd_blocks_per_cu()) blocks = 256LL * bwd_blocks_per_cu();
+  const int bpc = bwd_blocks_per_cu(rows ? 2 : 1);
+  if (blocks > 256LL * bpc) blocks = 256LL * bpc;
   dim3 grid((unsigned)blocks), block(256);
 #define SRWN_LB(U, G, D, C)                                                                                    \
   if (up == U && gin == G && down == D && sk == C) {                                                          \
