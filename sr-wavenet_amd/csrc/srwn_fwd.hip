@@ -68,8 +68,9 @@ __global__ __launch_bounds__(256) void layer_fwd_kernel(const T* __restrict__ x,
   Frag<T>* lds_res = lds_conv + NCONV * 64;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   T* stage = reinterpret_cast<T*>(lds_res + NRES * 64) + wave * (32 * RowStage<T>::stride(R));   // wave-private
+  constexpr int NIMG = NBUF ? NBUF : 1;   // NBUF 0: one image set, the next tile waits in registers
   T* ximg = reinterpret_cast<T*>(lds_res + NRES * 64) + 4 * (32 * RowStage<T>::stride(R)) +
-            wave * (NBUF * K * TILE_E);                                                          // [NBUF][K][32][R]
+            wave * (NIMG * K * TILE_E);                                                          // [NIMG][K][32][R]
   lds_dma_copy(wconv, lds_conv, NCONV * 64 * (int)sizeof(Frag<T>), wave, lane, 4);
   lds_dma_copy(wres, lds_res, NRES * 64 * (int)sizeof(Frag<T>), wave, lane, 4);
 
@@ -104,6 +105,36 @@ __global__ __launch_bounds__(256) void layer_fwd_kernel(const T* __restrict__ x,
                                          (__attribute__((address_space(3))) void*)(img + p * (1024 / (int)sizeof(T))), 16, 0, 0);
       }
     }
+  };
+
+  // NBUF 0: the same whole-row pieces fetched into registers (in flight while the previous tile is processed) and
+  // dropped into the image with ds_write_b128 -- the compiler tracks these loads per register, so the prefetch
+  // costs no LDS and needs no hand-counted vmcnt.
+  f32x4 xr[K][PIECES];
+  auto load_regs = [&](int tile) {
+    const int b = tile / ntb;
+    const int t0 = (tile - b * ntb) * 32;
+    const T* xb = x + (size_t)b * Tlen * R;
+    const int rl0 = lane / CPR, slot = lane % CPR;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int p = 0; p < PIECES; ++p) {
+        const int rl = p * RPP + rl0;
+        int tr = t0 + rl - (K - 1 - k) * dilation;
+        tr = tr < 0 ? 0 : (tr < Tlen ? tr : Tlen - 1);
+        const int c = slot ^ (rl & (CPR - 1));
+        xr[k][p] = *reinterpret_cast<const f32x4*>(xb + (size_t)tr * R + c * VEC);
+      }
+  };
+  auto put_regs = [&]() {
+    wave_lds_order();                     // the previous tile's reads of the image are done
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int p = 0; p < PIECES; ++p)
+        *reinterpret_cast<f32x4*>(ximg + k * TILE_E + p * (1024 / (int)sizeof(T)) + lane * VEC) = xr[k][p];
+    wave_lds_order();
   };
 
   // one tile: conv MFMAs -> tanh/gate -> residual MFMAs -> whole-row stores
@@ -192,6 +223,17 @@ __global__ __launch_bounds__(256) void layer_fwd_kernel(const T* __restrict__ x,
 
   const int stride = gridDim.x * 4;
   int tile = blockIdx.x * 4 + wave;
+  if (NBUF == 0) {
+    load_regs(tile < ntiles ? tile : ntiles - 1);
+    __syncthreads();   // weights landed
+    while (tile < ntiles) {
+      put_regs();
+      if (tile + stride < ntiles) load_regs(tile + stride);
+      process(tile, 0);
+      tile += stride;
+    }
+    return;
+  }
   fetch(tile, 0);
   __syncthreads();   // weights + first tile landed (vmcnt(0) + barrier)
   if (NBUF == 2) {
@@ -235,7 +277,8 @@ static int launch_layer_fwd_n(const void* x, const void* cond, const void* wconv
                               int dilation, int cond_frames, int pool, int cond_stride, hipStream_t st) {
   constexpr int R = 32 * RT, KS = R / 16;
   const size_t sh = (size_t)(RT * K * KS + RT * KS) * 64 * sizeof(Frag<T>) +
-                    (size_t)4 * 32 * RowStage<T>::stride(R) * sizeof(T) + (size_t)4 * NBUF * K * 32 * R * sizeof(T);
+                    (size_t)4 * 32 * RowStage<T>::stride(R) * sizeof(T) +
+                    (size_t)4 * (NBUF ? NBUF : 1) * K * 32 * R * sizeof(T);
   const int ntb = (Tlen + 31) / 32;
   const long long ntiles = (long long)B * ntb;
   static const int bpc = layer_blocks_per_cu("SRWN_FWD_BPC", 2);   // single-buffered images: 74 KB LDS -> 2 blocks/CU
@@ -260,32 +303,11 @@ template <typename T, int RT, int K>
 static int launch_layer_fwd(const void* x, const void* cond, const void* wconv, const void* wres,
                             const float* bias_f, const float* bias_r, void* h_out, void* z_out, int B, int Tlen,
                             int dilation, int cond_frames, int pool, int cond_stride, hipStream_t st) {
-  static const int nbuf_env = [] { const char* e = getenv("SRWN_FWD_NBUF"); return e ? atoi(e) : 1; }();
+  static const int nbuf_env = [] { const char* e = getenv("SRWN_FWD_NBUF"); return e ? atoi(e) : 0; }();
+  if (sizeof(T) == 2 && nbuf_env == 0) return launch_layer_fwd_n<T, RT, K, 0>(x, cond, wconv, wres, bias_f, bias_r, h_out, z_out, B, Tlen, dilation, cond_frames, pool, cond_stride, st);
   if (sizeof(T) == 2 && nbuf_env == 1) return launch_layer_fwd_n<T, RT, K, 1>(x, cond, wconv, wres, bias_f, bias_r, h_out, z_out, B, Tlen, dilation, cond_frames, pool, cond_stride, st);
   return launch_layer_fwd_n<T, RT, K, (sizeof(T) == 2) ? 2 : 1>(x, cond, wconv, wres, bias_f, bias_r, h_out, z_out, B, Tlen, dilation, cond_frames, pool, cond_stride, st);
 }
-#if 0
-  const size_t sh = (size_t)(RT * K * KS + RT * KS) * 64 * sizeof(Frag<T>) +
-                    (size_t)4 * 32 * RowStage<T>::stride(R) * sizeof(T) + (size_t)4 * NBUF * K * 32 * R * sizeof(T);
-  const int ntb = (Tlen + 31) / 32;
-  const long long ntiles = (long long)B * ntb;
-  static const int bpc = layer_blocks_per_cu("SRWN_FWD_BPC", 2);   // single-buffered images: 74 KB LDS -> 2 blocks/CU
-  long long blocks = (ntiles + 3) / 4;
-  if (blocks > 256LL * bpc) blocks = 256LL * bpc;
-  dim3 grid((unsigned)blocks), block(256);
-  if (cond) {
-    auto kfn = layer_fwd_kernel<T, RT, K, true, NBUF>;
-    if (sh > 32768) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    hipLaunchKernelGGL(kfn, grid, block, sh, st, (const T*)x, (const T*)cond, (const T*)wconv, (const T*)wres, bias_f,
-                       bias_r, (T*)h_out, (T*)z_out, Tlen, dilation, cond_frames, pool, cond_stride, ntb, (int)ntiles);
-  } else {
-    auto kfn = layer_fwd_kernel<T, RT, K, false, NBUF>;
-    if (sh > 32768) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    hipLaunchKernelGGL(kfn, grid, block, sh, st, (const T*)x, (const T*)nullptr, (const T*)wconv, (const T*)wres,
-                       bias_f, bias_r, (T*)h_out, (T*)z_out, Tlen, dilation, 1, 1, R, ntb, (int)ntiles);
-  }
-  return 0;
-#endif
 
 
 extern "C" int srwn_residual_layer_fwd(const void* x, const void* cond, const void* wconv, const void* wres,

@@ -288,8 +288,14 @@ namespace {
 // RC wide; D tile [df | G].  RC = 64: wave w owns conv row tile w (rows 32w.. of [xd|xc]) x both df column tiles and
 // dWr tile (w>>1, w&1).  RC = 32: waves 0/1 own the two conv row tiles, wave 2 the single dWr tile (the pass is
 // HBM-bound; the idle wave costs nothing), and 64 rows are staged per step so every thread still moves one vector.
-template <typename T, bool COND, int RC>
-__global__ __launch_bounds__(256) void wgrad_layer_kernel(WgLArgs a) {
+// NG = row groups per workgroup: each group of 4 waves streams its own contiguous share of the slab through its
+// own pair of LDS tiles (all groups in step, one barrier per chunk) and the groups' accumulators are summed
+// through LDS before the partial is written.  A launch covers a few layers x ~42 slabs, i.e. about one workgroup per
+// CU: with a single group that leaves one 20-KB chunk in flight per CU and the pass is latency-bound (3.5 TB/s;
+// the same kernel at 3 workgroups per CU streams 4.7 TB/s) -- more groups, not more slabs, because every slab is
+// another fp32 partial for reduce_partials to read.
+template <typename T, bool COND, int RC, int NG>
+__global__ __launch_bounds__(256 * NG) void wgrad_layer_kernel(WgLArgs a) {
   constexpr int KR = (RC == 64) ? 32 : 64;      // rows staged per step
   constexpr int LA = 3 * RC + 16, LD = 2 * RC + 16;   // LDS row strides (elements, 16-byte multiples)
   constexpr int CT = RC / 32;                   // column tiles of df / G
@@ -298,15 +304,20 @@ __global__ __launch_bounds__(256) void wgrad_layer_kernel(WgLArgs a) {
   constexpr int NV = KR * VPC / 256;            // vectors per thread per tensor tile (1 bf16, 2 f32)
   static_assert(NV >= 1, "staging shape");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  T* lds = reinterpret_cast<T*>(smem);          // [2 buffers][A tile KR x LA | D tile KR x LD]
+  const int grp = threadIdx.x >> 8;             // row group
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;   // within the group
+  T* lds = reinterpret_cast<T*>(smem) + (size_t)grp * 2 * KR * (LA + LD);   // [NG][2 buffers][A tile KR x LA | D tile KR x LD]
   auto tileA = [&](int buf) { return lds + (size_t)buf * KR * (LA + LD); };
   auto tileD = [&](int buf) { return lds + (size_t)buf * KR * (LA + LD) + KR * LA; };
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int slab = blockIdx.x, layer = blockIdx.y;
   const int d = a.dil[layer];
-  const int64_t r_begin = (int64_t)slab * a.rows_per_slab;
-  const int64_t r_end = (r_begin + a.rows_per_slab < a.rows) ? r_begin + a.rows_per_slab : a.rows;
+  const int64_t s_begin = (int64_t)slab * a.rows_per_slab;
+  const int64_t s_end = (s_begin + a.rows_per_slab < a.rows) ? s_begin + a.rows_per_slab : a.rows;
+  const int rows_per_group = (a.rows_per_slab / KR + NG - 1) / NG * KR;     // rows_per_slab is a multiple of KR
+  const int nit_all = rows_per_group / KR;                                   // barrier count, the same for every group
+  const int64_t r_begin = s_begin + (int64_t)grp * rows_per_group;
+  const int64_t r_end = (r_begin + rows_per_group < s_end) ? r_begin + rows_per_group : s_end;
   const int nit = (r_end > r_begin) ? (int)((r_end - r_begin + KR - 1) / KR) : 0;
   const T* xb = reinterpret_cast<const T*>(a.x) + (int64_t)layer * a.layer_stride;
   const T* zb = reinterpret_cast<const T*>(a.z) + (int64_t)layer * a.layer_stride;
@@ -395,7 +406,8 @@ __global__ __launch_bounds__(256) void wgrad_layer_kernel(WgLArgs a) {
 
   if (nit > 0) { gload(0); lstore(0); }
   __syncthreads();
-  for (int it = 0; it < nit; ++it) {
+  for (int it = 0; it < nit_all; ++it) {
+    if (it >= nit) { __syncthreads(); continue; }
     const int buf = it & 1;
     if (it + 1 < nit) gload(it + 1);
     const T* ta = tileA(buf); const T* td = tileD(buf);
@@ -419,6 +431,35 @@ __global__ __launch_bounds__(256) void wgrad_layer_kernel(WgLArgs a) {
     __syncthreads();
   }
 
+  if (NG > 1) {
+    // sum the groups: groups 1.. park their accumulators in LDS ([g-1][value][thread], the tiles are dead after the
+    // loop's last barrier), group 0 adds them in group order (deterministic)
+    constexpr int NVAL = 16 * (CT + 1) + 1;
+    float* red = reinterpret_cast<float*>(smem);
+    static_assert((size_t)(NG - 1) * NVAL * 256 * 4 <= (size_t)NG * 2 * KR * (LA + LD) * sizeof(T), "reduction scratch");
+    if (grp > 0) {
+      float* r = red + (size_t)(grp - 1) * NVAL * 256 + tid;
+#pragma unroll
+      for (int n = 0; n < CT; ++n)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) r[(16 * n + q) * 256] = accF[n][q];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) r[(16 * CT + q) * 256] = accR[q];
+      r[(16 * (CT + 1)) * 256] = bsum;
+    }
+    __syncthreads();
+    if (grp > 0) return;
+    for (int g = 1; g < NG; ++g) {
+      const float* r = red + (size_t)(g - 1) * NVAL * 256 + tid;
+#pragma unroll
+      for (int n = 0; n < CT; ++n)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) accF[n][q] += r[(16 * n + q) * 256];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) accR[q] += r[(16 * CT + q) * 256];
+      bsum += r[(16 * (CT + 1)) * 256];
+    }
+  }
   const int col = lane & 31, half = lane >> 5;
   const int64_t ls = (int64_t)layer * a.nslabs + slab;
   float* pf = a.part_f + ls * (2 * RC * RC);   // [k*RC + i][o]: conv row tile w covers rows 32w..32w+31
@@ -467,22 +508,33 @@ extern "C" int srwn_wgrad_layers(const void* x, const void* z, const void* df, c
   for (int i = 0; i < 64; ++i) a.dil[i] = (i < nlayers) ? dilations[i] : 1;
   for (int i = 0; i < nlayers; ++i)
     if (a.dil[i] < 1) return set_error(SRWN_E_SHAPE, "wgrad_layers: dilation %d", a.dil[i]);
-  dim3 grid((unsigned)nslabs, (unsigned)nlayers), block(256);
   hipStream_t st = (hipStream_t)stream;
-#define SRWN_WL(TT, C)                                                                                         \
+  // row groups per workgroup: 2 in bf16 (90 KB of LDS; still fits beside a layer_bwd workgroup of the main stream),
+  // 1 in fp32 (one group's two tiles are already 90 KB)
+  static const int ng_env = [] { const char* e = getenv("SRWN_WGL_GROUPS"); return e ? atoi(e) : 2; }();
+  const int ng = (dtype == SRWN_F32) ? 1 : (ng_env >= 3 ? 3 : (ng_env <= 1 ? 1 : 2));
+  dim3 grid((unsigned)nslabs, (unsigned)nlayers), block(256 * ng);
+#define SRWN_WLN(TT, C, NGV)                                                                                   \
   {                                                                                                            \
-    auto kfn = (R == 64) ? wgrad_layer_kernel<TT, C, 64> : wgrad_layer_kernel<TT, C, 32>;                      \
-    const size_t sh = (size_t)2 * kr * (5 * R + 32) * sizeof(TT);                                              \
+    auto kfn = (R == 64) ? wgrad_layer_kernel<TT, C, 64, NGV> : wgrad_layer_kernel<TT, C, 32, NGV>;            \
+    const size_t sh = (size_t)NGV * 2 * kr * (5 * R + 32) * sizeof(TT);                                        \
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
     if (e != hipSuccess) return set_error((int)e, "wgrad_layers: LDS %zu: %s", sh, hipGetErrorString(e));      \
     hipLaunchKernelGGL(kfn, grid, block, sh, st, a);                                                           \
     return check_launch("wgrad_layers");                                                                       \
   }
+#define SRWN_WL(TT, C)                                                                                         \
+  {                                                                                                            \
+    if (ng == 3) SRWN_WLN(TT, C, 3)                                                                            \
+    if (ng == 2) SRWN_WLN(TT, C, 2)                                                                            \
+    SRWN_WLN(TT, C, 1)                                                                                         \
+  }
   if (dtype == SRWN_BF16) {
     if (cond) SRWN_WL(bf16_t, true) else SRWN_WL(bf16_t, false)
   } else if (dtype == SRWN_F32) {
-    if (cond) SRWN_WL(float, true) else SRWN_WL(float, false)
+    if (cond) SRWN_WLN(float, true, 1) else SRWN_WLN(float, false, 1)
   }
+#undef SRWN_WLN
 #undef SRWN_WL
   return set_error(SRWN_E_DTYPE, "wgrad_layers: dtype %d", dtype);
 }
