@@ -142,14 +142,14 @@ def main():
     # Dominant kernel = the fused layer data-gradient kernel (layer_bwd_kernel): 31 launches per step, the largest
     # share of the step, HBM-bound.  Algorithmic bytes per launch: per sample and layer it reads
     # G_{l+2}, df_{l+1}, dcs_l, z_l and writes G_{l+1}, df_l = 6 x R x 2 B (bf16) = 768 B.  `traffic` is the PMC
-    # measurement of the same kernel (profiles/r01_d_hbm_traffic.md: FETCH_SIZE x2-corrected + WRITE_SIZE).
+    # measurement of the same kernel (profiles/r01_l_hbm_traffic.md: FETCH_SIZE x2-corrected + WRITE_SIZE, in 1e6 bytes).
     es = 2 if args.dtype == "bf16" else 4
     step_ms = 1e3 * dt_s / args.steps
     bwd_launch_ms = spans["bwd_layers"] / (L + 1)          # L DOWN(+UP) launches + the UP-only launch below layer 0
     bwd_bytes = 6.0 * R * es * N
     ach_bw = bwd_bytes / (bwd_launch_ms * 1e-3) / 1e9
     roofline = {"kernel": "layer_bwd_kernel", "bound": "hbm", "achieved": ach_bw, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                "frac": ach_bw / PEAK_HBM_GBS, "traffic": 100.3e6 if (args.dtype == "bf16" and (B, T, R, S) == (8, 16000, 64, 256)) else None,
+                "frac": ach_bw / PEAK_HBM_GBS, "traffic": 105.0e6 if (args.dtype == "bf16" and (B, T, R, S) == (8, 16000, 64, 256)) else None,
                 "bytes_per_launch": bwd_bytes, "launch_us": 1e3 * bwd_launch_ms, "launches_per_step": L + 1,
                 "share_of_step": spans["bwd_layers"] / step_ms,
                 "whole_step_mfma_frac": fl["per_step"] / (dt_s / args.steps) / 1e12 / PEAK_BF16_TFLOPS,
@@ -159,7 +159,7 @@ def main():
     achieved = kflops[dom] / (spans[dom] * 1e-3) / 1e12
     roofline_gemm = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_BF16_TFLOPS,
-                     "traffic": 546.6e6 if (dom == "skip_sum" and args.dtype == "bf16" and (B, T, R, S, L) == (8, 16000, 64, 256, 30)) else None}
+                     "traffic": 573.3e6 if (dom == "skip_sum" and args.dtype == "bf16" and (B, T, R, S, L) == (8, 16000, 64, 256, 30)) else None}
 
     if rank == 0:
         out = {
