@@ -18,6 +18,8 @@ weight gradients are time-contraction GEMMs (srwn_wgrad) batched over layers.
 """
 from __future__ import annotations
 
+import os
+
 import math
 from typing import Dict, Optional
 
@@ -152,11 +154,21 @@ class EncoderStack:
         self.o_nc_wr = P.pack_linear(pk, sec["nc_wr"].offset, EC, EC, EC)
         self.o_nc_wrT = P.pack_linear_T(pk, sec["nc_wr"].offset, EC, EC, EC)
         self.o_conv, self.o_convT, self.o_wr, self.o_wrT = [], [], [], []
+        # fused layer kernels (srwn_nc_layer_fwd/_bwd: bf16, 128 channels, K = 2; SRWN_NC_FUSED=0 keeps the two-launch
+        # path): the 1x1's B operand is the conv's accumulator tile -> the 1x1 images in permuted k order
+        self.fused = (self.dt == torch.bfloat16 and EC == 128 and Kw == 2 and
+                      os.environ.get("SRWN_NC_FUSED", "1") != "0")
+        self.o_wr_p, self.o_wrT_p = [], []
         for l in range(L):
             self.o_conv.append(P.pack_conv(pk, sec["EW"].offset + l * Kw * EC * EC, Kw, EC))
             self.o_convT.append(P.pack_conv_T(pk, sec["EW"].offset + l * Kw * EC * EC, Kw, EC))
             self.o_wr.append(P.pack_linear(pk, sec["EWR"].offset + l * EC * EC, EC, EC, EC))
             self.o_wrT.append(P.pack_linear_T(pk, sec["EWR"].offset + l * EC * EC, EC, EC, EC))
+            if self.fused:
+                self.o_wr_p.append(P.pack_linear(pk, sec["EWR"].offset + l * EC * EC, EC, EC, EC, perm=True))
+                self.o_wrT_p.append(P.pack_linear_T(pk, sec["EWR"].offset + l * EC * EC, EC, EC, EC, perm=True))
+        if self.fused:
+            self.o_nc_wrT_p = P.pack_linear_T(pk, sec["nc_wr"].offset, EC, EC, EC, perm=True)
         # every skip 1x1 as one image: rows = skip channel, k = layer*EC + n (applied to the frame means)
         self.o_ws = pk.reserve(S // 32, L * EC // 16)
         for l in range(L):
@@ -224,6 +236,11 @@ class EncoderStack:
              B, T, EC, self.Kw, K.abi_dtype(self.dt), st)
         self._tap(self.a[0], 1, 0, self.wptr(self.o_nc_wr), v("nc_br"), self.r[0], K.EPI_RELU)
         for l in range(L):
+            if self.fused:   # conv + relu + 1x1 + relu in one launch; the last layer's residual output is never used
+                call("srwn_nc_layer_fwd", self.r[l].data_ptr(), self.wptr(self.o_conv[l]), self.wptr(self.o_wr_p[l]),
+                     v("EB")[l].data_ptr(), v("EBR")[l].data_ptr(), self.a[l + 1].data_ptr(),
+                     self.r[l + 1].data_ptr() if l < L - 1 else None, B, T, EC, self.Kw, K.abi_dtype(self.dt), st)
+                continue
             self._tap(self.r[l], self.Kw, 1, self.wptr(self.o_conv[l]), v("EB")[l], self.a[l + 1], K.EPI_RELU)
             if l < L - 1:   # the last layer's residual output is never used (model.py:144-150)
                 self._tap(self.a[l + 1], 1, 0, self.wptr(self.o_wr[l]), v("EBR")[l], self.r[l + 1], K.EPI_RELU)
@@ -260,11 +277,23 @@ class EncoderStack:
         K.pw_linear(self.ds_mean.data_ptr(), S, 0, S, S, self.wptr(self.o_wsT), None, self.da_all, L * EC, L * EC, rc,
                     epi=K.EPI_F32, compute_dtype=dt)
         # layer chain, top down: the pooled skip gradient enters as a per-frame broadcast (frame_add)
-        for l in range(L - 1, -1, -1):
-            self._tap(self.dh[l + 1], 1, 0, self.wptr(self.o_wrT[l]), None, self.dpre[l + 1], K.EPI_MASK,
-                      aux=self.a[l + 1], fadd_ptr=self.da_all.data_ptr() + 4 * l * EC)
-            self._tap(self.dpre[l + 1], Kw, -1, self.wptr(self.o_convT[l]), None, self.dh[l], K.EPI_MASK, aux=self.r[l])
-        self._tap(self.dh[0], 1, 0, self.wptr(self.o_nc_wrT), None, self.dpre[0], K.EPI_MASK, aux=self.a[0])
+        if self.fused:
+            # one launch per layer: the conv data gradient of layer l, then the 1x1 data gradient of the layer below it
+            # (layer l-1's residual 1x1, or 'nc_conv''s under layer 0) on the tile still in registers
+            self._tap(self.dh[L], 1, 0, self.wptr(self.o_wrT[L - 1]), None, self.dpre[L], K.EPI_MASK, aux=self.a[L],
+                      fadd_ptr=self.da_all.data_ptr() + 4 * (L - 1) * EC)          # dh[L] = 0: the skip path only
+            for l in range(L - 1, -1, -1):
+                call("srwn_nc_layer_bwd", self.dpre[l + 1].data_ptr(), self.wptr(self.o_convT[l]), self.r[l].data_ptr(),
+                     self.dh[l].data_ptr(), self.wptr(self.o_wrT_p[l - 1] if l else self.o_nc_wrT_p),
+                     self.da_all.data_ptr() + 4 * (l - 1) * EC if l else None, L * EC, self.frames, self.pool,
+                     1.0 / self.pool, self.a[l].data_ptr(), self.dpre[l].data_ptr(), B, T, EC, Kw, K.abi_dtype(dt), st)
+        else:
+            for l in range(L - 1, -1, -1):
+                self._tap(self.dh[l + 1], 1, 0, self.wptr(self.o_wrT[l]), None, self.dpre[l + 1], K.EPI_MASK,
+                          aux=self.a[l + 1], fadd_ptr=self.da_all.data_ptr() + 4 * l * EC)
+                self._tap(self.dpre[l + 1], Kw, -1, self.wptr(self.o_convT[l]), None, self.dh[l], K.EPI_MASK,
+                          aux=self.r[l])
+            self._tap(self.dh[0], 1, 0, self.wptr(self.o_nc_wrT), None, self.dpre[0], K.EPI_MASK, aux=self.a[0])
         # weight gradients of the L layers -- both conv taps, the 1x1 residual and the two biases -- in ONE pass over
         # r, a, dpre, dh (layer l: r[l], a[l+1], dpre[l+1], dh[l+1]; the last layer's residual 1x1 sees dh[L] = 0)
         NE = N * EC

@@ -228,3 +228,40 @@ def test_wgrad_nc_layers_kernel(dt, tol):
         assert rel_err(ow[l, 0].cpu().numpy(), w0) < tol and rel_err(ow[l, 1].cpu().numpy(), w1) < tol
         assert rel_err(orr[l].cpu().numpy(), np.einsum("btn,btm->nm", aq[l], hq[l])) < tol
         assert rel_err(ob[l].cpu().numpy(), pq[l].sum((0, 1))) < tol and rel_err(obr[l].cpu().numpy(), hq[l].sum((0, 1))) < tol
+
+
+@pytest.mark.parametrize("B,T,pool", [(2, 256, 32), (3, 96, 32), (1, 33, 33), (2, 50, 25), (1, 1, 1)])
+def test_fused_nc_layers_match_the_two_launch_path(B, T, pool, monkeypatch):
+    """srwn_nc_layer_fwd/_bwd (one launch per encoder layer, accumulator-chained) against srwn_tap_linear x 2 in bf16:
+    same products on the same bf16-rounded operands, so activations agree to an ulp of bf16 and gradients closely;
+    canary rows beyond each saved tensor stay untouched."""
+    out = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("SRWN_NC_FUSED", fused)
+        ae, ep, dp_, x, c, _ = _ae(torch.bfloat16, 32, 128, 0, B=B, T=T, pool=pool)
+        assert ae.enc.fused == (fused == "1")
+        ae.forward(); ae.backward(); torch.cuda.synchronize()
+        e = ae.enc
+        out[fused] = dict(a=e.a.float().cpu().numpy(), r=e.r.float().cpu().numpy(), dh=e.dh.float().cpu().numpy(),
+                          dpre=e.dpre.float().cpu().numpy(), enc=e.enc.cpu().numpy(), g=e.grads.cpu().numpy(),
+                          loss=float(ae.loss.item()))
+    f, u = out["1"], out["0"]
+    L = f["a"].shape[0] - 1
+    assert rel_err(f["a"], u["a"]) < 1e-2 and rel_err(f["r"][:L], u["r"][:L]) < 1e-2
+    assert rel_err(f["enc"], u["enc"]) < 1e-2 and abs(f["loss"] - u["loss"]) < 1e-2 * abs(u["loss"])
+    assert rel_err(f["dpre"], u["dpre"]) < 3e-2 and rel_err(f["dh"][:L], u["dh"][:L]) < 3e-2
+    assert np.linalg.norm(f["g"] - u["g"]) < 3e-2 * np.linalg.norm(u["g"])
+
+
+def test_nc_layer_kernels_reject_other_shapes():
+    L_ = sub("_lib")
+    z = torch.zeros(64 * 128, device=DEV, dtype=torch.bfloat16)
+    b = torch.zeros(128, device=DEV)
+    zp, bp = z.data_ptr(), b.data_ptr()
+    with pytest.raises(RuntimeError, match="128 channels"):
+        L_.call("srwn_nc_layer_fwd", zp, zp, zp, bp, bp, zp, zp, 1, 64, 64, 2, 1, None)          # 64 channels
+    with pytest.raises(RuntimeError, match="bf16"):
+        L_.call("srwn_nc_layer_fwd", zp, zp, zp, bp, bp, zp, zp, 1, 64, 128, 2, 0, None)         # fp32
+    with pytest.raises(RuntimeError, match="wresT"):
+        L_.call("srwn_nc_layer_bwd", zp, zp, zp, zp, None, None, 0, 0, 1, 1.0, None, zp, 1, 64, 128, 2, 1, None)
+    assert L_.call("srwn_nc_layer_fwd", zp, zp, zp, bp, bp, zp, zp, 0, 64, 128, 2, 1, None) == 0   # empty batch
