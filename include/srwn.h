@@ -365,17 +365,24 @@ int srwn_tap_linear(const void* x, int64_t x_row_stride, int32_t ntaps, int32_t 
  *   r_out[t] = relu(bias_r + a_out[t] . Wr)                   (the relu'd input of the next layer; NULL: skipped --
  *                                                              the last layer's residual output is unused, model.py:144-150)
  * wconv = MFMA image [4][16] natural k (k = tap*128 + in channel), wres = image [4][8] in permuted k order (its B
- * operand is the first product's accumulator tile). */
+ * operand is the first product's accumulator tile).  a_bits / r_bits (may be NULL): srwn_nc_mask_words(B,T) 64-bit
+ * words receiving the relu masks of a_out / r_out in the layout srwn_nc_layer_bwd reads (word [tile*64 + lane], one bit
+ * per accumulator register of the lane: opaque outside srwn_nc.hip). */
+int64_t srwn_nc_mask_words(int32_t B, int32_t T);
 int srwn_nc_layer_fwd(const void* r_in, const void* wconv, const void* wres, const float* bias_c, const float* bias_r,
-                      void* a_out, void* r_out, int32_t B, int32_t T, int32_t C, int32_t K, int32_t dtype, void* stream);
+                      void* a_out, void* r_out, uint64_t* a_bits, uint64_t* r_bits, int32_t B, int32_t T, int32_t C,
+                      int32_t K, int32_t dtype, void* stream);
+/* the same mask words for a [B,T,128] bf16 tensor written by another kernel (x > 0) */
+int srwn_nc_mask_bits(const void* x, uint64_t* bits, int32_t B, int32_t T, int32_t C, int32_t dtype, void* stream);
 /* Its data gradient, pairing the conv of layer l with the 1x1 of the layer below (autodiff of ops.py:50-57):
- *   dh_out[t]   = [r_mask[t] > 0] . sum_k dpre_up[t-k] . Wconv[k]^T                                 (= d loss / d r_l)
- *   dpre_out[t] = [a_mask[t] > 0] . (dh_out[t] . Wr_below^T + frame_add[clip*frames + t/pool]*scale)  (NULL: skipped)
+ *   dh_out[t]   = [r[t] > 0] . sum_k dpre_up[t-k] . Wconv[k]^T                                      (= d loss / d r_l)
+ *   dpre_out[t] = [a[t] > 0] . (dh_out[t] . Wr_below^T + frame_add[clip*frames + t/pool]*scale)       (NULL: skipped)
+ * r_bits / a_bits = mask words of the layer's relu'd input and of the activation under the 1x1 below;
  * wconvT = image [4][16] natural k (rows = in channel, k = tap*128 + out channel), wresT = image [4][8] permuted k;
  * frame_add (fp32, may be NULL) is the pooled skip path's gradient broadcast over its frame (model.py:154). */
-int srwn_nc_layer_bwd(const void* dpre_up, const void* wconvT, const void* r_mask, void* dh_out, const void* wresT,
+int srwn_nc_layer_bwd(const void* dpre_up, const void* wconvT, const uint64_t* r_bits, void* dh_out, const void* wresT,
                       const float* frame_add, int64_t frame_add_ld, int32_t frames, int32_t pool_stride,
-                      float frame_add_scale, const void* a_mask, void* dpre_out, int32_t B, int32_t T, int32_t C,
+                      float frame_add_scale, const uint64_t* a_bits, void* dpre_out, int32_t B, int32_t T, int32_t C,
                       int32_t K, int32_t dtype, void* stream);
 /* weight gradients of the encoder's ResidualDilationLayerNC chain (ops.py:48-58), all layers in one pass over the saved
  * tensors ([L][rows][128] stacks, `layer_stride` elements apart; 128 channels, K = 2 taps at t and t+1):

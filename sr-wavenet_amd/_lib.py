@@ -67,7 +67,9 @@ SIGNATURES = {
                                   _i32, _i32, _f32, _i32, _i32, _p]),
     "srwn_wgrad_nc_layers": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _i32, _p]),
     "srwn_nc_input_fwd": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
-    "srwn_nc_layer_fwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
+    "srwn_nc_layer_fwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
+    "srwn_nc_mask_words": (_i64, [_i32, _i32]),
+    "srwn_nc_mask_bits": (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _p]),
     "srwn_nc_layer_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _f32, _p, _p, _i32, _i32, _i32, _i32,
                                     _i32, _p]),
     "srwn_small_gemm": (C.c_int, [_p, _i64, _i32, _i64, _i32, _p, _i64, _i64, _i32, _i64, _p, _p, _i64, _i32, _i32,

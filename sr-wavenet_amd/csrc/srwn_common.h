@@ -146,7 +146,11 @@ __device__ __forceinline__ void wave_lds_order() { asm volatile("s_waitcnt lgkmc
 
 // vals[mt][q]: accumulator-layout values of MTN row tiles (W = 32*MTN channels) for this lane's time row
 // `col`; gtile points at channel 0 of the tile's first row in HBM, rows `grow_stride` elements apart.
-template <typename T, int MTN>
+// DUP = true (needs rows_valid >= 1): rows beyond rows_valid re-store the last valid row instead of being skipped, so
+// every store instruction is issued unconditionally -- with the skip, each one sits behind an execz branch, the
+// compiler can no longer count the stores that follow a prefetch, and its s_waitcnt for the prefetched registers
+// becomes vmcnt(0): every tile then waits for the previous tile's stores to be acknowledged.
+template <typename T, int MTN, bool DUP = false>
 __device__ __forceinline__ void store_rows_via_lds(T* stage, T* gtile, int64_t grow_stride, const float (&vals)[MTN][16],
                                                    int rows_valid, int lane) {
   constexpr int W = 32 * MTN, LS = RowStage<T>::stride(W), VEC = RowStage<T>::VEC;
@@ -164,9 +168,10 @@ __device__ __forceinline__ void store_rows_via_lds(T* stage, T* gtile, int64_t g
   const int rsub = lane / LPR, piece = lane % LPR;
 #pragma unroll
   for (int i = 0; i < 32 / RPI; ++i) {
-    const int r = i * RPI + rsub;
+    int r = i * RPI + rsub;
+    if (DUP) r = r < rows_valid ? r : rows_valid - 1;
     const f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * LS + piece * VEC);
-    if (r < rows_valid) *reinterpret_cast<f32x4*>(gtile + (int64_t)r * grow_stride + piece * VEC) = v;
+    if (DUP || r < rows_valid) *reinterpret_cast<f32x4*>(gtile + (int64_t)r * grow_stride + piece * VEC) = v;
   }
 }
 

@@ -28,6 +28,7 @@ import torch
 
 from . import kernels as K
 from . import packing as P
+from . import _lib
 from ._lib import call
 from .engine import Section, StackConfig, WaveNetEngine
 
@@ -199,6 +200,10 @@ class EncoderStack:
         self.r = z(L, N, EC)              # r[l] = relu(residual output feeding layer l)
         self.dpre = z(L + 1, N, EC)       # gradient at the conv pre-activations
         self.dh = z(L + 1, N, EC)         # gradient at the residual pre-activations; dh[L] stays 0 (unused output)
+        if self.fused:                    # relu masks as bit words in the fused kernels' tile/lane layout
+            nw = int(_lib.load().srwn_nc_mask_words(B, T))
+            self.abits = torch.zeros(L + 1, nw, dtype=torch.int64, device=self.dev)
+            self.rbits = torch.zeros(L, nw, dtype=torch.int64, device=self.dev)
         self.a_mean = z(L, self.rows_c, EC)
         self.bs_sum = f(S)
         self.s_mean = f(self.rows_c, S)
@@ -215,7 +220,6 @@ class EncoderStack:
         ne = self.ns_enc
         self.pe_w = f(L * ne * self.Kw * EC * EC); self.pe_r = f(L * ne * EC * EC)
         self.pe_b = f(L * ne * EC); self.pe_br = f(L * ne * EC)
-        from . import _lib
         self.ic_ws = f(int(_lib.load().srwn_init_conv_wgrad_partials(B, T, EC, self.Kw)))
 
     # -- forward -------------------------------------------------------------------------------------
@@ -239,7 +243,8 @@ class EncoderStack:
             if self.fused:   # conv + relu + 1x1 + relu in one launch; the last layer's residual output is never used
                 call("srwn_nc_layer_fwd", self.r[l].data_ptr(), self.wptr(self.o_conv[l]), self.wptr(self.o_wr_p[l]),
                      v("EB")[l].data_ptr(), v("EBR")[l].data_ptr(), self.a[l + 1].data_ptr(),
-                     self.r[l + 1].data_ptr() if l < L - 1 else None, B, T, EC, self.Kw, K.abi_dtype(self.dt), st)
+                     self.r[l + 1].data_ptr() if l < L - 1 else None, self.abits[l + 1].data_ptr(),
+                     self.rbits[l + 1].data_ptr() if l < L - 1 else None, B, T, EC, self.Kw, K.abi_dtype(self.dt), st)
                 continue
             self._tap(self.r[l], self.Kw, 1, self.wptr(self.o_conv[l]), v("EB")[l], self.a[l + 1], K.EPI_RELU)
             if l < L - 1:   # the last layer's residual output is never used (model.py:144-150)
@@ -282,11 +287,14 @@ class EncoderStack:
             # (layer l-1's residual 1x1, or 'nc_conv''s under layer 0) on the tile still in registers
             self._tap(self.dh[L], 1, 0, self.wptr(self.o_wrT[L - 1]), None, self.dpre[L], K.EPI_MASK, aux=self.a[L],
                       fadd_ptr=self.da_all.data_ptr() + 4 * (L - 1) * EC)          # dh[L] = 0: the skip path only
+            for t_, bits in ((self.a[0], self.abits[0]), (self.r[0], self.rbits[0])):   # written by the generic kernels
+                call("srwn_nc_mask_bits", t_.data_ptr(), bits.data_ptr(), B, T, EC, K.abi_dtype(dt), st)
             for l in range(L - 1, -1, -1):
-                call("srwn_nc_layer_bwd", self.dpre[l + 1].data_ptr(), self.wptr(self.o_convT[l]), self.r[l].data_ptr(),
-                     self.dh[l].data_ptr(), self.wptr(self.o_wrT_p[l - 1] if l else self.o_nc_wrT_p),
+                call("srwn_nc_layer_bwd", self.dpre[l + 1].data_ptr(), self.wptr(self.o_convT[l]),
+                     self.rbits[l].data_ptr(), self.dh[l].data_ptr(),
+                     self.wptr(self.o_wrT_p[l - 1] if l else self.o_nc_wrT_p),
                      self.da_all.data_ptr() + 4 * (l - 1) * EC if l else None, L * EC, self.frames, self.pool,
-                     1.0 / self.pool, self.a[l].data_ptr(), self.dpre[l].data_ptr(), B, T, EC, Kw, K.abi_dtype(dt), st)
+                     1.0 / self.pool, self.abits[l].data_ptr(), self.dpre[l].data_ptr(), B, T, EC, Kw, K.abi_dtype(dt), st)
         else:
             for l in range(L - 1, -1, -1):
                 self._tap(self.dh[l + 1], 1, 0, self.wptr(self.o_wrT[l]), None, self.dpre[l + 1], K.EPI_MASK,

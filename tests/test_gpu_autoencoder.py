@@ -259,9 +259,25 @@ def test_nc_layer_kernels_reject_other_shapes():
     b = torch.zeros(128, device=DEV)
     zp, bp = z.data_ptr(), b.data_ptr()
     with pytest.raises(RuntimeError, match="128 channels"):
-        L_.call("srwn_nc_layer_fwd", zp, zp, zp, bp, bp, zp, zp, 1, 64, 64, 2, 1, None)          # 64 channels
+        L_.call("srwn_nc_layer_fwd", zp, zp, zp, bp, bp, zp, zp, None, None, 1, 64, 64, 2, 1, None)     # 64 channels
     with pytest.raises(RuntimeError, match="bf16"):
-        L_.call("srwn_nc_layer_fwd", zp, zp, zp, bp, bp, zp, zp, 1, 64, 128, 2, 0, None)         # fp32
+        L_.call("srwn_nc_layer_fwd", zp, zp, zp, bp, bp, zp, zp, None, None, 1, 64, 128, 2, 0, None)    # fp32
     with pytest.raises(RuntimeError, match="wresT"):
         L_.call("srwn_nc_layer_bwd", zp, zp, zp, zp, None, None, 0, 0, 1, 1.0, None, zp, 1, 64, 128, 2, 1, None)
-    assert L_.call("srwn_nc_layer_fwd", zp, zp, zp, bp, bp, zp, zp, 0, 64, 128, 2, 1, None) == 0   # empty batch
+    assert L_.call("srwn_nc_layer_fwd", zp, zp, zp, bp, bp, zp, zp, None, None, 0, 64, 128, 2, 1, None) == 0   # empty batch
+    assert int(L_.load().srwn_nc_mask_words(3, 33)) == 3 * 2 * 64
+
+
+def test_nc_mask_bits_match_the_forward_kernels_words():
+    """The relu-mask words the fused forward writes equal srwn_nc_mask_bits of the tensors it stored."""
+    L_ = sub("_lib")
+    ae, *_ = _ae(torch.bfloat16, 32, 128, 0, B=3, T=96, pool=32)
+    ae.forward(); torch.cuda.synchronize()
+    e = ae.enc
+    assert e.fused
+    for l in range(1, e.L + 1):
+        for t_, bits in ((e.a[l], e.abits[l]),) + (((e.r[l], e.rbits[l]),) if l < e.L else ()):
+            want = torch.zeros_like(bits)
+            L_.call("srwn_nc_mask_bits", t_.data_ptr(), want.data_ptr(), e.B, e.T, 128, 1, None)
+            assert torch.equal(bits, want)
+            assert int((bits != 0).sum()) > 0
