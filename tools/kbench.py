@@ -51,6 +51,11 @@ def main():
         "skip_sum": (lambda: K.pw_linear(eng.zs.data_ptr(), R, N * R, R, L * R, eng.wptr(eng.o_skip), eng.bs_sum,
                                          eng.r0, S, S, N, pro=K.PRO_GATE, epi=K.EPI_RELU),
                      2.0 * N * L * R * S, N * (L * R + S) * 2),
+        "skip_sum_nogate": (lambda: K.pw_linear(eng.zs.data_ptr(), R, N * R, R, L * R, eng.wptr(eng.o_skip), eng.bs_sum,
+                                                eng.r0, S, S, N, pro=K.PRO_NONE, epi=K.EPI_RELU),
+                            2.0 * N * L * R * S, N * (L * R + S) * 2),
+        "wgrad256_skip_nogate": (lambda: K.wgrad256(eng.zs.data_ptr(), NR, R, L, eng.dtotal, eng.wg_parts, eng.wg_bparts, N,
+                                                    eng.ns_skip, pro=K.PRO_NONE), 2.0 * N * L * R * S, N * L * R * 2 + N * S * 2),
         "head_1x1": (lambda: K.pw_linear(eng.r0.data_ptr(), S, 0, S, S, eng.wptr(eng.o_w1), v("head_b1"), eng.r1, S,
                                          S, N, epi=K.EPI_RELU), 2.0 * N * S * S, N * S * 4),
         "head_ce": (lambda: K.head_softmax_ce(eng.r1, eng.wptr(eng.o_w2), v("head_b2"), eng.targets, eng.loss_parts,
