@@ -34,20 +34,37 @@ template <typename T> __device__ __forceinline__ void glds16(const void* g, void
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
+// LDS-DMA the compiler does not see (it treats a visible one as a pending write to any LDS address and answers with
+// s_waitcnt vmcnt(0) -- which would also drain activation loads issued chunks ahead).  The kernel retires these pieces
+// itself with a counted s_waitcnt before the chunk barrier.  M0 (LDS base of the DMA) is saved and restored.
+__device__ __forceinline__ void glds16_untracked(const void* g, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(g), "s"(lds_addr) : "memory");
+}
+
+// Waves per workgroup.  Every workgroup streams the WHOLE weight image through LDS, so the LDS-DMA volume is
+// (rows / rows per workgroup) x image: with 4 waves (128 rows) the skip sum moved 1 GB of weights for 0.49 GB of
+// activations and ran at the chip's LDS-DMA rate (~6.4 TB/s, MI355X_MICROARCH.md), not at its MFMA or HBM rate.
+// Eight waves share each chunk (the same 8 waves per CU as two 4-wave workgroups: the registers allow no more).
+// The softmax head and the NT = 2 experiment need more than 256 registers (one wave per SIMD): four waves there.
+constexpr int rg_waves(int epi, int nt) { return (epi == SRWN_EPI_SOFTMAX_CE || nt == 2) ? 4 : 8; }
+
 template <typename T, int MT, int KSC, int PRO, int EPI, int NT, bool TAPS = false>
-__global__ __launch_bounds__(256, (EPI == SRWN_EPI_SOFTMAX_CE || NT == 2) ? 1 : 2) void rowgemm_kernel(RgArgs a) {
+__global__ __launch_bounds__(64 * rg_waves(EPI, NT), (EPI == SRWN_EPI_SOFTMAX_CE || NT == 2) ? 1 : 2) void rowgemm_kernel(RgArgs a) {
+  constexpr int kRgWaves = rg_waves(EPI, NT);
   static_assert(MT % 2 == 0, "outputs are emitted in 64-channel groups");
   static_assert(EPI != SRWN_EPI_SOFTMAX_CE || NT == 1, "softmax epilogue holds one column tile");
   constexpr int FB = sizeof(Frag<T>) * 64;          // bytes of one fragment image (1 KiB bf16, 2 KiB f32)
   constexpr int CHUNK_B = MT * KSC * FB;            // bytes of one weight chunk in LDS
   constexpr int PIECES = CHUNK_B / 1024;            // 1-KiB glds pieces per chunk
-  static_assert(PIECES % 4 == 0, "chunk must split evenly over 4 waves");
+  static_assert(PIECES % kRgWaves == 0, "chunk must split evenly over the waves");
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][CHUNK_B]; reused as row stages at the end
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int col = lane & 31, half = lane >> 5;
-  const int64_t tile0 = ((int64_t)blockIdx.x * 4 + wave) * NT;   // first 32-row tile of this wave
+  const int64_t tile0 = ((int64_t)blockIdx.x * kRgWaves + wave) * NT;   // first 32-row tile of this wave
   int64_t rowv[NT];
   bool valid[NT];
   int tclip[NT];   // (TAPS) time index of the row inside its clip
@@ -59,16 +76,17 @@ __global__ __launch_bounds__(256, (EPI == SRWN_EPI_SOFTMAX_CE || NT == 2) ? 1 : 
   }
   const int nchunks = a.ks_total / KSC;
   const char* wbase = reinterpret_cast<const char*>(a.wpack);
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 
   // piece p of chunk c: fragment run (mt, byte offset) -> global address; LDS image is [mt][KSC][64] frags
   auto stage = [&](int c, int buf) {
 #pragma unroll
-    for (int i = 0; i < PIECES / 4; ++i) {
-      const int p = wave * (PIECES / 4) + i;
+    for (int i = 0; i < PIECES / kRgWaves; ++i) {
+      const int p = wave * (PIECES / kRgWaves) + i;
       const int mt = p / (KSC * FB / 1024), within = (p % (KSC * FB / 1024)) * 1024;
       const char* g = wbase + ((size_t)mt * a.ks_total + (size_t)c * KSC) * FB + within + lane * 16;
-      char* l = smem + buf * CHUNK_B + mt * (KSC * FB) + within;
-      glds16<T>(g, l);
+      const unsigned l = lds_base + (unsigned)(buf * CHUNK_B + mt * (KSC * FB) + within);
+      glds16_untracked(g, __builtin_amdgcn_readfirstlane(l));
     }
   };
   // unconditional (clamped) activation loads; rows beyond the end produce values that are never stored
@@ -106,38 +124,75 @@ __global__ __launch_bounds__(256, (EPI == SRWN_EPI_SOFTMAX_CE || NT == 2) ? 1 : 
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt][q] = bv;
     }
 
-  Frag<T> bcur[NT][KSC], bnext[NT][KSC];
-  bool oknext[NT][KSC];
+  // Pipeline: weight chunk c+1 streams into the other LDS buffer (LDS-DMA from L2) while chunk c is consumed;
+  // activation fragments are fetched from HBM TWO chunks ahead into a ring of two register sets -- one chunk of
+  // MFMAs (~0.5 us) does not cover an HBM round trip under load, and with a one-chunk distance every chunk barrier
+  // exposed the remainder.  Per chunk: exactly NT*KSC activation loads are issued after the DMA pieces, so
+  // s_waitcnt vmcnt(NT*KSC) before the barrier retires the DMA (and everything older) and nothing newer.
+  Frag<T> bcur[NT][KSC], bA[NT][KSC], bB[NT][KSC];
+  bool okA[NT][KSC], okB[NT][KSC];
   stage(0, 0);
-  load_b(0, bnext, oknext);
-  __syncthreads();   // (drains the glds: vmcnt(0) + barrier)
-  for (int c = 0; c < nchunks; ++c) {
+  load_b(0, bA, okA);
+  load_b(nchunks > 1 ? 1 : 0, bB, okB);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  auto chunk = [&](int c, Frag<T> (&bthis)[NT][KSC], bool (&okthis)[NT][KSC]) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int ks = 0; ks < KSC; ++ks) {
-        bcur[nt][ks] = bnext[nt][ks];   // rows past the end are clamped re-reads: computed, never stored
-        if (TAPS) bcur[nt][ks] = oknext[nt][ks] ? bcur[nt][ks] : zero_frag<T>();   // taps outside the clip
+        bcur[nt][ks] = bthis[nt][ks];   // rows past the end are clamped re-reads: computed, never stored
+        if (TAPS) bcur[nt][ks] = okthis[nt][ks] ? bcur[nt][ks] : zero_frag<T>();   // taps outside the clip
         if (PRO == SRWN_PRO_GATE) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) bcur[nt][ks].set(j, gate_of_z<T>(bcur[nt][ks].get(j)));
         }
       }
-    {
-      const int cn = (c + 1 < nchunks) ? c + 1 : c;   // (last iteration re-fetches chunk c: harmless, keeps counts fixed)
-      if (c + 1 < nchunks) stage(cn, (c + 1) & 1);
-      load_b(cn, bnext, oknext);
-    }
+    if (c + 1 < nchunks) stage(c + 1, (c + 1) & 1);
+    load_b(c + 2 < nchunks ? c + 2 : nchunks - 1, bthis, okthis);   // (past the end: a re-fetch that keeps the count fixed)
     const Frag<T>* lw = reinterpret_cast<const Frag<T>*>(smem + (c & 1) * CHUNK_B) + lane;
+    // weight fragments one k-step ahead in registers: left to itself hipcc emits ds_read -> s_waitcnt lgkmcnt(0) ->
+    // v_mfma per fragment, i.e. one exposed LDS round trip per 32-cycle MFMA; the sched barriers keep the next
+    // k-step's reads ahead of this k-step's MFMAs
+    // (bf16 only: an fp32 fragment is 8 registers and the second set does not fit beside 128 accumulators)
+    constexpr bool APF = sizeof(T) == 2 && !TAPS && NT == 1;
+    if constexpr (APF) {
+      Frag<T> af[2][MT];
 #pragma unroll
-    for (int ks = 0; ks < KSC; ++ks)
+      for (int mt = 0; mt < MT; ++mt) af[0][mt] = lw[(mt * KSC) * 64];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const Frag<T> af = lw[(mt * KSC + ks) * 64];
+      for (int ks = 0; ks < KSC; ++ks) {
+        if (ks + 1 < KSC) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) mma(acc[mt][nt], af, bcur[nt][ks]);
+          for (int mt = 0; mt < MT; ++mt) af[(ks + 1) & 1][mt] = lw[(mt * KSC + ks + 1) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) mma(acc[mt][nt], af[ks & 1][mt], bcur[nt][ks]);
+        __builtin_amdgcn_sched_barrier(0);
       }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < KSC; ++ks)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const Frag<T> af = lw[(mt * KSC + ks) * 64];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) mma(acc[mt][nt], af, bcur[nt][ks]);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NT * KSC) : "memory");
     __syncthreads();
+  };
+  {
+    int c = 0;
+    for (; c + 1 < nchunks; c += 2) {
+      chunk(c, bA, okA);
+      chunk(c + 1, bB, okB);
+    }
+    if (c < nchunks) chunk(c, bA, okA);
   }
   // the weight buffers are free now: each wave takes a private row stage ([32][64 + pad]) from them
   T* rstage = reinterpret_cast<T*>(smem) + wave * (32 * RowStage<T>::stride(64));
@@ -348,12 +403,13 @@ namespace srwn {
 template <typename T, int MT, int KSC, int NT>
 static int launch_rg(const RgArgs& a, int pro, int epi, hipStream_t st) {
   constexpr int CHUNK_B = MT * KSC * (int)sizeof(Frag<T>) * 64;
-  // the weight double buffer is reused as 4 private row stages in the epilogue: take the larger of the two
-  const size_t stage_b = (size_t)4 * 32 * RowStage<T>::stride(64) * sizeof(T);
-  const size_t sh = 2 * (size_t)CHUNK_B > stage_b ? 2 * (size_t)CHUNK_B : stage_b;
+  // the weight double buffer is reused as the waves' private row stages in the epilogue: take the larger of the two
   constexpr int NTS = 1;   // softmax epilogue always one column tile per wave
-  const int rows_per_block = 128 * ((epi == SRWN_EPI_SOFTMAX_CE) ? NTS : NT);
-  dim3 grid((unsigned)((a.rows + rows_per_block - 1) / rows_per_block)), block(256);
+  const int nw = rg_waves(epi, (epi == SRWN_EPI_SOFTMAX_CE) ? NTS : NT);
+  const size_t stage_b = (size_t)nw * 32 * RowStage<T>::stride(64) * sizeof(T);
+  const size_t sh = 2 * (size_t)CHUNK_B > stage_b ? 2 * (size_t)CHUNK_B : stage_b;
+  const int rows_per_block = 32 * nw * ((epi == SRWN_EPI_SOFTMAX_CE) ? NTS : NT);
+  dim3 grid((unsigned)((a.rows + rows_per_block - 1) / rows_per_block)), block(64 * nw);
 #define SRWN_RG(P, E)                                                                                        \
   if (pro == P && epi == E) {                                                                                \
     auto kfn = rowgemm_kernel<T, MT, KSC, P, E, (E == SRWN_EPI_SOFTMAX_CE) ? 1 : NT>;                        \
@@ -377,10 +433,11 @@ static int launch_rg(const RgArgs& a, int pro, int epi, hipStream_t st) {
 template <typename T, int MT, int KSC>
 static int launch_rg_taps(const RgArgs& a, int epi, hipStream_t st) {
   constexpr int CHUNK_B = MT * KSC * (int)sizeof(Frag<T>) * 64;
-  // the weight double buffer is reused as 4 private row stages in the epilogue: take the larger of the two
-  const size_t stage_b = (size_t)4 * 32 * RowStage<T>::stride(64) * sizeof(T);
+  // the weight double buffer is reused as the waves' private row stages in the epilogue: take the larger of the two
+  constexpr int kRgWaves = rg_waves(SRWN_EPI_NONE, 1);
+  const size_t stage_b = (size_t)kRgWaves * 32 * RowStage<T>::stride(64) * sizeof(T);
   const size_t sh = 2 * (size_t)CHUNK_B > stage_b ? 2 * (size_t)CHUNK_B : stage_b;
-  dim3 grid((unsigned)((a.rows + 127) / 128)), block(256);
+  dim3 grid((unsigned)((a.rows + 32 * kRgWaves - 1) / (32 * kRgWaves))), block(64 * kRgWaves);
 #define SRWN_RGT(E)                                                                                          \
   if (epi == E) {                                                                                            \
     auto kfn = rowgemm_kernel<T, MT, KSC, SRWN_PRO_NONE, E, 1, true>;                                        \
