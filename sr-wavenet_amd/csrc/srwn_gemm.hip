@@ -309,23 +309,25 @@ struct CgArgs {
   const void* x; int64_t x_row_stride; const void* wpack; void* y; int64_t y_layer_stride; int nlayers; int64_t rows;
 };
 
-template <typename T, int RT, int KSS, int NBUF>
-__global__ __launch_bounds__(256) void colgemm_kernel(CgArgs a) {
+// NW waves per workgroup share each layer's weight image (every workgroup streams all of them: 8 waves halve that
+// LDS-DMA volume, which at 4 waves was twice the size of the output).
+template <typename T, int RT, int KSS, int NBUF, int NW>
+__global__ __launch_bounds__(64 * NW) void colgemm_kernel(CgArgs a) {
   constexpr int R = 32 * RT;
   constexpr int FB = sizeof(Frag<T>) * 64;
   constexpr int CHUNK_B = RT * KSS * FB;
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [NBUF][CHUNK_B] weights | 4 row stages
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [NBUF][CHUNK_B] weights | NW row stages
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int col = lane & 31, half = lane >> 5;
   T* stage = reinterpret_cast<T*>(smem + NBUF * CHUNK_B) + wave * (32 * RowStage<T>::stride(R));
-  const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
+  const int64_t row0 = ((int64_t)blockIdx.x * NW + wave) * 32;
   const int64_t row = row0 + col;
   const bool valid = row < a.rows;
   const int rows_valid = (a.rows - row0) < 32 ? (int)(a.rows - row0) : 32;   // may be <= 0 for idle waves
   const char* wbase = reinterpret_cast<const char*>(a.wpack);
 
-  lds_dma_copy(wbase, smem, CHUNK_B, wave, lane, 4);
+  lds_dma_copy(wbase, smem, CHUNK_B, wave, lane, NW);
   Frag<T> bf[KSS];
   {
     const T* p = reinterpret_cast<const T*>(a.x) + (valid ? row : 0) * a.x_row_stride + 8 * half;
@@ -338,20 +340,35 @@ __global__ __launch_bounds__(256) void colgemm_kernel(CgArgs a) {
   for (int l = 0; l < a.nlayers; ++l) {
     const int buf = (NBUF == 2) ? (l & 1) : 0;
     if (NBUF == 2 && l + 1 < a.nlayers)
-      lds_dma_copy(wbase + (size_t)(l + 1) * CHUNK_B, smem + ((l + 1) & 1) * CHUNK_B, CHUNK_B, wave, lane, 4);
+      lds_dma_copy(wbase + (size_t)(l + 1) * CHUNK_B, smem + ((l + 1) & 1) * CHUNK_B, CHUNK_B, wave, lane, NW);
     const Frag<T>* lw = reinterpret_cast<const Frag<T>*>(smem + buf * CHUNK_B) + lane;
     f32x16 acc[RT];
 #pragma unroll
     for (int mt = 0; mt < RT; ++mt)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[mt][q] = 0.0f;
+    // weight fragments four k-steps ahead of their MFMAs (see rowgemm_kernel)
+    constexpr int G = 4;
+    Frag<T> af[2][G][RT];
 #pragma unroll
-    for (int ks = 0; ks < KSS; ++ks)
+    for (int j = 0; j < G; ++j)
 #pragma unroll
-      for (int mt = 0; mt < RT; ++mt) {
-        const Frag<T> af = lw[(mt * KSS + ks) * 64];
-        mma(acc[mt], af, bf[ks]);
+      for (int mt = 0; mt < RT; ++mt) af[0][j][mt] = lw[(mt * KSS + j) * 64];
+#pragma unroll
+    for (int k0 = 0; k0 < KSS; k0 += G) {
+      if (k0 + G < KSS) {
+#pragma unroll
+        for (int j = 0; j < G; ++j)
+#pragma unroll
+          for (int mt = 0; mt < RT; ++mt) af[((k0 / G) + 1) & 1][j][mt] = lw[(mt * KSS + k0 + G + j) * 64];
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < G; ++j)
+#pragma unroll
+        for (int mt = 0; mt < RT; ++mt) mma(acc[mt], af[(k0 / G) & 1][j][mt], bf[k0 + j]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     float v[RT][16];
 #pragma unroll
     for (int mt = 0; mt < RT; ++mt)
@@ -361,7 +378,7 @@ __global__ __launch_bounds__(256) void colgemm_kernel(CgArgs a) {
     store_rows_via_lds<T, RT>(stage, ytile, R, v, rows_valid, lane);
     __syncthreads();
     if (NBUF == 1 && l + 1 < a.nlayers) {
-      lds_dma_copy(wbase + (size_t)(l + 1) * CHUNK_B, smem, CHUNK_B, wave, lane, 4);
+      lds_dma_copy(wbase + (size_t)(l + 1) * CHUNK_B, smem, CHUNK_B, wave, lane, NW);
       __syncthreads();
     }
   }
@@ -370,11 +387,12 @@ __global__ __launch_bounds__(256) void colgemm_kernel(CgArgs a) {
 template <typename T, int RT, int KSS, int NBUF>
 static int launch_cg(const CgArgs& a, hipStream_t st) {
   constexpr int R = 32 * RT;
-  const size_t sh = (size_t)NBUF * RT * KSS * sizeof(Frag<T>) * 64 + (size_t)4 * 32 * RowStage<T>::stride(R) * sizeof(T);
-  auto kfn = colgemm_kernel<T, RT, KSS, NBUF>;
+  constexpr int NW = (sizeof(T) == 2) ? 8 : 4;
+  const size_t sh = (size_t)NBUF * RT * KSS * sizeof(Frag<T>) * 64 + (size_t)NW * 32 * RowStage<T>::stride(R) * sizeof(T);
+  auto kfn = colgemm_kernel<T, RT, KSS, NBUF, NW>;
   hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
   if (e != hipSuccess) return set_error((int)e, "skip_dgrad_all: LDS %zu: %s", sh, hipGetErrorString(e));
-  hipLaunchKernelGGL(kfn, dim3((unsigned)((a.rows + 127) / 128)), dim3(256), sh, st, a);
+  hipLaunchKernelGGL(kfn, dim3((unsigned)((a.rows + 32 * NW - 1) / (32 * NW))), dim3(64 * NW), sh, st, a);
   return check_launch("skip_dgrad_all");
 }
 
