@@ -159,7 +159,8 @@ def main():
     achieved = kflops[dom] / (spans[dom] * 1e-3) / 1e12
     roofline_gemm = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_BF16_TFLOPS,
-                     "traffic": 573.3e6 if (dom == "skip_sum" and args.dtype == "bf16" and (B, T, R, S, L) == (8, 16000, 64, 256, 30)) else None}
+                     "traffic": ({"skip_sum": 573.3e6, "wgrad_skip": 632.8e6}[dom]   # profiles/r01_l_hbm_traffic.md
+                                 if (args.dtype == "bf16" and (B, T, R, S, L) == (8, 16000, 64, 256, 30)) else None)}
 
     if rank == 0:
         out = {
