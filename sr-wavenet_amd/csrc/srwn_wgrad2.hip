@@ -87,8 +87,15 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(Wg2Args a) {
     for (int n = 0; n < NTW; ++n)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[m][n][q] = 0.0f;
-  float bsum = 0.0f;
-  const bool do_bias = (a.bias_partials != nullptr) && (mblk == 0) && (tid < kW);
+  // column sums of D (the bias gradient): every wave sums kRows/8 rows of the chunk for CPL columns per lane with one
+  // vector read per row, and the eight partial sums meet in LDS at the end.  (One thread per column walking all 32
+  // rows kept four waves ~600 cycles longer per chunk than the 512 cycles of MFMA work: with one barrier per chunk
+  // and one workgroup per CU, the bias-carrying workgroups set the kernel time.)
+  constexpr int CPL = kW / 64;                   // columns per lane
+  float bs[CPL];
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) bs[j] = 0.0f;
+  const bool do_bias = (a.bias_partials != nullptr) && (mblk == 0);
 
   f32x4 ra[NVA], rd[NV];   // raw 16-byte vectors in flight (bit containers)
   auto gload = [&](int it) {
@@ -150,8 +157,12 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(Wg2Args a) {
     if (it + 1 < nit) gload(it + 1);
     const T* ta = tileA(buf); const T* td = tileD(buf);
     if (do_bias) {
-#pragma unroll 8
-      for (int rr = 0; rr < kRows; ++rr) bsum += (float)td[rr * kStride + tid];
+#pragma unroll
+      for (int rr = 0; rr < kRows / 8; ++rr) {
+        const T* p = td + (wave * (kRows / 8) + rr) * kStride + lane * CPL;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) bs[j] += (float)p[j];
+      }
     }
 #pragma unroll
     for (int ks = 0; ks < (wave_live ? kRows / 16 : 0); ++ks) {
@@ -183,7 +194,18 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(Wg2Args a) {
         for (int q = 0; q < 16; ++q) pbase[(int64_t)(32 * m + crow(q, half)) * kW + o] = acc[m][n][q];
       }
   }
-  if (do_bias) a.bias_partials[(int64_t)slab * kW + tid] = bsum;
+  if (do_bias) {   // (block-uniform) the loop's last barrier has passed: the tiles are free
+    float* red = reinterpret_cast<float*>(smem);   // [8 waves][kW]
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) red[wave * kW + lane * CPL + j] = bs[j];
+    __syncthreads();
+    if (tid < kW) {
+      float t = 0.0f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) t += red[w * kW + tid];
+      a.bias_partials[(int64_t)slab * kW + tid] = t;
+    }
+  }
 }
 
 }  // namespace
