@@ -426,6 +426,91 @@ __global__ __launch_bounds__(256 * NG) void wgrad_layer_kernel(WgLArgs a) {
     }
   };
 
+  if constexpr (sizeof(T) == 2 && !COND) {
+    // bf16, unconditioned stacks: a ring of three register sets -- chunk it+4 is requested while chunk it is
+    // multiplied, three steps before it moves to LDS.  With one set the request preceded its use by one chunk's
+    // MFMAs (~0.2 us) against an HBM round trip of > 1 us, so every step waited for memory.  The loads are
+    // unconditional (rows clamped into the tensor; rows outside the group's range are zeroed on their way to LDS),
+    // which lets hipcc count them instead of draining.
+    struct Ring { f32x4 xd[NV], xc[NV], z[NV], f[NV], g[NV]; };
+    auto rload = [&](int it, Ring& r) {
+      const int64_t r0 = r_begin + (int64_t)it * KR;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int idx = tid + v * 256;
+        const int rr = idx / VPC, cv = (idx % VPC) * VEC;
+        int64_t rowc = r0 + rr;
+        rowc = rowc < a.rows ? rowc : a.rows - 1;
+        const int t = (int)(rowc % a.Tlen);
+        const int64_t rowd = (t - d >= 0) ? rowc - d : rowc;
+        r.xd[v] = *reinterpret_cast<const f32x4*>(xb + rowd * RC + cv);
+        r.xc[v] = *reinterpret_cast<const f32x4*>(xb + rowc * RC + cv);
+        r.z[v] = *reinterpret_cast<const f32x4*>(zb + rowc * RC + cv);
+        r.f[v] = *reinterpret_cast<const f32x4*>(fb + rowc * RC + cv);
+        r.g[v] = *reinterpret_cast<const f32x4*>(gb + rowc * RC + cv);
+      }
+    };
+    auto rstore = [&](int it, const Ring& r) {
+      const int64_t r0 = r_begin + (int64_t)it * KR;
+      T* ta = tileA(it & 1); T* td = tileD(it & 1);
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int idx = tid + v * 256;
+        const int rr = idx / VPC, cv = (idx % VPC) * VEC;
+        const int64_t row = r0 + rr;
+        const bool okr = row < r_end;
+        const bool okdd = okr && ((int)(row % a.Tlen) - d >= 0);
+        bf16x8 b = __builtin_bit_cast(bf16x8, okr ? r.z[v] : zero);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) b[e] = (bf16_t)gate_of_z<T>((float)b[e]);
+        *reinterpret_cast<f32x4*>(ta + rr * LA + cv) = okdd ? r.xd[v] : zero;
+        *reinterpret_cast<f32x4*>(ta + rr * LA + RC + cv) = okr ? r.xc[v] : zero;
+        *reinterpret_cast<f32x4*>(ta + rr * LA + 2 * RC + cv) = __builtin_bit_cast(f32x4, b);
+        *reinterpret_cast<f32x4*>(td + rr * LD + cv) = okr ? r.f[v] : zero;
+        *reinterpret_cast<f32x4*>(td + rr * LD + RC + cv) = okr ? r.g[v] : zero;
+      }
+    };
+    auto multiply = [&](int buf) {
+      const T* ta = tileA(buf); const T* td = tileD(buf);
+      if (tid < 2 * RC) {
+#pragma unroll 8
+        for (int rr = 0; rr < KR; ++rr) bsum += (float)td[rr * LD + tid];
+      }
+#pragma unroll
+      for (int ks = 0; ks < KR / 16; ++ks) {
+        if (has_conv) {
+          const Frag<T> a_conv = Ld2<T>::load(ta, LA, 16 * ks, 32 * wave, lane);
+#pragma unroll
+          for (int n = 0; n < CT; ++n) mma(accF[n], a_conv, Ld2<T>::load(td, LD, 16 * ks, 32 * n, lane));
+        }
+        if (has_res) {
+          const Frag<T> a_c = Ld2<T>::load(ta, LA, 16 * ks, 2 * RC + 32 * res_rt, lane);
+          mma(accR, a_c, Ld2<T>::load(td, LD, 16 * ks, RC + 32 * res_ct, lane));
+        }
+      }
+    };
+    Ring q0, q1, q2;            // chunk c waits in set c % 3
+    rload(0, q0);
+    rload(1, q1);
+    rload(2, q2);
+    if (nit > 0) rstore(0, q0);
+    rload(3, q0);
+    __syncthreads();
+    auto step = [&](int it, Ring& nxt) {   // every group runs nit_all steps (the barrier count is per workgroup)
+      if (it < nit) multiply(it & 1);
+      if (it + 1 < nit) rstore(it + 1, nxt);
+      rload(it + 4, nxt);
+      __syncthreads();
+    };
+    for (int it = 0; it < nit_all; it += 3) {
+      step(it, q1);
+      if (it + 1 >= nit_all) break;
+      step(it + 1, q2);
+      if (it + 2 >= nit_all) break;
+      step(it + 2, q0);
+    }
+  } else {
   if (nit > 0) { gload(0); lstore(0); }
   __syncthreads();
   for (int it = 0; it < nit_all; ++it) {
@@ -451,6 +536,7 @@ __global__ __launch_bounds__(256 * NG) void wgrad_layer_kernel(WgLArgs a) {
     }
     if (it + 1 < nit) lstore(buf ^ 1);
     __syncthreads();
+  }
   }
 
   if (NG > 1) {
