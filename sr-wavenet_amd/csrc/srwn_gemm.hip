@@ -202,55 +202,70 @@ __global__ __launch_bounds__(64 * rg_waves(EPI, NT), (EPI == SRWN_EPI_SOFTMAX_CE
     const int64_t row = rowv[0];
     const bool vld = valid[0];
     const int tgt = vld ? a.targets[row] : -1;
+    // The range and target compares (n < cout_valid, n == tgt) are loop-invariant across the three passes; hipcc
+    // hoists all 256 of them into SGPR pairs, runs out and spills several hundred through v_writelane.  `opaque`
+    // makes each pass recompute its own (2 VALU ops per element) and consume them at once.  One exp per logit: the
+    // accumulators are overwritten by exp(logit - max) and scaled by grad_scale/sum for the gradient.
+    auto opaque = [](int x) { asm volatile("" : "+v"(x)); return x; };
     float m = -INFINITY, vt = 0.0f;
+    {
+      const int cv = opaque(a.cout_valid), tg = opaque(tgt);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int n = 32 * mt + crow(q, half);
-        if (n < a.cout_valid) m = fmaxf(m, acc[mt][0][q]);
-        if (n == tgt) vt = acc[mt][0][q];
-      }
+        for (int q = 0; q < 16; ++q) {
+          const int n = 32 * mt + crow(q, half);
+          if (n < cv) m = fmaxf(m, acc[mt][0][q]);
+          if (n == tg) vt = acc[mt][0][q];
+        }
+    }
     m = fmaxf(m, __shfl_xor(m, 32));
     vt += __shfl_xor(vt, 32);
+    if (a.logits_out && vld) {
+      float* lr = a.logits_out + row * (int64_t)a.cout_valid;
+      const int cv = opaque(a.cout_valid);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int n = 32 * mt + crow(q, half);
+          if (n < cv) lr[n] = acc[mt][0][q];
+        }
+    }
     float s = 0.0f;
+    {
+      const int cv = opaque(a.cout_valid);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int n = 32 * mt + crow(q, half);
-        if (n < a.cout_valid) s += __expf(acc[mt][0][q] - m);
-      }
+        for (int q = 0; q < 16; ++q) {
+          const int n = 32 * mt + crow(q, half);
+          const float e = (n < cv) ? __expf(acc[mt][0][q] - m) : 0.0f;
+          acc[mt][0][q] = e;
+          s += e;
+        }
+    }
     s += __shfl_xor(s, 32);
     const float lse = m + __logf(s);
     float loss = (vld && half == 0) ? (lse - vt) : 0.0f;
 #pragma unroll
     for (int off = 16; off > 0; off >>= 1) loss += __shfl_xor(loss, off);
     if (lane == 0 && tile0 * 32 < a.rows) a.loss_partials[tile0] = loss;
-    if (a.logits_out && vld) {
-      float* lr = a.logits_out + row * (int64_t)a.cout_valid;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int n = 32 * mt + crow(q, half);
-          if (n < a.cout_valid) lr[n] = acc[mt][0][q];
-        }
-    }
     if (a.y) {
+      const float ps = a.grad_scale / s;   // probabilities * grad_scale
       const int64_t r0 = tile0 * 32;
       const int rows_valid = (a.rows - r0) < 32 ? (int)(a.rows - r0) : 32;
       T* ytile = reinterpret_cast<T*>(a.y) + (rows_valid > 0 ? r0 : 0) * a.y_row_stride;
 #pragma unroll
       for (int j = 0; j < MT / 2; ++j) {
+        const int tg = opaque(tgt);
         float v[2][16];
 #pragma unroll
         for (int m2 = 0; m2 < 2; ++m2)
 #pragma unroll
           for (int q = 0; q < 16; ++q) {
             const int n = 32 * (2 * j + m2) + crow(q, half);
-            const float p = (n < a.cout_valid) ? __expf(acc[2 * j + m2][0][q] - lse) : 0.0f;
-            v[m2][q] = (p - (n == tgt ? 1.0f : 0.0f)) * a.grad_scale;
+            v[m2][q] = fmaf(acc[2 * j + m2][0][q], ps, n == tg ? -a.grad_scale : 0.0f);
           }
         store_rows_via_lds<T, 2>(rstage, ytile + 64 * j, a.y_row_stride, v, rows_valid, lane);
       }
