@@ -25,6 +25,10 @@ extern "C" {
 #define SRWN_IO_E_SHAPE  (-8)   /* FixedLenFeature length mismatch */
 
 const char* srwn_io_last_error(void);
+/* CRC-32C (Castagnoli) of a host buffer and TensorFlow's mask ((crc >> 15 | crc << 17) + 0xa282ead8): TFRecord
+ * frames, checkpoint index blocks and tensor-bundle entries store the masked value (tf_checkpoint.py uses these). */
+uint32_t srwn_crc32c(const void* data, uint64_t n);
+uint32_t srwn_crc32c_mask(uint32_t crc);
 
 /* maps the file and indexes every record; verify_crc != 0 checks both CRCs of every record.  NULL on failure. */
 void* srwn_tfr_open(const char* path, int32_t verify_crc);

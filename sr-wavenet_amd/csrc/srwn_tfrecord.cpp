@@ -198,6 +198,14 @@ int check_idx(File* f, int64_t i) {
 
 extern "C" const char* srwn_io_last_error(void) { return g_err; }
 
+// CRC-32C (Castagnoli) of a host buffer, and TensorFlow's masking of it (records, table blocks and tensor bundle
+// entries all store the masked value)
+extern "C" uint32_t srwn_crc32c(const void* data, uint64_t n) {
+  crc_init();
+  return crc32c(static_cast<const uint8_t*>(data), (size_t)n);
+}
+extern "C" uint32_t srwn_crc32c_mask(uint32_t crc) { return masked(crc); }
+
 extern "C" void* srwn_tfr_open(const char* path, int32_t verify_crc) {
   crc_init();
   if (!path) { fail(SRWN_IO_E_ARG, "null path"); return nullptr; }

@@ -47,6 +47,53 @@ def _default_dtype():
     return torch.float32 if os.environ.get("SRWN_DTYPE", "bf16").lower() in ("f32", "fp32", "float32") else torch.bfloat16
 
 
+# --- checkpoint files --------------------------------------------------------------------------------------------
+# Two on-disk forms behind the reference's `checkpoint` state file (model.py:217-235): this package's own
+# `model.ckpt-N.pt` (a torch state dict keyed by the reference's variable names) and TensorFlow's V2 bundle
+# `model.ckpt-N.index` + `.data-00000-of-00001` as tf.train.Saver writes it (tf_checkpoint.py; SRWN_CKPT_FORMAT=tf or
+# save(..., fmt="tf")), so weights trained with the reference load by name and vice versa.
+def _write_state(logdir, global_step, params, fmt=None):
+    fmt = fmt or os.environ.get("SRWN_CKPT_FORMAT", "pt")
+    os.makedirs(logdir, exist_ok=True)
+    if fmt == "tf":
+        from . import tf_checkpoint as tfc
+        name = "model.ckpt-%d" % int(global_step)
+        tfc.write_bundle(os.path.join(logdir, name), {k: v.detach().float().cpu().numpy() for k, v in params.items()})
+        tfc.write_checkpoint_state(logdir, name)
+        return
+    if fmt != "pt":
+        raise ValueError("checkpoint format %r (pt, tf)" % (fmt,))
+    state = {k: v.detach().cpu().clone() for k, v in params.items()}
+    torch.save(state, os.path.join(logdir, "model.ckpt-%d.pt" % int(global_step)))
+    with open(os.path.join(logdir, "checkpoint"), "w") as f:
+        f.write('model_checkpoint_path: "model.ckpt-%d.pt"\n' % int(global_step))
+
+
+def _read_state(logdir, params_fn):
+    """None: no checkpoint state file; False: the file it names is missing; True: the tensors of `params_fn()` filled
+    (it is only called once a file is there: building the name map instantiates the model's first engine)."""
+    if logdir is None or not os.path.exists(os.path.join(logdir, "checkpoint")):
+        return None
+    from . import tf_checkpoint as tfc
+    path = tfc.latest_checkpoint(logdir)
+    if path is None or not (os.path.exists(path) or tfc.is_bundle(path)):
+        print("Could not find checkpoint at %s" % path)
+        return False
+    params = params_fn()
+    if tfc.is_bundle(path):
+        arrays = tfc.read_bundle(path, names=list(params))       # Adam slots and counters in the file are ignored
+        get = lambda k: torch.from_numpy(arrays[k])
+    else:
+        state = torch.load(path, weights_only=True)
+        get = lambda k: state[k]
+    for k, dst in params.items():
+        src = get(k)
+        if src.numel() != dst.numel():
+            raise ValueError("checkpoint variable %s has shape %s, the model's is %s" % (k, tuple(src.shape), tuple(dst.shape)))
+        dst.copy_(src.to(dst.device).reshape(dst.shape))
+    return True
+
+
 class _EngineOwner:
     """Builds one engine per (batch, length) seen, all sharing the same parameters."""
 
@@ -77,31 +124,19 @@ class _EngineOwner:
         return self._primary.tf_variables(self._scope, decoder=self._decoder_names)
 
     # --- checkpointing with the reference's cadence semantics (model.py:217-239) -------------------
-    def save(self, logdir, global_step, force=False):
+    def save(self, logdir, global_step, force=False, fmt=None):
         if force or time.time() - self.last_checkpoint_time > 60:
-            os.makedirs(logdir, exist_ok=True)
-            state = {k: v.detach().cpu().clone() for k, v in self.network_params.items()}
-            torch.save(state, os.path.join(logdir, "model.ckpt-%d.pt" % int(global_step)))
-            with open(os.path.join(logdir, "checkpoint"), "w") as f:
-                f.write('model_checkpoint_path: "model.ckpt-%d.pt"\n' % int(global_step))
+            _write_state(logdir, global_step, self.network_params, fmt)
             self.last_checkpoint_time = time.time()
             return True
         return False
 
     def load(self, logdir):
-        if logdir is None or not os.path.exists(os.path.join(logdir, "checkpoint")):
-            return None
-        line = open(os.path.join(logdir, "checkpoint")).readline()
-        path = os.path.join(logdir, line.split('"')[1])
-        if not os.path.exists(path):
-            print("Could not find checkpoint at %s" % path)
-            return False
-        state = torch.load(path, weights_only=True)
-        for k, dst in self.network_params.items():
-            dst.copy_(state[k].to(dst.device).reshape(dst.shape))
-        self._primary.repack()
-        print("Restoring previous session")
-        return True
+        ok = _read_state(logdir, lambda: self.network_params)
+        if ok:
+            self._primary.repack()
+            print("Restoring previous session")
+        return ok
 
 
 class WaveNet(_EngineOwner):
@@ -193,10 +228,10 @@ class WaveNetTeacher(_EngineOwner):
                                 dtype=dtype or _default_dtype(),
                                 learning_rate=learning_rate), seed)
 
-    def save(self, logdir, global_step, force=False):
+    def save(self, logdir, global_step, force=False, fmt=None):
         """Checkpoint + ``config.json`` (the constructor arguments; the reference gets them from the meta graph
         it imports at model.py:318)."""
-        done = super().save(logdir, global_step, force)
+        done = super().save(logdir, global_step, force, fmt)
         if done:
             import json
             with open(os.path.join(logdir, "config.json"), "w") as f:
@@ -368,14 +403,10 @@ class WaveNetAutoEncoder(object):
         return out
 
     # --- the reference's methods (model.py:217-285) ---------------------------------------------------
-    def save(self, logdir, global_step, force=False):
+    def save(self, logdir, global_step, force=False, fmt=None):
         if force or time.time() - self.last_checkpoint_time > 60:
             import json
-            os.makedirs(logdir, exist_ok=True)
-            state = {k: v.detach().cpu().clone() for k, v in self.network_params.items()}
-            torch.save(state, os.path.join(logdir, "model.ckpt-%d.pt" % int(global_step)))
-            with open(os.path.join(logdir, "checkpoint"), "w") as f:
-                f.write('model_checkpoint_path: "model.ckpt-%d.pt"\n' % int(global_step))
+            _write_state(logdir, global_step, self.network_params, fmt)
             with open(os.path.join(logdir, "config.json"), "w") as f:
                 json.dump(dict(self._ctor, **{"class": "WaveNetAutoEncoder"}), f)
             self.last_checkpoint_time = time.time()
@@ -383,19 +414,11 @@ class WaveNetAutoEncoder(object):
         return False
 
     def load(self, logdir):
-        if logdir is None or not os.path.exists(os.path.join(logdir, "checkpoint")):
-            return None
-        line = open(os.path.join(logdir, "checkpoint")).readline()
-        path = os.path.join(logdir, line.split('"')[1])
-        if not os.path.exists(path):
-            print("Could not find checkpoint at %s" % path)
-            return False
-        state = torch.load(path, weights_only=True)
-        for k, dst in self.network_params.items():
-            dst.copy_(state[k].to(dst.device).reshape(dst.shape))
-        self._eng.enc.repack(); self._eng.dec.repack()
-        print("Restoring previous session")
-        return True
+        ok = _read_state(logdir, lambda: self.network_params)
+        if ok:
+            self._eng.enc.repack(); self._eng.dec.repack()
+            print("Restoring previous session")
+        return ok
 
     @classmethod
     def from_checkpoint(cls, logdir, batch, length, dtype=None):
@@ -573,28 +596,16 @@ class ParallelWaveNet(object):
     def load(self, sess, logdir):
         if self._teacher_dir is not None and self._teacher is not None:
             self._teacher.load(self._teacher_dir)                                         # model.py:543-544
-        if logdir is None or not os.path.exists(os.path.join(logdir, "checkpoint")):
-            return None
-        line = open(os.path.join(logdir, "checkpoint")).readline()
-        path = os.path.join(logdir, line.split('"')[1])
-        if not os.path.exists(path):
-            print("Could not find checkpoint at %s" % path)
-            return False
-        state = torch.load(path, weights_only=True)
-        for k, dst in self.network_params.items():
-            dst.copy_(state[k].to(dst.device).reshape(dst.shape))
-        for f in self._primary.flows:
-            f.repack()
-        print("Restoring previous session")
-        return True
+        ok = _read_state(logdir, lambda: self.network_params)
+        if ok:
+            for f in self._primary.flows:
+                f.repack()
+            print("Restoring previous session")
+        return ok
 
-    def save(self, sess, logdir, global_step, force=False):
+    def save(self, sess, logdir, global_step, force=False, fmt=None):
         if force or time.time() - self.last_checkpoint_time > 60:
-            os.makedirs(logdir, exist_ok=True)
-            state = {k: v.detach().cpu().clone() for k, v in self.network_params.items()}
-            torch.save(state, os.path.join(logdir, "model.ckpt-%d.pt" % int(global_step)))
-            with open(os.path.join(logdir, "checkpoint"), "w") as f:
-                f.write('model_checkpoint_path: "model.ckpt-%d.pt"\n' % int(global_step))
+            _write_state(logdir, global_step, self.network_params, fmt)
             self.last_checkpoint_time = time.time()
             return True
         return False

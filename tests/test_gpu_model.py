@@ -255,3 +255,47 @@ def test_example_drivers_end_to_end(tmp_path):
         d = os.path.join(root, "sr-wavenet_amd", "dropin")
         while d in sys.path:
             sys.path.remove(d)
+
+
+def test_tensorflow_format_checkpoints_round_trip_by_reference_names(tmp_path, monkeypatch):
+    """save(fmt="tf") writes what tf.train.Saver(self.network_params) would (model.ckpt-N.index / .data-00000-of-00001
+    + the `checkpoint` state file, variables under the reference's names, model.py:119,230-235); load() restores from
+    it, ignoring optimizer slots a real Saver file may also hold; a second model built from scratch loads it too."""
+    M = sub("model"); TFC = sub("tf_checkpoint")
+    dil = [1, 2, 4]
+    B, T = 2, 128
+    audio = O.synthetic_audio(B, T, seed=5)
+    m = M.WaveNetTeacher(T, 0, dil, dilation_channels=32, skip_channels=128, dtype=torch.float32)
+    for _ in range(2):
+        m.train(audio)
+    want = float(m.loss(audio))
+    d = str(tmp_path / "tfckpt")
+    assert m.save(d, 12, force=True, fmt="tf") is True
+    assert sorted(os.listdir(d)) == ["checkpoint", "config.json", "model.ckpt-12.data-00000-of-00001", "model.ckpt-12.index"]
+    names = set(TFC.read_index(os.path.join(d, "model.ckpt-12.index"))[1])
+    # scope 'WaveNetTeacher' (model.py:87 builds the teacher under tf.variable_scope(name), default 'WaveNetTeacher')
+    assert "WaveNetTeacher/causal_conv_Kernel" in names
+    assert "WaveNetTeacher/dilated_conv_2_filter/dilated_conv_2_Kernel" in names
+    assert names == set(m.network_params)
+    # a Saver file also carries Adam slots and counters: add some, they must be ignored
+    arrays = TFC.read_bundle(os.path.join(d, "model.ckpt-12"))
+    arrays["WaveNetTeacher/causal_conv_Kernel/Adam"] = np.zeros_like(arrays["WaveNetTeacher/causal_conv_Kernel"])
+    arrays["beta1_power"] = np.array(0.9, np.float32)
+    TFC.write_bundle(os.path.join(d, "model.ckpt-12"), arrays)
+    for _ in range(2):
+        m.train(audio)
+    assert float(m.loss(audio)) != want
+    assert m.load(d) is True
+    assert abs(float(m.loss(audio)) - want) < 1e-6
+    fresh = M.WaveNetTeacher.from_checkpoint(d, dtype=torch.float32)
+    assert abs(float(fresh.loss(audio)) - want) < 1e-6
+    # a variable of the wrong size is an error, not a silent reshape
+    arrays["WaveNetTeacher/causal_conv_Bias"] = np.zeros((1, 1, 7), np.float32)
+    TFC.write_bundle(os.path.join(d, "model.ckpt-12"), arrays)
+    with pytest.raises(ValueError, match="causal_conv_Bias"):
+        m.load(d)
+    # environment default
+    monkeypatch.setenv("SRWN_CKPT_FORMAT", "tf")
+    d2 = str(tmp_path / "env")
+    assert m.save(d2, 1, force=True)
+    assert os.path.exists(os.path.join(d2, "model.ckpt-1.index"))
