@@ -103,15 +103,27 @@ __global__ __launch_bounds__(256) void nc_layer_fwd_kernel(NcFwdArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) accF[mt][4 * g + e] = bv[e];
       }
+    // operands of k-step s+1 are read from LDS before the MFMAs of k-step s issue (one wave per SIMD here: nothing
+    // else hides the ds_read -> v_mfma round trip hipcc otherwise leaves in front of every MFMA)
+    {
+      constexpr int NS = kTaps * kKS;
+      Frag<bf16_t> af[2][kRT], bfr[2];
+      auto fetch = [&](int s, int slot) {
+        const int k = s / kKS, ks = s % kKS;
+        bfr[slot] = load_nat(buf + (col + k) * kLS + 16 * ks + 8 * half);
 #pragma unroll
-    for (int k = 0; k < kTaps; ++k) {
-      const bool valid = tc + k < a.Tlen;   // a tap beyond the clip contributes 0 (SAME padding)
+        for (int mt = 0; mt < kRT; ++mt) af[slot][mt] = lds_conv[(mt * NS + s) * 64 + lane];
+      };
+      fetch(0, 0);
 #pragma unroll
-      for (int ks = 0; ks < kKS; ++ks) {
-        Frag<bf16_t> bf = load_nat(buf + (col + k) * kLS + 16 * ks + 8 * half);
-        bf = valid ? bf : zero_frag<bf16_t>();
+      for (int s = 0; s < NS; ++s) {
+        if (s + 1 < NS) fetch(s + 1, (s + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const bool valid = tc + s / kKS < a.Tlen;   // a tap beyond the clip contributes 0 (SAME padding)
+        const Frag<bf16_t> bf = valid ? bfr[s & 1] : zero_frag<bf16_t>();
 #pragma unroll
-        for (int mt = 0; mt < kRT; ++mt) mma(accF[mt], lds_conv[(mt * (kTaps * kKS) + k * kKS + ks) * 64 + lane], bf);
+        for (int mt = 0; mt < kRT; ++mt) mma(accF[mt], af[s & 1][mt], bf);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     Frag<bf16_t> cf[kKS];
@@ -138,10 +150,22 @@ __global__ __launch_bounds__(256) void nc_layer_fwd_kernel(NcFwdArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) accR[mt][4 * g + e] = bv[e];
       }
+    {
+      Frag<bf16_t> af[2][kRT];
 #pragma unroll
-    for (int s = 0; s < kKS; ++s)
+      for (int mt = 0; mt < kRT; ++mt) af[0][mt] = lds_res[(mt * kKS) * 64 + lane];
 #pragma unroll
-      for (int mt = 0; mt < kRT; ++mt) mma(accR[mt], lds_res[(mt * kKS + s) * 64 + lane], cf[s]);
+      for (int s = 0; s < kKS; ++s) {
+        if (s + 1 < kKS) {
+#pragma unroll
+          for (int mt = 0; mt < kRT; ++mt) af[(s + 1) & 1][mt] = lds_res[(mt * kKS + s + 1) * 64 + lane];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mt = 0; mt < kRT; ++mt) mma(accR[mt], af[s & 1][mt], cf[s]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
     float rv[kRT][16];
 #pragma unroll
     for (int mt = 0; mt < kRT; ++mt)
@@ -235,15 +259,25 @@ __global__ __launch_bounds__(256) void nc_layer_bwd_kernel(NcBwdArgs a) {
     for (int mt = 0; mt < kRT; ++mt)
 #pragma unroll
       for (int q = 0; q < 16; ++q) accG[mt][q] = 0.0f;
+    {   // (operands one k-step ahead of their MFMAs, as in the forward kernel)
+      constexpr int NS = kTaps * kKS;
+      Frag<bf16_t> af[2][kRT], bfr[2];
+      auto fetch = [&](int s, int slot) {
+        const int k = s / kKS, ks = s % kKS;
+        bfr[slot] = load_nat(buf + (col + 1 - k) * kLS + 16 * ks + 8 * half);
 #pragma unroll
-    for (int k = 0; k < kTaps; ++k) {
-      const bool valid = ok && (tc - k >= 0);   // dh[t] = sum_k W[k]^T dpre[t-k]; before the clip: 0
+        for (int mt = 0; mt < kRT; ++mt) af[slot][mt] = lds_conv[(mt * NS + s) * 64 + lane];
+      };
+      fetch(0, 0);
 #pragma unroll
-      for (int ks = 0; ks < kKS; ++ks) {
-        Frag<bf16_t> bf = load_nat(buf + (col + 1 - k) * kLS + 16 * ks + 8 * half);
-        bf = valid ? bf : zero_frag<bf16_t>();
+      for (int s = 0; s < NS; ++s) {
+        if (s + 1 < NS) fetch(s + 1, (s + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const bool valid = ok && (tc - s / kKS >= 0);   // dh[t] = sum_k W[k]^T dpre[t-k]; before the clip: 0
+        const Frag<bf16_t> bf = valid ? bfr[s & 1] : zero_frag<bf16_t>();
 #pragma unroll
-        for (int mt = 0; mt < kRT; ++mt) mma(accG[mt], lds_conv[(mt * (kTaps * kKS) + k * kKS + ks) * 64 + lane], bf);
+        for (int mt = 0; mt < kRT; ++mt) mma(accG[mt], af[s & 1][mt], bf);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     Frag<bf16_t> gf[kKS];
@@ -267,10 +301,22 @@ __global__ __launch_bounds__(256) void nc_layer_bwd_kernel(NcBwdArgs a) {
       for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int e = 0; e < 4; ++e) accC[mt][4 * g + e] = FADD ? r.fa[mt][g][e] * a.fadd_scale : 0.0f;
+    {
+      Frag<bf16_t> af[2][kRT];
 #pragma unroll
-    for (int s = 0; s < kKS; ++s)
+      for (int mt = 0; mt < kRT; ++mt) af[0][mt] = lds_res[(mt * kKS) * 64 + lane];
 #pragma unroll
-      for (int mt = 0; mt < kRT; ++mt) mma(accC[mt], lds_res[(mt * kKS + s) * 64 + lane], gf[s]);
+      for (int s = 0; s < kKS; ++s) {
+        if (s + 1 < kKS) {
+#pragma unroll
+          for (int mt = 0; mt < kRT; ++mt) af[(s + 1) & 1][mt] = lds_res[(mt * kKS + s + 1) * 64 + lane];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mt = 0; mt < kRT; ++mt) mma(accC[mt], af[s & 1][mt], gf[s]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
     float pv[kRT][16];
 #pragma unroll
     for (int mt = 0; mt < kRT; ++mt)
