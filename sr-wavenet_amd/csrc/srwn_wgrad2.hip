@@ -426,13 +426,13 @@ __global__ __launch_bounds__(256 * NG) void wgrad_layer_kernel(WgLArgs a) {
     }
   };
 
-  if constexpr (sizeof(T) == 2 && !COND) {
-    // bf16, unconditioned stacks: a ring of three register sets -- chunk it+4 is requested while chunk it is
+  if constexpr (sizeof(T) == 2) {
+    // bf16: a ring of three register sets -- chunk it+4 is requested while chunk it is
     // multiplied, three steps before it moves to LDS.  With one set the request preceded its use by one chunk's
     // MFMAs (~0.2 us) against an HBM round trip of > 1 us, so every step waited for memory.  The loads are
     // unconditional (rows clamped into the tensor; rows outside the group's range are zeroed on their way to LDS),
     // which lets hipcc count them instead of draining.
-    struct Ring { f32x4 xd[NV], xc[NV], z[NV], f[NV], g[NV]; };
+    struct Ring { f32x4 xd[NV], xc[NV], z[NV], f[NV], g[NV], cd[COND ? NV : 1], cc[COND ? NV : 1]; };
     auto rload = [&](int it, Ring& r) {
       const int64_t r0 = r_begin + (int64_t)it * KR;
 #pragma unroll
@@ -448,7 +448,19 @@ __global__ __launch_bounds__(256 * NG) void wgrad_layer_kernel(WgLArgs a) {
         r.z[v] = *reinterpret_cast<const f32x4*>(zb + rowc * RC + cv);
         r.f[v] = *reinterpret_cast<const f32x4*>(fb + rowc * RC + cv);
         r.g[v] = *reinterpret_cast<const f32x4*>(gb + rowc * RC + cv);
+        if (COND) {
+          const int64_t bidx = rowc / a.Tlen;
+          const int td = (t - d >= 0) ? t - d : t;
+          r.cd[v] = *reinterpret_cast<const f32x4*>(cb + (bidx * a.cond_frames + td / a.pool) * a.cond_stride + cv);
+          r.cc[v] = *reinterpret_cast<const f32x4*>(cb + (bidx * a.cond_frames + t / a.pool) * a.cond_stride + cv);
+        }
       }
+    };
+    auto addc2 = [&](f32x4 x, f32x4 c) {   // x + c in T precision (the conditioned input the forward pass saw)
+      bf16x8 xb_ = __builtin_bit_cast(bf16x8, x), cb_ = __builtin_bit_cast(bf16x8, c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xb_[e] = (bf16_t)((float)xb_[e] + (float)cb_[e]);
+      return __builtin_bit_cast(f32x4, xb_);
     };
     auto rstore = [&](int it, const Ring& r) {
       const int64_t r0 = r_begin + (int64_t)it * KR;
@@ -464,8 +476,10 @@ __global__ __launch_bounds__(256 * NG) void wgrad_layer_kernel(WgLArgs a) {
         bf16x8 b = __builtin_bit_cast(bf16x8, okr ? r.z[v] : zero);
 #pragma unroll
         for (int e = 0; e < 8; ++e) b[e] = (bf16_t)gate_of_z<T>((float)b[e]);
-        *reinterpret_cast<f32x4*>(ta + rr * LA + cv) = okdd ? r.xd[v] : zero;
-        *reinterpret_cast<f32x4*>(ta + rr * LA + RC + cv) = okr ? r.xc[v] : zero;
+        f32x4 xd = r.xd[v], xc = r.xc[v];
+        if (COND) { xd = addc2(xd, r.cd[v]); xc = addc2(xc, r.cc[v]); }
+        *reinterpret_cast<f32x4*>(ta + rr * LA + cv) = okdd ? xd : zero;
+        *reinterpret_cast<f32x4*>(ta + rr * LA + RC + cv) = okr ? xc : zero;
         *reinterpret_cast<f32x4*>(ta + rr * LA + 2 * RC + cv) = __builtin_bit_cast(f32x4, b);
         *reinterpret_cast<f32x4*>(td + rr * LD + cv) = okr ? r.f[v] : zero;
         *reinterpret_cast<f32x4*>(td + rr * LD + RC + cv) = okr ? r.g[v] : zero;
