@@ -96,6 +96,25 @@ int srwn_residual_layer_fwd(const void* x, const void* cond, const void* wconv, 
                             int32_t T, int32_t R, int32_t K, int32_t dilation, int32_t cond_frames,
                             int32_t pool_stride, int32_t cond_row_stride, int32_t dtype, void* stream);
 
+/* ---- several consecutive residual layers per launch (the stacking loops model.py:42-47, 176-189, 428-453 around
+ * ResidualDilationLayer, ops.py:23-46).  Same arithmetic, operands and outputs as `nlayers` calls of
+ * srwn_residual_layer_fwd (bit-identical results), but the layer outputs travel between layers in LDS:
+ * layer g (dilation dilations[g]) reads x_{g} and stores z_g at z_out + g*layer_stride and x_{g+1} at
+ * x_out + g*layer_stride (elements; the engine's [L,B,T,R] stacks).  wconv/wres/bias_f/bias_r/cond_next are HOST
+ * arrays of nlayers device pointers (cond_next[g] = the conditioning bias of the layer above layer g, or NULL).
+ * Requirement: sum(dilations)/gcd(dilations) <= 63 and nlayers <= 8 (srwn_group_plan cuts a stack accordingly):
+ * the kernel works on the residue classes t = j*gcd + r, where the group's dilations are small, and recomputes a
+ * halo of that many steps per segment.  seg_rows = 0 lets the library choose the segment length. */
+int srwn_residual_group_fwd(const void* x0, void* x_out, void* z_out, int64_t layer_stride,
+                            const void* const* wconv, const void* const* wres, const float* const* bias_f,
+                            const float* const* bias_r, const void* const* cond_next, int32_t cond_frames,
+                            int32_t pool_stride, int32_t cond_row_stride, const int32_t* dilations, int32_t nlayers,
+                            int32_t B, int32_t T, int32_t R, int32_t K, int32_t seg_rows, int32_t dtype, void* stream);
+/* greedy cut of a stack's dilation list (model.py:9, teacher.py:57) into such groups: starts[0..n] (starts[n] = nlayers),
+ * returns n.  `starts` needs nlayers + 1 entries. */
+int32_t srwn_group_plan(const int32_t* dilations, int32_t nlayers, int32_t max_halo, int32_t max_layers,
+                        int32_t* starts);
+
 /* ---- pointwise linear ("channels GEMM"): tf.layers.conv1d kernel_size=1 (ops.py:39,44;
  * model.py:53,56,180) and the sum of all skip 1x1s (model.py:50) as one K = L*R contraction:
  *   y[row, n] = epi( bias[n] + sum_k pro(x[row, k]) * W[k, n] )

@@ -30,6 +30,9 @@ SIGNATURES = {
     "srwn_init_conv_wgrad": (C.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "srwn_residual_layer_fwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                           _i32, _i32, _p]),
+    "srwn_residual_group_fwd": (C.c_int, [_p, _p, _p, _i64, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _i32, _i32, _i32,
+                                          _i32, _i32, _i32, _i32, _p]),
+    "srwn_group_plan": (_i32, [_p, _i32, _i32, _i32, _p]),
     "srwn_pw_linear": (C.c_int, [_p, _i64, _i64, _i32, _i32, _p, _p, _p, _i64, _i32, _i32, _i64, _p, _i64, _i32,
                                  _i32, _i32, _p]),
     "srwn_pw_linear_ksplit": (C.c_int, [_p, _i64, _i64, _i32, _i32, _p, _p, _p, _i64, _i32, _i32, _i64, _i32, _i32, _p]),

@@ -1,0 +1,465 @@
+// Multi-layer ("group") kernels of the residual stack: several consecutive ResidualDilationLayers (ops.py:23-46,
+// stacked by model.py:42-47 / 176-189 / 428-453) per launch, activations carried between layers in LDS instead of HBM.
+// gfx950 (MI355X) only; MFMA orientation and lane maps: srwn_common.h.
+//
+// Time decomposition.  A group is a run of layers whose dilations are all multiples of a common stride `st`
+// (st = gcd; d_g = st * sub_g).  Positions t = j*st + r of one residue class r form a sub-sequence on which the
+// group's layers act with the small dilations sub_g, independently of every other residue class.  So
+//   {1,2,4,8,16}      -> st = 1,  sub = 1,2,4,8,16   (32 segments of 500 steps per 16000-step clip)
+//   {32,...,512}      -> st = 32, sub = 1,2,4,8,16   (32 residue classes of 500 steps per clip)
+// are the same program: a workgroup owns one SEGMENT = (clip b, residue r, positions [j0, j0+W)) plus a halo of
+// H = sum(sub_g) <= 63 positions on the causal side, which it recomputes instead of exchanging with a neighbour.
+// The only difference is the HBM row stride (a row = R channels of one time step = one or two whole cache lines).
+//
+// Forward (group_fwd_kernel): 8 waves; the segment's rows live in one LDS image [rows][R] (padded rows); per layer
+//   tap(t - sub) fragments of every owned 32-row tile are read -> barrier -> conv MFMAs, tanh, gate, 1x1 residual
+//   exactly as layer_fwd_kernel does them (same MFMA order: results are bit-identical to the per-layer path) ->
+//   z and the new x go through the tile's own image rows to HBM as whole rows -> barrier.  Weights of layer g+1
+//   stream into the second weight buffer while layer g computes.
+#include <cstdlib>
+#include "srwn_common.h"
+#include "srwn_host.h"
+#include "../../include/srwn.h"
+
+using namespace srwn;
+
+namespace {
+
+constexpr int kMaxGroup = 8;
+
+template <typename T> struct Raw4g;
+template <> struct Raw4g<bf16_t> {
+  typedef bf16x4 type;
+  static __device__ __forceinline__ type load(const bf16_t* p) { return *reinterpret_cast<const bf16x4*>(p); }
+  static __device__ __forceinline__ float get(const type& v, int e) { return (float)v[e]; }
+};
+template <> struct Raw4g<float> {
+  typedef f32x4 type;
+  static __device__ __forceinline__ type load(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+  static __device__ __forceinline__ float get(const type& v, int e) { return v[e]; }
+};
+
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+struct GroupFwdArgs {
+  const void* x0;                 // input of the group's first layer [B,T,R]
+  void* x_out;                    // layer g's output at x_out + g*layer_stride (elements)
+  void* z_out;                    // layer g's z at z_out + g*layer_stride
+  int64_t layer_stride;
+  const void* wconv[kMaxGroup];   // packed conv images (natural k order), as srwn_residual_layer_fwd takes them
+  const void* wres[kMaxGroup];    // packed 1x1 residual images (permuted k order)
+  const float* bias_f[kMaxGroup];
+  const float* bias_r[kMaxGroup];
+  const void* cond[kMaxGroup];    // conditioning bias of the layer ABOVE layer g (added to what layer g stores), or null
+  int cond_frames, pool, cond_stride;
+  int sub[kMaxGroup];             // dilation / st
+  int nl, st, Tlen, B;
+  int W, H, NT;                   // positions per segment, halo positions, 32-row tiles per segment image
+  int nsub;                       // segments per sub-sequence
+  int nseg;                       // B * st * nsub
+};
+
+template <typename T, int RT, bool COND, int MAXT, int NWB>
+__global__ __launch_bounds__(512) void group_fwd_kernel(GroupFwdArgs a) {
+  constexpr int R = 32 * RT, K = 2, KS = R / 16;
+  constexpr int NCONV = RT * K * KS, NRES = RT * KS, NW = NCONV + NRES;   // weight fragments per layer
+  constexpr int LS = RowStage<T>::stride(R), VEC = RowStage<T>::VEC;
+  constexpr int LPR = R / VEC, RPI = 64 / LPR, NI = 32 / RPI;             // whole-row access: lanes per row, rows per instr
+  constexpr int WBYTES = NW * 64 * (int)sizeof(Frag<T>);
+  constexpr int WPIECES = WBYTES / 16, CPIECES = NCONV * 64 * (int)sizeof(Frag<T>) / 16;
+  constexpr int WPT = (WPIECES + 511) / 512;                              // 16-byte weight pieces per thread
+  typedef typename Raw4g<T>::type raw4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  Frag<T>* wbuf = reinterpret_cast<Frag<T>*>(smem);                       // [NWB][NW*64]
+  float* bbuf = reinterpret_cast<float*>(smem + (size_t)NWB * WBYTES);    // [NWB][2R]: bias_f | bias_r
+  T* img = reinterpret_cast<T*>(smem + (size_t)NWB * WBYTES + (size_t)NWB * 2 * R * 4);   // [NT*32][LS]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 31, half = lane >> 5;
+  const int rsub = lane / LPR, piece = lane % LPR;
+
+  f32x4 wreg[WPT];
+  f32x4 breg;
+  auto wload = [&](int g) {       // layer g's [conv | res] images and biases: global -> registers
+    const f32x4* pc = reinterpret_cast<const f32x4*>(a.wconv[g]);
+    const f32x4* pr = reinterpret_cast<const f32x4*>(a.wres[g]);
+#pragma unroll
+    for (int v = 0; v < WPT; ++v) {
+      int p = tid + v * 512;
+      p = p < WPIECES ? p : WPIECES - 1;
+      wreg[v] = p < CPIECES ? pc[p] : pr[p - CPIECES];
+    }
+    if (tid < 2 * R / 4) {
+      const int c = 4 * tid;
+      breg = c < R ? *reinterpret_cast<const f32x4*>(a.bias_f[g] + c) : *reinterpret_cast<const f32x4*>(a.bias_r[g] + c - R);
+    }
+  };
+  auto wstore = [&](int buf) {    // registers -> weight buffer `buf`
+    f32x4* dst = reinterpret_cast<f32x4*>(smem + (size_t)buf * WBYTES);
+#pragma unroll
+    for (int v = 0; v < WPT; ++v) {
+      const int p = tid + v * 512;
+      if (p < WPIECES) dst[p] = wreg[v];
+    }
+    if (tid < 2 * R / 4) *reinterpret_cast<f32x4*>(bbuf + buf * 2 * R + 4 * tid) = breg;
+  };
+
+  for (int seg = blockIdx.x; seg < a.nseg; seg += gridDim.x) {
+    // segment -> (clip b, residue r, first position j0); consecutive ids = neighbouring memory
+    const int per_clip = a.st * a.nsub;
+    const int b = seg / per_clip;
+    const int rem = seg - b * per_clip;
+    int r, j0;
+    if (a.nsub == 1) { r = rem; j0 = 0; }
+    else { r = rem / a.nsub; j0 = (rem - r * a.nsub) * a.W; }
+    const int Jr = (a.Tlen - r + a.st - 1) / a.st;             // positions of this residue class (may be 0)
+    const int Wseg = (Jr - j0) < a.W ? (Jr - j0) : a.W;        // positions this segment owns (<= 0: nothing to do)
+    const int jbase = j0 - a.H;                                // position of image row 0
+    const size_t clip = (size_t)b * a.Tlen;
+    // global row (element offset / R) of position j, clamped into the residue class
+    auto grow = [&](int j) -> size_t {
+      int jj = j < 0 ? 0 : j;
+      jj = jj < Jr ? jj : Jr - 1;
+      jj = jj < 0 ? 0 : jj;
+      size_t t = (size_t)jj * a.st + r;
+      t = t < (size_t)a.Tlen ? t : (size_t)a.Tlen - 1;
+      return clip + t;
+    };
+
+    // ---- segment image + the first layer's weights
+    wload(0);
+    {
+      const T* x0 = reinterpret_cast<const T*>(a.x0);
+      const int nrows = a.NT * 32;
+      constexpr int RPP = 512 / LPR;            // rows per pass of the whole workgroup
+      constexpr int UN = 4;
+      for (int i0 = 0; i0 < nrows; i0 += RPP * UN) {
+        f32x4 v[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          int i = i0 + u * RPP + tid / LPR;
+          i = i < nrows ? i : nrows - 1;
+          v[u] = *reinterpret_cast<const f32x4*>(x0 + grow(jbase + i) * R + (tid % LPR) * VEC);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          const int i = i0 + u * RPP + tid / LPR;
+          if (i < nrows) *reinterpret_cast<f32x4*>(img + (size_t)i * LS + (tid % LPR) * VEC) = v[u];
+        }
+      }
+    }
+    wstore(0);
+    wg_barrier();
+
+    for (int g = 0; g < a.nl; ++g) {
+      const int d = a.sub[g];
+      const int wb = (NWB == 2) ? (g & 1) : 0;
+      if (NWB == 1 && g > 0) wload(g);
+      // ---- tap (t - d) fragments of every owned tile, before anyone overwrites the rows they come from
+      Frag<T> tap0[MAXT][KS];
+#pragma unroll
+      for (int m = 0; m < MAXT; ++m) {
+        const int q = wave + 8 * m;
+        if (q < a.NT) {
+          int src = 32 * q + col - d;
+          src = src < 0 ? 0 : src;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) tap0[m][ks] = load_nat(img + (size_t)src * LS + 16 * ks + 8 * half);
+        }
+      }
+      if (NWB == 1 && g > 0) wstore(0);
+      wg_barrier();
+      const bool more = g + 1 < a.nl;
+      if (NWB == 2 && more) wload(g + 1);
+
+      const Frag<T>* lds_conv = wbuf + (size_t)wb * NW * 64;
+      const Frag<T>* lds_res = lds_conv + NCONV * 64;
+      const float* bl = bbuf + wb * 2 * R;
+      T* zg = reinterpret_cast<T*>(a.z_out) + (size_t)g * a.layer_stride;
+      T* xg = reinterpret_cast<T*>(a.x_out) + (size_t)g * a.layer_stride;
+      const T* cg = COND ? reinterpret_cast<const T*>(a.cond[g]) : nullptr;
+
+#pragma unroll
+      for (int m = 0; m < MAXT; ++m) {
+        const int q = wave + 8 * m;
+        if (q >= a.NT) continue;
+        T* trow = img + (size_t)(32 * q) * LS;           // the tile's own rows
+        const int j = jbase + 32 * q + col;              // this lane's position
+        const bool ok0 = (j - d) >= 0;                   // causal zero padding of the delayed tap (ops.py:9)
+        // rows of this tile that exist and belong to the segment: [lo, hi)
+        int lo = a.H - 32 * q;
+        lo = lo < 0 ? 0 : lo;
+        int hi = a.H + Wseg - 32 * q;
+        hi = hi > 32 ? 32 : hi;
+        const bool st_ok = hi > lo;
+
+        Frag<T> cur1[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) cur1[ks] = load_nat(trow + (size_t)col * LS + 16 * ks + 8 * half);
+        raw4 xres[RT][4];
+#pragma unroll
+        for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) xres[mt][gq] = Raw4g<T>::load(trow + (size_t)col * LS + 32 * mt + 8 * gq + 4 * half);
+
+        // ---- dilated causal conv as one (K*R)-deep contraction; accumulators start at the bias
+        f32x16 accF[RT];
+#pragma unroll
+        for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bl + 32 * mt + 8 * gq + 4 * half);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) accF[mt][4 * gq + e] = bv[e];
+          }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const Frag<T> bfr = ok0 ? tap0[m][ks] : zero_frag<T>();
+#pragma unroll
+          for (int mt = 0; mt < RT; ++mt) mma(accF[mt], lds_conv[(mt * (K * KS) + ks) * 64 + lane], bfr);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int mt = 0; mt < RT; ++mt) mma(accF[mt], lds_conv[(mt * (K * KS) + KS + ks) * 64 + lane], cur1[ks]);
+
+        // ---- tanh, gate; z leaves through the tile's own rows
+        Frag<T> cf[KS];
+        {
+          float zz[RT][16];
+#pragma unroll
+          for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+            for (int qq = 0; qq < 16; ++qq) {
+              const float z = Math<T>::tanh_(accF[mt][qq]);
+              zz[mt][qq] = z;
+              cf[2 * mt + (qq >> 3)].set(qq & 7, gate_of_z<T>(z));
+            }
+          if (st_ok) {
+            wave_lds_order();             // the reads of the own rows above are done
+#pragma unroll
+            for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+              for (int gq = 0; gq < 4; ++gq)
+                store4(trow + (size_t)col * LS + 32 * mt + 8 * gq + 4 * half, zz[mt][4 * gq], zz[mt][4 * gq + 1],
+                       zz[mt][4 * gq + 2], zz[mt][4 * gq + 3]);
+            wave_lds_order();
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+              int rr = i * RPI + rsub;
+              rr = rr < lo ? lo : (rr < hi ? rr : hi - 1);
+              const f32x4 v = *reinterpret_cast<const f32x4*>(trow + (size_t)rr * LS + piece * VEC);
+              *reinterpret_cast<f32x4*>(zg + grow(jbase + 32 * q + rr) * R + piece * VEC) = v;
+            }
+          }
+        }
+        // ---- 1x1 residual from registers, scaled residual add
+        f32x16 accR[RT];
+#pragma unroll
+        for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bl + R + 32 * mt + 8 * gq + 4 * half);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) accR[mt][4 * gq + e] = bv[e];
+          }
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+          for (int mt = 0; mt < RT; ++mt) mma(accR[mt], lds_res[(mt * KS + s) * 64 + lane], cf[s]);
+        {
+          float hv[RT][16];
+          const T* crow_ = nullptr;
+          if (COND && cg) {
+            size_t t = grow(j) - clip;                 // time step of this lane's row (clamped)
+            crow_ = cg + ((size_t)b * a.cond_frames + t / a.pool) * a.cond_stride;
+          }
+#pragma unroll
+          for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+              f32x4 cv = {0.f, 0.f, 0.f, 0.f};
+              if (COND && crow_) cv = load4(crow_ + 32 * mt + 8 * gq + 4 * half);
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                hv[mt][4 * gq + e] = (Raw4g<T>::get(xres[mt][gq], e) + accR[mt][4 * gq + e]) * kSqrtHalf + cv[e];
+            }
+          wave_lds_order();               // z row reads (and, without stores, the own-row reads) are done
+#pragma unroll
+          for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+              store4(trow + (size_t)col * LS + 32 * mt + 8 * gq + 4 * half, hv[mt][4 * gq], hv[mt][4 * gq + 1],
+                     hv[mt][4 * gq + 2], hv[mt][4 * gq + 3]);
+          if (st_ok) {
+            wave_lds_order();
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+              int rr = i * RPI + rsub;
+              rr = rr < lo ? lo : (rr < hi ? rr : hi - 1);
+              const f32x4 v = *reinterpret_cast<const f32x4*>(trow + (size_t)rr * LS + piece * VEC);
+              *reinterpret_cast<f32x4*>(xg + grow(jbase + 32 * q + rr) * R + piece * VEC) = v;
+            }
+          }
+        }
+      }
+      if (NWB == 2 && more) wstore(wb ^ 1);
+      wg_barrier();
+    }
+  }
+}
+
+int g_cus = 0;
+int num_cus() {
+  if (g_cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+      g_cus = n;
+    else
+      g_cus = 256;
+  }
+  return g_cus;
+}
+
+constexpr int kLdsBudget = 160 * 1024;
+
+// common stride, sub-dilations, halo of a run of layers
+int group_geometry(const int32_t* dil, int nl, int* st_out, int* sub, int* H_out) {
+  auto gcd = [](int x, int y) { while (y) { int t = x % y; x = y; y = t; } return x; };
+  int st = 0;
+  for (int i = 0; i < nl; ++i) {
+    if (dil[i] < 1) return -1;
+    st = gcd(st, dil[i]);
+  }
+  int H = 0;
+  for (int i = 0; i < nl; ++i) { sub[i] = dil[i] / st; H += sub[i]; }
+  *st_out = st; *H_out = H;
+  return 0;
+}
+
+// positions per segment and tiles per image for a residue class of J positions
+void choose_segments(int J, int H, int B, int st, int nt_max, int seg_rows, int* W, int* NT, int* nsub) {
+  const int wmax = nt_max * 32 - H;
+  int w;
+  if (seg_rows > 0) {
+    w = seg_rows < wmax ? seg_rows : wmax;
+  } else {
+    int ns = (J + wmax - 1) / wmax;                       // fewest segments the image size allows
+    const long long streams = (long long)B * st;
+    long long want = (num_cus() + streams - 1) / streams; // enough segments for one per CU ...
+    const int floor_w = 4 * H > 128 ? 4 * H : 128;        // ... while the halo stays <= 25 % of a segment
+    long long cap = J / floor_w; if (cap < 1) cap = 1;
+    if (want > cap) want = cap;
+    if (want > ns) ns = (int)want;
+    w = (J + ns - 1) / ns;
+  }
+  if (w < 1) w = 1;
+  *W = w;
+  *nsub = (J + w - 1) / w;
+  *NT = (H + w + 31) / 32;
+}
+
+template <typename T, int RT, int MAXT, int NWB>
+int launch_group_fwd(GroupFwdArgs& a, bool cond, int seg_rows, hipStream_t st) {
+  constexpr int R = 32 * RT, KS = R / 16, NW = RT * 2 * KS + RT * KS;
+  const size_t fixed = (size_t)NWB * NW * 64 * sizeof(Frag<T>) + (size_t)NWB * 2 * R * 4;
+  const size_t row_bytes = (size_t)RowStage<T>::stride(R) * sizeof(T);
+  int nt_max = (int)((kLdsBudget - fixed) / (32 * row_bytes));
+  if (nt_max > 8 * MAXT) nt_max = 8 * MAXT;
+  if (nt_max * 32 - a.H < 32) return set_error(SRWN_E_UNSUPPORTED, "residual_group_fwd: halo %d too large", a.H);
+  const int J = (a.Tlen + a.st - 1) / a.st;
+  choose_segments(J, a.H, a.B, a.st, nt_max, seg_rows, &a.W, &a.NT, &a.nsub);
+  const long long nseg = (long long)a.B * a.st * a.nsub;
+  if (nseg > 0x7fffffffLL) return set_error(SRWN_E_SHAPE, "residual_group_fwd: too many segments");
+  a.nseg = (int)nseg;
+  const size_t sh = fixed + (size_t)a.NT * 32 * row_bytes;
+  long long blocks = nseg < num_cus() ? nseg : num_cus();
+  dim3 grid((unsigned)blocks), block(512);
+#define SRWN_GF(C)                                                                                              \
+  {                                                                                                             \
+    auto kfn = group_fwd_kernel<T, RT, C, MAXT, NWB>;                                                           \
+    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);  \
+    if (e != hipSuccess) return set_error((int)e, "residual_group_fwd: LDS %zu: %s", sh, hipGetErrorString(e)); \
+    hipLaunchKernelGGL(kfn, grid, block, sh, st, a);                                                            \
+    return check_launch("residual_group_fwd");                                                                  \
+  }
+  if (cond) SRWN_GF(true) else SRWN_GF(false)
+#undef SRWN_GF
+}
+
+}  // namespace
+
+extern "C" int srwn_residual_group_fwd(const void* x0, void* x_out, void* z_out, int64_t layer_stride,
+                                       const void* const* wconv, const void* const* wres,
+                                       const float* const* bias_f, const float* const* bias_r,
+                                       const void* const* cond_next, int32_t cond_frames, int32_t pool_stride,
+                                       int32_t cond_row_stride, const int32_t* dilations, int32_t nlayers, int32_t B,
+                                       int32_t T, int32_t R, int32_t K, int32_t seg_rows, int32_t dtype,
+                                       void* stream) {
+  if (B == 0 || T == 0 || nlayers == 0) return 0;
+  if (!x0 || !x_out || !z_out || !wconv || !wres || !bias_f || !bias_r || !dilations)
+    return set_error(SRWN_E_NULL, "residual_group_fwd: null pointer");
+  if (K != 2) return set_error(SRWN_E_UNSUPPORTED, "residual_group_fwd: filter_width %d (only 2 is built)", K);
+  if (R != 32 && R != 64) return set_error(SRWN_E_UNSUPPORTED, "residual_group_fwd: dilation_channels %d (built: 32, 64)", R);
+  if (nlayers < 0 || nlayers > kMaxGroup || B < 0 || T < 0 || seg_rows < 0)
+    return set_error(SRWN_E_SHAPE, "residual_group_fwd: nlayers=%d (max %d) B=%d T=%d", nlayers, kMaxGroup, B, T);
+  if (layer_stride < (int64_t)B * T * R) return set_error(SRWN_E_SHAPE, "residual_group_fwd: layer_stride %lld", (long long)layer_stride);
+  GroupFwdArgs a;
+  a.x0 = x0; a.x_out = x_out; a.z_out = z_out; a.layer_stride = layer_stride;
+  bool any_cond = false;
+  for (int g = 0; g < kMaxGroup; ++g) {
+    const bool in = g < nlayers;
+    a.wconv[g] = in ? wconv[g] : nullptr; a.wres[g] = in ? wres[g] : nullptr;
+    a.bias_f[g] = in ? bias_f[g] : nullptr; a.bias_r[g] = in ? bias_r[g] : nullptr;
+    a.cond[g] = (in && cond_next) ? cond_next[g] : nullptr;
+    a.sub[g] = 1;
+    if (in && (!a.wconv[g] || !a.wres[g] || !a.bias_f[g] || !a.bias_r[g]))
+      return set_error(SRWN_E_NULL, "residual_group_fwd: layer %d: null weights", g);
+    any_cond = any_cond || a.cond[g] != nullptr;
+  }
+  if (any_cond && (pool_stride < 1 || cond_row_stride < R || cond_row_stride % 8 || (int64_t)cond_frames * pool_stride < T))
+    return set_error(SRWN_E_SHAPE, "residual_group_fwd: cond frames %d x pool %d < T %d", cond_frames, pool_stride, T);
+  a.cond_frames = cond_frames; a.pool = pool_stride > 0 ? pool_stride : 1; a.cond_stride = cond_row_stride;
+  a.nl = nlayers; a.Tlen = T; a.B = B;
+  if (group_geometry(dilations, nlayers, &a.st, a.sub, &a.H) != 0)
+    return set_error(SRWN_E_SHAPE, "residual_group_fwd: dilations must be >= 1");
+  if (a.H > 63) return set_error(SRWN_E_UNSUPPORTED, "residual_group_fwd: halo %d > 63 (sum of dilations / their gcd)", a.H);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SRWN_BF16) {
+    if (R == 32) return launch_group_fwd<bf16_t, 1, 3, 2>(a, any_cond, seg_rows, st);
+    return launch_group_fwd<bf16_t, 2, 3, 2>(a, any_cond, seg_rows, st);
+  } else if (dtype == SRWN_F32) {
+    if (R == 32) return launch_group_fwd<float, 1, 1, 1>(a, any_cond, seg_rows, st);
+    return launch_group_fwd<float, 2, 1, 1>(a, any_cond, seg_rows, st);
+  }
+  return set_error(SRWN_E_DTYPE, "residual_group_fwd: dtype %d", dtype);
+}
+
+// how the layers of a stack are grouped for the fused kernels: greedy runs whose halo stays <= max_halo and whose
+// length stays <= max_layers; writes the first layer of each group to starts[] (size >= nlayers + 1, terminated by
+// nlayers) and returns the number of groups.
+extern "C" int32_t srwn_group_plan(const int32_t* dilations, int32_t nlayers, int32_t max_halo, int32_t max_layers,
+                                   int32_t* starts) {
+  if (!dilations || !starts || nlayers < 0) return 0;
+  if (max_layers < 1) max_layers = 1;
+  if (max_layers > kMaxGroup) max_layers = kMaxGroup;
+  auto gcd = [](int x, int y) { while (y) { int t = x % y; x = y; y = t; } return x; };
+  int n = 0, l = 0;
+  while (l < nlayers) {
+    starts[n++] = l;
+    int st = dilations[l] > 0 ? dilations[l] : 1, len = 1;
+    while (l + len < nlayers && len < max_layers) {
+      const int dn = dilations[l + len] > 0 ? dilations[l + len] : 1;
+      const int st2 = gcd(st, dn);
+      int H = 0;
+      for (int i = 0; i <= len; ++i) H += (dilations[l + i] > 0 ? dilations[l + i] : 1) / st2;
+      if (H > max_halo) break;
+      st = st2;
+      ++len;
+    }
+    l += len;
+  }
+  starts[n] = nlayers;
+  return n;
+}

@@ -102,6 +102,11 @@ class WaveNetEngine:
         self.spans: Dict[str, list] = {}
         import os as _os
         self.overlap = _os.environ.get("SRWN_OVERLAP", "1") != "0"
+        # multi-layer kernels (csrc/srwn_group.hip): SRWN_FUSE=0 keeps one launch per layer (the parity twin)
+        fuse = _os.environ.get("SRWN_FUSE", "1")
+        self.fuse_fwd = fuse not in ("0", "bwd")
+        self.fuse_bwd = fuse not in ("0", "fwd")
+        self.seg_rows = int(_os.environ.get("SRWN_SEG_ROWS", "0"))
         self.side = None
         if torch.cuda.is_available() and self.overlap:
             # weight-gradient passes are throughput work: lowest priority, so the latency-critical dgrad
@@ -119,6 +124,7 @@ class WaveNetEngine:
         self.frames = self.T // cfg.pool_stride if self.E else 0
         self.dev = torch.device(device)
         self.dt = cfg.dtype
+        self.groups = K.group_plan(self.dil, 31, int(_os.environ.get("SRWN_GROUP_LAYERS", "8")))
         self.pg = process_group
         self.world = dp.world_size(process_group)
         if share_from is None:
@@ -433,8 +439,16 @@ class WaveNetEngine:
         if self.E:
             self._cond_bias_to_input()
         with _Span(self, "fwd_layers"):
-            for l in range(L):
-                self._layer_fwd(l, self.cond_all if self.E else None)   # layer l reads columns [l*R, (l+1)*R)
+            cond_all = self.cond_all if self.E else None
+            if self.fuse_fwd:
+                for l0, l1 in self.groups:      # runs of layers whose outputs travel between layers in LDS
+                    if l1 - l0 >= 2:
+                        self._group_fwd(l0, l1, cond_all)
+                    else:
+                        self._layer_fwd(l0, cond_all)
+            else:
+                for l in range(L):
+                    self._layer_fwd(l, cond_all)   # layer l reads columns [l*R, (l+1)*R)
         K.reduce_partials(v("BS").reshape(-1), L, S, 1, True, 1.0, self.bs_sum.data_ptr(), 0)
         with _Span(self, "skip_sum"):
             K.pw_linear(self.zs.data_ptr(), R, N * R, R, L * R, self.wptr(self.o_skip), self.bs_sum, self.r0, S, S,
@@ -489,6 +503,20 @@ class WaveNetEngine:
                     self.view("BC").reshape(-1), self.cond_all, L * R, L * R, self.B * self.frames)
         call("srwn_add_frame_bias", self.xs[0].data_ptr(), self.cond_all.data_ptr(), L * R, self.B, self.T, R,
              self.frames, self.cfg.pool_stride, K.abi_dtype(self.dt), torch.cuda.current_stream().cuda_stream)
+
+    def _group_fwd(self, l0: int, l1: int, cond_all: Optional[torch.Tensor]):
+        """Layers [l0, l1) in one launch (srwn_residual_group_fwd); same stored xs / zs as the per-layer path."""
+        v = self.view
+        offs, cond3 = None, None
+        if cond_all is not None:
+            cond3 = cond_all.view(self.B, self.frames, self.L * self.R)
+            offs = [(l + 1) * self.R if l + 1 < self.L else None for l in range(l0, l1)]
+        K.residual_group_fwd(self.xs[l0], self.xs[l0 + 1:l1 + 1], self.zs[l0:l1],
+                             [self.wptr(self.o_conv[l]) for l in range(l0, l1)],
+                             [self.wptr(self.o_res[l]) for l in range(l0, l1)],
+                             [v("BF")[l] for l in range(l0, l1)], [v("BR")[l] for l in range(l0, l1)],
+                             self.dil[l0:l1], self.Kw, cond=cond3, cond_channel_offsets=offs,
+                             pool_stride=self.cfg.pool_stride, seg_rows=self.seg_rows)
 
     def _layer_fwd(self, l: int, cond_all: Optional[torch.Tensor]):
         v = self.view

@@ -169,6 +169,56 @@ def residual_layer_fwd(x: torch.Tensor, cond: Optional[torch.Tensor], wconv_ptr:
          frames, int(pool_stride), int(cstride), dt, _stream())
 
 
+def group_plan(dilations, max_halo: int = 31, max_layers: int = 8):
+    """Cuts a dilation list into runs the multi-layer kernels take: [(first, end), ...]."""
+    import ctypes as C
+    n = len(dilations)
+    d = (C.c_int32 * max(n, 1))(*[int(v) for v in dilations])
+    starts = (C.c_int32 * (n + 1))()
+    k = _lib.load().srwn_group_plan(d, n, int(max_halo), int(max_layers), starts)
+    return [(int(starts[i]), int(starts[i + 1])) for i in range(k)]
+
+
+def _ptr_array(ptrs):
+    import ctypes as C
+    return (C.c_void_p * len(ptrs))(*[None if p is None else int(p) for p in ptrs])
+
+
+def residual_group_fwd(x0: torch.Tensor, x_out: torch.Tensor, z_out: torch.Tensor, wconv_ptrs, wres_ptrs,
+                       biases_f, biases_r, dilations, K: int = 2, cond: Optional[torch.Tensor] = None,
+                       cond_channel_offsets=None, pool_stride: int = 1, seg_rows: int = 0):
+    """x_out / z_out: [n,B,T,R] stacks (views of the engine's xs[l0+1:], zs[l0:]); cond: [B, frames, C] whose channels
+    [cond_channel_offsets[g], +R) hold the bias of the layer above layer g (None entries: no add)."""
+    import ctypes as C
+    B, T, R = x0.shape
+    n = len(dilations)
+    if not (len(wconv_ptrs) == len(wres_ptrs) == len(biases_f) == len(biases_r) == n):
+        raise ValueError("residual_group_fwd: per-layer argument lists differ in length")
+    px = _chk(x0, "x0")
+    dt = abi_dtype(x0.dtype)
+    for name, t in (("x_out", x_out), ("z_out", z_out)):
+        _chk(t, name, x0.dtype)
+        if t.dim() != 4 or t.shape[0] < n or tuple(t.shape[1:]) != (B, T, R):
+            raise ValueError("%s: shape %s, expected [>=%d,%d,%d,%d]" % (name, tuple(t.shape), n, B, T, R))
+    pbf = [_chk(b, "bias_f", torch.float32, (R,)) for b in biases_f]
+    pbr = [_chk(b, "bias_r", torch.float32, (R,)) for b in biases_r]
+    frames, cstride, pcs = 1, R, None
+    if cond is not None:
+        _chk(cond, "cond", x0.dtype)
+        frames, cstride = cond.shape[1], cond.shape[2]
+        if cond.dim() != 3 or cond.shape[0] != B or frames * pool_stride < T:
+            raise ValueError("cond: shape %s for B=%d T=%d pool=%d" % (tuple(cond.shape), B, T, pool_stride))
+        offs = list(cond_channel_offsets)
+        for o in offs:
+            if o is not None and (o < 0 or o + R > cstride):
+                raise ValueError("cond channel offset %r outside %d channels" % (o, cstride))
+        pcs = _ptr_array([None if o is None else cond.data_ptr() + o * cond.element_size() for o in offs])
+    dl = (C.c_int32 * n)(*[int(d) for d in dilations])
+    call("srwn_residual_group_fwd", px, x_out.data_ptr(), z_out.data_ptr(), B * T * R, _ptr_array(wconv_ptrs),
+         _ptr_array(wres_ptrs), _ptr_array(pbf), _ptr_array(pbr), pcs, frames, int(pool_stride), int(cstride), dl, n,
+         B, T, R, int(K), int(seg_rows), dt, _stream())
+
+
 # ----------------------------------------------------------------------------------------------
 # pointwise linear and the fused softmax head
 # ----------------------------------------------------------------------------------------------
