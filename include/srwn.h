@@ -110,6 +110,18 @@ int srwn_residual_group_fwd(const void* x0, void* x_out, void* z_out, int64_t la
                             const float* const* bias_r, const void* const* cond_next, int32_t cond_frames,
                             int32_t pool_stride, int32_t cond_row_stride, const int32_t* dilations, int32_t nlayers,
                             int32_t B, int32_t T, int32_t R, int32_t K, int32_t seg_rows, int32_t dtype, void* stream);
+/* the backward chain of such a group (autodiff of the same lines; TF builds it in AdamOptimizer.minimize, model.py:31),
+ * top layer first, in one launch: for g = nlayers-1 .. 0
+ *   df_g = (Wr_g . (G_{g+1} sqrt(.5)) + dcs_g) * d(z sigmoid z)/df (z_g)        -> df_out + g*layer_stride
+ *   G_g  = G_{g+1} sqrt(.5) + sum_k Wf_g[k] . df_g[t + (K-1-k)*dilations[g]]     -> g_out  + g*layer_stride
+ * with G_{nlayers} = g_top (NULL = 0: the teacher's last dense output is unused, model.py:45-50) and dcs = Ws . dtotal
+ * of every layer from srwn_skip_dgrad_all (NULL for the flows of ParallelWaveNet, model.py:440-449: no skip path).
+ * Same values as nlayers + 1 calls of srwn_residual_layer_bwd (identical in fp32; in bf16 the gradient handed from
+ * layer to layer is the stored, rounded one).  wconvT / wresT: HOST arrays of nlayers device pointers. */
+int srwn_residual_group_bwd(const void* g_top, void* g_out, void* df_out, const void* z, const void* dcs,
+                            int64_t layer_stride, const void* const* wconvT, const void* const* wresT,
+                            const int32_t* dilations, int32_t nlayers, int32_t B, int32_t T, int32_t R, int32_t K,
+                            int32_t seg_rows, int32_t dtype, void* stream);
 /* greedy cut of a stack's dilation list (model.py:9, teacher.py:57) into such groups: starts[0..n] (starts[n] = nlayers),
  * returns n.  `starts` needs nlayers + 1 entries. */
 int32_t srwn_group_plan(const int32_t* dilations, int32_t nlayers, int32_t max_halo, int32_t max_layers,

@@ -32,12 +32,32 @@ template <> struct Raw4g<bf16_t> {
   typedef bf16x4 type;
   static __device__ __forceinline__ type load(const bf16_t* p) { return *reinterpret_cast<const bf16x4*>(p); }
   static __device__ __forceinline__ float get(const type& v, int e) { return (float)v[e]; }
+  static __device__ __forceinline__ type zero() { return type{(bf16_t)0.0f, (bf16_t)0.0f, (bf16_t)0.0f, (bf16_t)0.0f}; }
+  static __device__ __forceinline__ type pack(float a, float b, float c, float d) {
+    return type{(bf16_t)a, (bf16_t)b, (bf16_t)c, (bf16_t)d};
+  }
 };
 template <> struct Raw4g<float> {
   typedef f32x4 type;
   static __device__ __forceinline__ type load(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
   static __device__ __forceinline__ float get(const type& v, int e) { return v[e]; }
+  static __device__ __forceinline__ type zero() { return type{0.f, 0.f, 0.f, 0.f}; }
+  static __device__ __forceinline__ type pack(float a, float b, float c, float d) { return type{a, b, c, d}; }
 };
+
+// LDS-DMA the compiler does not see (a visible one makes it answer every later wait with vmcnt(0)); retired by
+// dma_wait() before the barrier that publishes the buffer.  M0 (LDS base of the DMA) is saved and restored.
+__device__ __forceinline__ void glds16_untracked(const void* g, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(g), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// a lane-linear byte image (packed MFMA fragments) global -> LDS, 1 KiB per wave-instruction, 8 waves
+__device__ __forceinline__ void dma_image(const void* gsrc, unsigned lds_dst, int nbytes, int wave, int lane) {
+  const char* g = reinterpret_cast<const char*>(gsrc) + lane * 16;
+  for (int p = wave; p < nbytes / 1024; p += 8) glds16_untracked(g + (size_t)p * 1024, __builtin_amdgcn_readfirstlane(lds_dst + p * 1024));
+}
 
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -67,7 +87,6 @@ __global__ __launch_bounds__(512) void group_fwd_kernel(GroupFwdArgs a) {
   constexpr int LPR = R / VEC, RPI = 64 / LPR, NI = 32 / RPI;             // whole-row access: lanes per row, rows per instr
   constexpr int WBYTES = NW * 64 * (int)sizeof(Frag<T>);
   constexpr int WPIECES = WBYTES / 16, CPIECES = NCONV * 64 * (int)sizeof(Frag<T>) / 16;
-  constexpr int WPT = (WPIECES + 511) / 512;                              // 16-byte weight pieces per thread
   typedef typename Raw4g<T>::type raw4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   Frag<T>* wbuf = reinterpret_cast<Frag<T>*>(smem);                       // [NWB][NW*64]
@@ -78,29 +97,26 @@ __global__ __launch_bounds__(512) void group_fwd_kernel(GroupFwdArgs a) {
   const int col = lane & 31, half = lane >> 5;
   const int rsub = lane / LPR, piece = lane % LPR;
 
-  f32x4 wreg[WPT];
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   f32x4 breg;
-  auto wload = [&](int g) {       // layer g's [conv | res] images and biases: global -> registers
-    const f32x4* pc = reinterpret_cast<const f32x4*>(a.wconv[g]);
-    const f32x4* pr = reinterpret_cast<const f32x4*>(a.wres[g]);
-#pragma unroll
-    for (int v = 0; v < WPT; ++v) {
-      int p = tid + v * 512;
-      p = p < WPIECES ? p : WPIECES - 1;
-      wreg[v] = p < CPIECES ? pc[p] : pr[p - CPIECES];
-    }
+  auto wload = [&](int g, int buf) {   // layer g's [conv | res] images -> weight buffer `buf` by LDS-DMA; biases -> registers
+    dma_image(a.wconv[g], lds_base + buf * WBYTES, CPIECES * 16, wave, lane);
+    dma_image(a.wres[g], lds_base + buf * WBYTES + CPIECES * 16, (WPIECES - CPIECES) * 16, wave, lane);
     if (tid < 2 * R / 4) {
       const int c = 4 * tid;
       breg = c < R ? *reinterpret_cast<const f32x4*>(a.bias_f[g] + c) : *reinterpret_cast<const f32x4*>(a.bias_r[g] + c - R);
     }
   };
-  auto wstore = [&](int buf) {    // registers -> weight buffer `buf`
-    f32x4* dst = reinterpret_cast<f32x4*>(smem + (size_t)buf * WBYTES);
-#pragma unroll
-    for (int v = 0; v < WPT; ++v) {
-      const int p = tid + v * 512;
-      if (p < WPIECES) dst[p] = wreg[v];
-    }
+  // retire the DMA, park the biases.  `younger` = tiles whose 2*NI row stores this wave has issued SINCE the DMA:
+  // vmcnt counts in issue order, so leaving that many operations outstanding retires the DMA without waiting for
+  // the stores to be acknowledged.
+  auto wstore = [&](int buf, int younger) {
+    constexpr int STP = 2 * NI;
+    static_assert(MAXT <= 3 && 3 * STP < 64, "vmcnt immediates");
+    if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STP) : "memory");
+    else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * STP) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * STP) : "memory");
     if (tid < 2 * R / 4) *reinterpret_cast<f32x4*>(bbuf + buf * 2 * R + 4 * tid) = breg;
   };
 
@@ -127,7 +143,7 @@ __global__ __launch_bounds__(512) void group_fwd_kernel(GroupFwdArgs a) {
     };
 
     // ---- segment image + the first layer's weights
-    wload(0);
+    wload(0, 0);
     {
       const T* x0 = reinterpret_cast<const T*>(a.x0);
       const int nrows = a.NT * 32;
@@ -148,13 +164,23 @@ __global__ __launch_bounds__(512) void group_fwd_kernel(GroupFwdArgs a) {
         }
       }
     }
-    wstore(0);
+    wstore(0, 0);
     wg_barrier();
+    int nstored = 0;                 // owned tiles that store rows (wave-uniform)
+#pragma unroll
+    for (int m = 0; m < MAXT; ++m) {
+      const int q = wave + 8 * m;
+      int lo = a.H - 32 * q;
+      lo = lo < 0 ? 0 : lo;
+      int hi = a.H + Wseg - 32 * q;
+      hi = hi > 32 ? 32 : hi;
+      if (q < a.NT && hi > lo) ++nstored;
+    }
 
     for (int g = 0; g < a.nl; ++g) {
       const int d = a.sub[g];
       const int wb = (NWB == 2) ? (g & 1) : 0;
-      if (NWB == 1 && g > 0) wload(g);
+      if (NWB == 1 && g > 0) wload(g, 0);
       // ---- tap (t - d) fragments of every owned tile, before anyone overwrites the rows they come from
       Frag<T> tap0[MAXT][KS];
 #pragma unroll
@@ -167,10 +193,10 @@ __global__ __launch_bounds__(512) void group_fwd_kernel(GroupFwdArgs a) {
           for (int ks = 0; ks < KS; ++ks) tap0[m][ks] = load_nat(img + (size_t)src * LS + 16 * ks + 8 * half);
         }
       }
-      if (NWB == 1 && g > 0) wstore(0);
+      if (NWB == 1 && g > 0) wstore(0, 0);
       wg_barrier();
       const bool more = g + 1 < a.nl;
-      if (NWB == 2 && more) wload(g + 1);
+      if (NWB == 2 && more) wload(g + 1, wb ^ 1);
 
       const Frag<T>* lds_conv = wbuf + (size_t)wb * NW * 64;
       const Frag<T>* lds_res = lds_conv + NCONV * 64;
@@ -303,9 +329,281 @@ __global__ __launch_bounds__(512) void group_fwd_kernel(GroupFwdArgs a) {
           }
         }
       }
-      if (NWB == 2 && more) wstore(wb ^ 1);
+      if (NWB == 2 && more) wstore(wb ^ 1, nstored);
       wg_barrier();
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward chain of a group (autodiff of ops.py:23-46 through the stacking loops), top layer first.  Same segments as
+// the forward kernel with the halo on the ANTI-causal side: layer g's input gradient needs df_g at t + sub_g.
+//   df_g  = (Wr_g . (G_{g+1} sqrt(.5)) + dcs_g) * d(z sigmoid z)/df (z_g)              -> df_out[g]
+//   G_g   = G_{g+1} sqrt(.5) + sum_k Wf_g[k] . df_g[t + (K-1-k) sub_g]                 -> g_out[g]
+// G_{g+1} stays in registers between layers (fp32: exactly what layer_bwd_kernel chains from its UP half into its DOWN
+// half); df_g travels through the LDS image for the shifted tap.  z and dcs arrive as whole rows one tile ahead and are
+// redistributed through the tile's own image rows; df and G leave the same way.  Per layer: 256 B/row read + 256 B/row
+// written (bf16, R = 64) against 768+ for one launch per layer.
+// ------------------------------------------------------------------------------------------
+struct GroupBwdArgs {
+  const void* g_top;              // gradient wrt the group's top output [B,T,R], or null (= 0: top of the teacher stack)
+  void* g_out;                    // layer g's input gradient at g_out + g*layer_stride
+  void* df_out;                   // layer g's conv pre-activation gradient at df_out + g*layer_stride
+  const void* z;                  // z of layer g at z + g*layer_stride
+  const void* dcs;                // Ws_g . dtotal of layer g at dcs + g*layer_stride, or null (no skip path)
+  int64_t layer_stride;
+  const void* wconvT[kMaxGroup];  // packed [R/32][K*R/16] natural (rows = in channel), as srwn_residual_layer_bwd takes them
+  const void* wresT[kMaxGroup];   // packed [R/32][R/16] permuted
+  int sub[kMaxGroup];
+  int nl, st, Tlen, B;
+  int W, H, NT, nsub, nseg;
+};
+
+template <typename T, int RT, bool DCS, int MAXT, int NWB>
+__global__ __launch_bounds__(512) void group_bwd_kernel(GroupBwdArgs a) {
+  constexpr int R = 32 * RT, K = 2, KS = R / 16;
+  constexpr int NCONV = RT * K * KS, NRES = RT * KS, NW = NCONV + NRES;
+  constexpr int LS = RowStage<T>::stride(R), VEC = RowStage<T>::VEC;
+  constexpr int LPR = R / VEC, RPI = 64 / LPR, NI = 32 / RPI;
+  constexpr int WBYTES = NW * 64 * (int)sizeof(Frag<T>);
+  constexpr int WPIECES = WBYTES / 16, CPIECES = NCONV * 64 * (int)sizeof(Frag<T>) / 16;
+  typedef typename Raw4g<T>::type raw4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  Frag<T>* wbuf = reinterpret_cast<Frag<T>*>(smem);                       // [NWB][convT | resT]
+  T* img = reinterpret_cast<T*>(smem + (size_t)NWB * WBYTES);             // [NT*32][LS]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 31, half = lane >> 5;
+  const int rsub = lane / LPR, piece = lane % LPR;
+
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  auto wload = [&](int g, int buf) {   // layer g's [convT | resT] images -> weight buffer `buf` by LDS-DMA
+    dma_image(a.wconvT[g], lds_base + buf * WBYTES, CPIECES * 16, wave, lane);
+    dma_image(a.wresT[g], lds_base + buf * WBYTES + CPIECES * 16, (WPIECES - CPIECES) * 16, wave, lane);
+  };
+  const int ntw = (a.NT - wave + 7) / 8;          // tiles this wave owns: q = wave + 8m, m < ntw
+
+  for (int seg = blockIdx.x; seg < a.nseg; seg += gridDim.x) {
+    const int per_clip = a.st * a.nsub;
+    const int b = seg / per_clip;
+    const int rem = seg - b * per_clip;
+    int r, j0;
+    if (a.nsub == 1) { r = rem; j0 = 0; }
+    else { r = rem / a.nsub; j0 = (rem - r * a.nsub) * a.W; }
+    const int Jr = (a.Tlen - r + a.st - 1) / a.st;
+    const int Wseg = (Jr - j0) < a.W ? (Jr - j0) : a.W;
+    const int jbase = j0;                                       // image row 0 = first owned position; halo behind it
+    const size_t clip = (size_t)b * a.Tlen;
+    auto grow = [&](int j) -> size_t {
+      int jj = j < Jr ? j : Jr - 1;
+      jj = jj < 0 ? 0 : jj;
+      size_t t = (size_t)jj * a.st + r;
+      t = t < (size_t)a.Tlen ? t : (size_t)a.Tlen - 1;
+      return clip + t;
+    };
+    // whole rows of one tile: registers <-> the tile's own image rows <-> HBM
+    auto rows_load = [&](const T* base, int q, f32x4 (&v)[NI]) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) v[i] = *reinterpret_cast<const f32x4*>(base + grow(jbase + 32 * q + i * RPI + rsub) * R + piece * VEC);
+    };
+    auto rows_put = [&](T* trow, const f32x4 (&v)[NI]) {
+      wave_lds_order();
+#pragma unroll
+      for (int i = 0; i < NI; ++i) *reinterpret_cast<f32x4*>(trow + (size_t)(i * RPI + rsub) * LS + piece * VEC) = v[i];
+      wave_lds_order();
+    };
+    auto acc_get = [&](const T* trow, raw4 (&o)[RT][4]) {
+#pragma unroll
+      for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) o[mt][gq] = Raw4g<T>::load(trow + (size_t)col * LS + 32 * mt + 8 * gq + 4 * half);
+    };
+    // accumulator-layout values -> own rows -> HBM rows [0, hi) of the tile (hi >= 1)
+    auto tile_store = [&](T* trow, T* gbase, int q, int hi, const float (&vals)[RT][16]) {
+      wave_lds_order();
+#pragma unroll
+      for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+          store4(trow + (size_t)col * LS + 32 * mt + 8 * gq + 4 * half, vals[mt][4 * gq], vals[mt][4 * gq + 1],
+                 vals[mt][4 * gq + 2], vals[mt][4 * gq + 3]);
+      wave_lds_order();
+      if (hi > 0) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          int rr = i * RPI + rsub;
+          rr = rr < hi ? rr : hi - 1;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(trow + (size_t)rr * LS + piece * VEC);
+          *reinterpret_cast<f32x4*>(gbase + grow(jbase + 32 * q + rr) * R + piece * VEC) = v;
+        }
+      }
+    };
+
+    auto tile_store_raw = [&](T* trow, T* gbase, int q, int hi, const raw4 (&vals)[RT][4]) {
+      wave_lds_order();
+#pragma unroll
+      for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+          *reinterpret_cast<raw4*>(trow + (size_t)col * LS + 32 * mt + 8 * gq + 4 * half) = vals[mt][gq];
+      wave_lds_order();
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        int rr = i * RPI + rsub;
+        rr = rr < hi ? rr : hi - 1;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(trow + (size_t)rr * LS + piece * VEC);
+        *reinterpret_cast<f32x4*>(gbase + grow(jbase + 32 * q + rr) * R + piece * VEC) = v;
+      }
+    };
+
+    // ---- G of the group's top output (registers, accumulator layout), the top layer's weights
+    // (kept in the storage type: what one launch per layer would read back from HBM; in fp32 mode that is exact)
+    raw4 G[MAXT][RT][4];
+    const int gtop = a.nl - 1;
+    wload(gtop, 0);
+#pragma unroll
+    for (int m = 0; m < MAXT; ++m) {
+      const int q = wave + 8 * m;
+#pragma unroll
+      for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) G[m][mt][gq] = Raw4g<T>::zero();
+      if (q < a.NT && a.g_top) {
+        T* trow = img + (size_t)(32 * q) * LS;
+        f32x4 v[NI];
+        rows_load(reinterpret_cast<const T*>(a.g_top), q, v);
+        rows_put(trow, v);
+        acc_get(trow, G[m]);
+      }
+    }
+    dma_wait();
+    // operands of the first tile of the top layer (one tile ahead from here on)
+    f32x4 zr[NI], dr[NI];
+    auto issue = [&](int g, int q) {
+      rows_load(reinterpret_cast<const T*>(a.z) + (size_t)g * a.layer_stride, q, zr);
+      if (DCS) rows_load(reinterpret_cast<const T*>(a.dcs) + (size_t)g * a.layer_stride, q, dr);
+    };
+    issue(gtop, wave < a.NT ? wave : a.NT - 1);
+    wg_barrier();
+
+    for (int n = 0; n < a.nl; ++n) {
+      const int g = a.nl - 1 - n;
+      const int d = a.sub[g];
+      int wb = 0;
+      if (NWB == 2) {
+        wb = n & 1;
+        if (g > 0) wload(g - 1, wb ^ 1);
+      } else if (n > 0) {
+        wload(g, 0); dma_wait(); wg_barrier();
+      }
+      const Frag<T>* lds_conv = wbuf + (size_t)wb * NW * 64;
+      const Frag<T>* lds_res = lds_conv + NCONV * 64;
+      T* dfg = reinterpret_cast<T*>(a.df_out) + (size_t)g * a.layer_stride;
+      T* gprev = reinterpret_cast<T*>(a.g_out) + (size_t)(g + 1) * a.layer_stride;   // where G_{g+1} goes (n > 0)
+      const bool haveg = (n > 0) || (a.g_top != nullptr);
+
+      // ---- phase A: df of every owned tile
+#pragma unroll
+      for (int m = 0; m < MAXT; ++m) {
+        const int q = wave + 8 * m;
+        if (q >= a.NT) continue;
+        T* trow = img + (size_t)(32 * q) * LS;
+        const bool ok = (jbase + 32 * q + col) < Jr;
+        int hi = Wseg - 32 * q;
+        hi = hi > 32 ? 32 : hi;
+        if (n > 0 && hi > 0) tile_store_raw(trow, gprev, q, hi, G[m]);   // G_{g+1}: complete since the last barrier
+        raw4 zz[RT][4], dc0[RT][4];
+        rows_put(trow, zr);
+        acc_get(trow, zz);
+        if (DCS) { rows_put(trow, dr); acc_get(trow, dc0); }
+        {   // next operands: the wave's next tile of this layer, or its first tile of the layer below
+          const bool same = (m + 1 < MAXT) && (q + 8 < a.NT);
+          if (same) issue(g, q + 8);
+          else if (g > 0) issue(g - 1, wave < a.NT ? wave : a.NT - 1);
+        }
+        f32x16 accC[RT];
+#pragma unroll
+        for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) accC[mt][4 * gq + e] = (DCS && ok) ? Raw4g<T>::get(dc0[mt][gq], e) : 0.0f;
+        if (haveg) {
+#pragma unroll
+          for (int s = 0; s < KS; ++s) {
+            Frag<T> bfr;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj)
+              bfr.set(jj, (ok ? Raw4g<T>::get(G[m][s >> 1][2 * (s & 1) + (jj >> 2)], jj & 3) : 0.0f) * kSqrtHalf);
+#pragma unroll
+            for (int mt = 0; mt < RT; ++mt) mma(accC[mt], lds_res[(mt * KS + s) * 64 + lane], bfr);
+          }
+        }
+        float dv[RT][16];
+#pragma unroll
+        for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              dv[mt][4 * gq + e] = accC[mt][4 * gq + e] * dgate_df<T>(Raw4g<T>::get(zz[mt][gq], e));
+        tile_store(trow, dfg, q, hi, dv);
+        __builtin_amdgcn_sched_barrier(0);   // keep the tile bodies apart: interleaving them only lengthens live ranges
+      }
+      wg_barrier();
+
+      // ---- phase B: G_g = G_{g+1} sqrt(.5) + taps of df_g
+#pragma unroll
+      for (int m = 0; m < MAXT; ++m) {
+        const int q = wave + 8 * m;
+        if (q >= a.NT) continue;
+        const int i0 = 32 * q + col;
+        const int j = jbase + i0;
+        const bool ok = j < Jr;
+        const bool ok_d = (j + d) < Jr;                 // the shifted tap stays inside the clip (zero beyond it)
+        int src = i0 + d;
+        src = src < a.NT * 32 ? src : a.NT * 32 - 1;
+        f32x16 accG[RT];
+#pragma unroll
+        for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            accG[mt][e] = (haveg && ok) ? Raw4g<T>::get(G[m][mt][e >> 2], e & 3) * kSqrtHalf : 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const Frag<T> f0 = load_nat(img + (size_t)src * LS + 16 * ks + 8 * half);
+          const Frag<T> bfr = ok_d ? f0 : zero_frag<T>();
+#pragma unroll
+          for (int mt = 0; mt < RT; ++mt) mma(accG[mt], lds_conv[(mt * (K * KS) + ks) * 64 + lane], bfr);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const Frag<T> f1 = load_nat(img + (size_t)i0 * LS + 16 * ks + 8 * half);
+          const Frag<T> bfr = ok ? f1 : zero_frag<T>();
+#pragma unroll
+          for (int mt = 0; mt < RT; ++mt) mma(accG[mt], lds_conv[(mt * (K * KS) + KS + ks) * 64 + lane], bfr);
+        }
+#pragma unroll
+        for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq)
+            G[m][mt][gq] = Raw4g<T>::pack(accG[mt][4 * gq], accG[mt][4 * gq + 1], accG[mt][4 * gq + 2], accG[mt][4 * gq + 3]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (NWB == 2 && g > 0) dma_wait();
+      wg_barrier();
+    }
+    // ---- the group's bottom gradient
+#pragma unroll
+    for (int m = 0; m < MAXT; ++m) {
+      const int q = wave + 8 * m;
+      if (q >= a.NT) continue;
+      int hi = Wseg - 32 * q;
+      hi = hi > 32 ? 32 : hi;
+      if (hi <= 0) continue;
+      tile_store_raw(img + (size_t)(32 * q) * LS, reinterpret_cast<T*>(a.g_out), q, hi, G[m]);
+    }
+    wg_barrier();
   }
 }
 
@@ -388,7 +686,71 @@ int launch_group_fwd(GroupFwdArgs& a, bool cond, int seg_rows, hipStream_t st) {
 #undef SRWN_GF
 }
 
+template <typename T, int RT, int MAXT, int NWB>
+int launch_group_bwd(GroupBwdArgs& a, int seg_rows, hipStream_t st) {
+  constexpr int R = 32 * RT, KS = R / 16, NW = RT * 2 * KS + RT * KS;
+  const size_t fixed = (size_t)NWB * NW * 64 * sizeof(Frag<T>);
+  const size_t row_bytes = (size_t)RowStage<T>::stride(R) * sizeof(T);
+  int nt_max = (int)((kLdsBudget - fixed) / (32 * row_bytes));
+  if (nt_max > 8 * MAXT) nt_max = 8 * MAXT;
+  if (nt_max * 32 - a.H < 32) return set_error(SRWN_E_UNSUPPORTED, "residual_group_bwd: halo %d too large", a.H);
+  const int J = (a.Tlen + a.st - 1) / a.st;
+  choose_segments(J, a.H, a.B, a.st, nt_max, seg_rows, &a.W, &a.NT, &a.nsub);
+  const long long nseg = (long long)a.B * a.st * a.nsub;
+  if (nseg > 0x7fffffffLL) return set_error(SRWN_E_SHAPE, "residual_group_bwd: too many segments");
+  a.nseg = (int)nseg;
+  const size_t sh = fixed + (size_t)a.NT * 32 * row_bytes;
+  long long blocks = nseg < num_cus() ? nseg : num_cus();
+  dim3 grid((unsigned)blocks), block(512);
+#define SRWN_GB(D)                                                                                              \
+  {                                                                                                             \
+    auto kfn = group_bwd_kernel<T, RT, D, MAXT, NWB>;                                                           \
+    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);  \
+    if (e != hipSuccess) return set_error((int)e, "residual_group_bwd: LDS %zu: %s", sh, hipGetErrorString(e)); \
+    hipLaunchKernelGGL(kfn, grid, block, sh, st, a);                                                            \
+    return check_launch("residual_group_bwd");                                                                  \
+  }
+  if (a.dcs) SRWN_GB(true) else SRWN_GB(false)
+#undef SRWN_GB
+}
+
 }  // namespace
+
+extern "C" int srwn_residual_group_bwd(const void* g_top, void* g_out, void* df_out, const void* z, const void* dcs,
+                                       int64_t layer_stride, const void* const* wconvT, const void* const* wresT,
+                                       const int32_t* dilations, int32_t nlayers, int32_t B, int32_t T, int32_t R,
+                                       int32_t K, int32_t seg_rows, int32_t dtype, void* stream) {
+  if (B == 0 || T == 0 || nlayers == 0) return 0;
+  if (!g_out || !df_out || !z || !wconvT || !wresT || !dilations)
+    return set_error(SRWN_E_NULL, "residual_group_bwd: null pointer");
+  if (K != 2) return set_error(SRWN_E_UNSUPPORTED, "residual_group_bwd: filter_width %d (only 2 is built)", K);
+  if (R != 32 && R != 64) return set_error(SRWN_E_UNSUPPORTED, "residual_group_bwd: dilation_channels %d (built: 32, 64)", R);
+  if (nlayers < 0 || nlayers > kMaxGroup || B < 0 || T < 0 || seg_rows < 0)
+    return set_error(SRWN_E_SHAPE, "residual_group_bwd: nlayers=%d (max %d) B=%d T=%d", nlayers, kMaxGroup, B, T);
+  if (layer_stride < (int64_t)B * T * R) return set_error(SRWN_E_SHAPE, "residual_group_bwd: layer_stride %lld", (long long)layer_stride);
+  if (!g_top && !dcs) return set_error(SRWN_E_SHAPE, "residual_group_bwd: no top gradient and no skip path: every gradient would be zero");
+  GroupBwdArgs a;
+  a.g_top = g_top; a.g_out = g_out; a.df_out = df_out; a.z = z; a.dcs = dcs; a.layer_stride = layer_stride;
+  for (int g = 0; g < kMaxGroup; ++g) {
+    const bool in = g < nlayers;
+    a.wconvT[g] = in ? wconvT[g] : nullptr; a.wresT[g] = in ? wresT[g] : nullptr;
+    a.sub[g] = 1;
+    if (in && (!a.wconvT[g] || !a.wresT[g])) return set_error(SRWN_E_NULL, "residual_group_bwd: layer %d: null weights", g);
+  }
+  a.nl = nlayers; a.Tlen = T; a.B = B;
+  if (group_geometry(dilations, nlayers, &a.st, a.sub, &a.H) != 0)
+    return set_error(SRWN_E_SHAPE, "residual_group_bwd: dilations must be >= 1");
+  if (a.H > 63) return set_error(SRWN_E_UNSUPPORTED, "residual_group_bwd: halo %d > 63 (sum of dilations / their gcd)", a.H);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SRWN_BF16) {
+    if (R == 32) return launch_group_bwd<bf16_t, 1, 3, 2>(a, seg_rows, st);
+    return launch_group_bwd<bf16_t, 2, 3, 2>(a, seg_rows, st);
+  } else if (dtype == SRWN_F32) {
+    if (R == 32) return launch_group_bwd<float, 1, 1, 1>(a, seg_rows, st);
+    return launch_group_bwd<float, 2, 1, 1>(a, seg_rows, st);
+  }
+  return set_error(SRWN_E_DTYPE, "residual_group_bwd: dtype %d", dtype);
+}
 
 extern "C" int srwn_residual_group_fwd(const void* x0, void* x_out, void* z_out, int64_t layer_stride,
                                        const void* const* wconv, const void* const* wres,

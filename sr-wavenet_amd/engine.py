@@ -439,16 +439,7 @@ class WaveNetEngine:
         if self.E:
             self._cond_bias_to_input()
         with _Span(self, "fwd_layers"):
-            cond_all = self.cond_all if self.E else None
-            if self.fuse_fwd:
-                for l0, l1 in self.groups:      # runs of layers whose outputs travel between layers in LDS
-                    if l1 - l0 >= 2:
-                        self._group_fwd(l0, l1, cond_all)
-                    else:
-                        self._layer_fwd(l0, cond_all)
-            else:
-                for l in range(L):
-                    self._layer_fwd(l, cond_all)   # layer l reads columns [l*R, (l+1)*R)
+            self._stack_fwd(self.cond_all if self.E else None)
         K.reduce_partials(v("BS").reshape(-1), L, S, 1, True, 1.0, self.bs_sum.data_ptr(), 0)
         with _Span(self, "skip_sum"):
             K.pw_linear(self.zs.data_ptr(), R, N * R, R, L * R, self.wptr(self.o_skip), self.bs_sum, self.r0, S, S,
@@ -503,6 +494,18 @@ class WaveNetEngine:
                     self.view("BC").reshape(-1), self.cond_all, L * R, L * R, self.B * self.frames)
         call("srwn_add_frame_bias", self.xs[0].data_ptr(), self.cond_all.data_ptr(), L * R, self.B, self.T, R,
              self.frames, self.cfg.pool_stride, K.abi_dtype(self.dt), torch.cuda.current_stream().cuda_stream)
+
+    def _stack_fwd(self, cond_all: Optional[torch.Tensor]):
+        """The residual layers (model.py:42-47 / 176-189 / 428-453): xs[0] -> xs[1..L], zs[0..L-1]."""
+        if self.fuse_fwd:
+            for l0, l1 in self.groups:      # runs of layers whose outputs travel between layers in LDS
+                if l1 - l0 >= 2:
+                    self._group_fwd(l0, l1, cond_all)
+                else:
+                    self._layer_fwd(l0, cond_all)
+        else:
+            for l in range(self.L):
+                self._layer_fwd(l, cond_all)   # layer l reads columns [l*R, (l+1)*R)
 
     def _group_fwd(self, l0: int, l1: int, cond_all: Optional[torch.Tensor]):
         """Layers [l0, l1) in one launch (srwn_residual_group_fwd); same stored xs / zs as the per-layer path."""
@@ -559,6 +562,34 @@ class WaveNetEngine:
         l_hi = self.split_layer - 1 if part == 2 else L - 1
         l_lo = self.split_layer if part == 1 else 0
         span = _Span(self, "bwd_layers" if part == 0 else "bwd_layers_part%d" % part).__enter__()
+        if self.fused_bwd:
+            # one launch per group of layers (srwn_residual_group_bwd), top group first; each group's weight-gradient
+            # pass follows it on the side stream.  The bottom group writes gs[0]: no UP-only launch below layer 0.
+            for l0, l1 in reversed(self.groups):
+                if l0 > l_hi or l0 < l_lo:
+                    continue
+                self._group_bwd(l0, l1)
+                if not self.timing:
+                    if overlap:
+                        ev = torch.cuda.Event()
+                        ev.record(main)
+                        side.wait_event(ev)
+                    with torch.cuda.stream(side):
+                        self._wgrad_layers_group(l0, l1)
+            span.__exit__()
+            if part == 1:
+                if overlap:
+                    main.wait_stream(side)
+                return
+            if self.timing:
+                for g in groups:
+                    self._wgrad_layers_group(*g)
+            with torch.cuda.stream(side):
+                self._wgrad_layers_finish()
+            self._wgrad_input_and_cond()
+            if overlap and join:
+                main.wait_stream(side)
+            return
         for l in range(l_hi, l_lo - 1, -1):
             has_up = l < L - 1
             g_in = self.gs[l + 2] if (has_up and l + 2 < L) else None
@@ -598,8 +629,25 @@ class WaveNetEngine:
         if self.side is not None and self.overlap and not self.timing:
             torch.cuda.current_stream().wait_stream(self.side)
 
+    @property
+    def fused_bwd(self) -> bool:
+        """The data-gradient chain runs as one launch per layer group (needs the precomputed skip gradients `dcs`, or a
+        stack without a skip path)."""
+        return self.fuse_bwd and self.use_wl and (getattr(self, "use_dcs", False) or self.cfg.head_mode == "flow")
+
+    def _group_bwd(self, l0: int, l1: int):
+        flow = self.cfg.head_mode == "flow"
+        g_top = self.gs[l1] if (flow or l1 < self.L) else None    # the teacher's last dense output is unused: G_L = 0
+        K.residual_group_bwd(g_top, self.gs[l0:l1], self.dfs[l0:l1], self.zs[l0:l1],
+                             None if flow else self.dcs[l0:l1],
+                             [self.wptr(self.o_convT[l]) for l in range(l0, l1)],
+                             [self.wptr(self.o_resT[l]) for l in range(l0, l1)], self.dil[l0:l1], self.Kw,
+                             seg_rows=self.seg_rows)
+
     def _wl_groups(self):
         import os as _os
+        if self.fused_bwd:
+            return list(self.groups)
         per = int(_os.environ.get("SRWN_WL_GROUP", "6"))
         return [(l0, min(l0 + per, self.L)) for l0 in range(0, self.L, per)]
 

@@ -219,6 +219,26 @@ def residual_group_fwd(x0: torch.Tensor, x_out: torch.Tensor, z_out: torch.Tenso
          B, T, R, int(K), int(seg_rows), dt, _stream())
 
 
+def residual_group_bwd(g_top: Optional[torch.Tensor], g_out: torch.Tensor, df_out: torch.Tensor, z: torch.Tensor,
+                       dcs: Optional[torch.Tensor], wconvT_ptrs, wresT_ptrs, dilations, K: int = 2, seg_rows: int = 0):
+    """g_out / df_out / z / dcs: [n,B,T,R] stacks (views of the engine's gs[l0:], dfs[l0:], zs[l0:], dcs[l0:])."""
+    import ctypes as C
+    n = len(dilations)
+    _, B, T, R = z.shape
+    if not (len(wconvT_ptrs) == len(wresT_ptrs) == n):
+        raise ValueError("residual_group_bwd: per-layer argument lists differ in length")
+    dt = abi_dtype(z.dtype)
+    for name, t in (("g_out", g_out), ("df_out", df_out), ("z", z)) + ((("dcs", dcs),) if dcs is not None else ()):
+        _chk(t, name, z.dtype)
+        if t.dim() != 4 or t.shape[0] < n or tuple(t.shape[1:]) != (B, T, R):
+            raise ValueError("%s: shape %s, expected [>=%d,%d,%d,%d]" % (name, tuple(t.shape), n, B, T, R))
+    pg = _opt(g_top, "g_top", z.dtype, (B, T, R))
+    dl = (C.c_int32 * n)(*[int(d) for d in dilations])
+    call("srwn_residual_group_bwd", pg, g_out.data_ptr(), df_out.data_ptr(), z.data_ptr(),
+         None if dcs is None else dcs.data_ptr(), B * T * R, _ptr_array(wconvT_ptrs), _ptr_array(wresT_ptrs), dl, n, B, T,
+         R, int(K), int(seg_rows), dt, _stream())
+
+
 # ----------------------------------------------------------------------------------------------
 # pointwise linear and the fused softmax head
 # ----------------------------------------------------------------------------------------------

@@ -183,8 +183,7 @@ class FlowStack(WaveNetEngine):
         K.causal_conv1d_fwd(x.view(B, T, 1), v("init_w"), v("init_b"), 1, 1, out=self.xs[0])   # model.py:423-424
         self._cond_bias_to_input()                                                               # model.py:431-435
         with _Span(self, "flow_fwd_layers"):
-            for l in range(L):
-                self._layer_fwd(l, self.cond_all)
+            self._stack_fwd(self.cond_all)
         K.flow_affine_fwd(self.xs[L].view(N, R), v("flow_w"), v("flow_b"), x.view(N), self.prm, self.x_out,
                           self.ent_parts)                                                       # model.py:451-483
 
@@ -206,7 +205,15 @@ class FlowStack(WaveNetEngine):
         groups = self._wl_groups() if self.use_wl else []
         group_lo = {g[0]: g for g in groups}
         with _Span(self, "flow_bwd_layers"):
-            for l in range(L - 1, -1, -1):
+            for l0, l1 in (reversed(self.groups) if self.fused_bwd else ()):   # one launch per layer group
+                self._group_bwd(l0, l1)
+                if overlap:
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    self._wgrad_layers_group(l0, l1)
+            for l in (() if self.fused_bwd else range(L - 1, -1, -1)):
                 top = l == L - 1
                 K.residual_layer_bwd(None if top else self.gs[l + 2], None if top else self.dfs[l + 1],
                                      None if top else self.wptr(self.o_convT[l + 1]), self.gs[l + 1],
@@ -219,8 +226,9 @@ class FlowStack(WaveNetEngine):
                         side.wait_event(ev)
                     with torch.cuda.stream(side):
                         self._wgrad_layers_group(*group_lo[l])
-            K.residual_layer_bwd(self.gs[1], self.dfs[0], self.wptr(self.o_convT[0]), self.gs[0],
-                                 None, None, None, None, None, B, T, R, 0, Kw, self.dil[0], 1, False, dt)
+            if not self.fused_bwd:
+                K.residual_layer_bwd(self.gs[1], self.dfs[0], self.wptr(self.o_convT[0]), self.gs[0],
+                                     None, None, None, None, None, B, T, R, 0, Kw, self.dil[0], 1, False, dt)
         if overlap:   # gs[0] (and every G_l for the conditioning gradients) is complete
             ev = torch.cuda.Event()
             ev.record(main)

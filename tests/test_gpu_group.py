@@ -81,6 +81,70 @@ def test_group_forward_conditioned(monkeypatch, dt, E, pool):
         assert torch.equal(ref.xs[l + 1], fus.xs[l + 1]), "x of layer %d" % (l + 1)
 
 
+def _rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dil,B,T,R,S,seg", SHAPES)
+def test_group_backward_equals_per_layer(monkeypatch, dt, dil, B, T, R, S, seg):
+    """fp32: the fused chain is the same arithmetic in the same order -> identical bits.  bf16: the gradient handed
+    from layer to layer is the stored (rounded) one, where one launch per layer chains the unrounded tile from its UP
+    half into its DOWN half -> equal to bf16 rounding."""
+    ref, fus = _pair(monkeypatch, dil, B, T, R, S, 64, dt, seg_rows=seg)
+    assert fus.fused_bwd and not ref.fused_bwd
+    for e in (ref, fus):
+        e.forward(); e.backward()
+    torch.cuda.synchronize()
+    L = len(dil)
+    for l in range(L):
+        if dt == torch.float32:
+            assert torch.equal(ref.dfs[l], fus.dfs[l]), "df of layer %d" % l
+            assert torch.equal(ref.gs[l], fus.gs[l]), "G of layer %d" % l
+        else:
+            assert _rel(fus.dfs[l], ref.dfs[l]) < 2e-2, "df of layer %d: %g" % (l, _rel(fus.dfs[l], ref.dfs[l]))
+            assert _rel(fus.gs[l], ref.gs[l]) < 2e-2, "G of layer %d: %g" % (l, _rel(fus.gs[l], ref.gs[l]))
+    gr, gf = ref.named_tensors(ref.grads), fus.named_tensors(fus.grads)
+    for n in gr:
+        if dt == torch.float32:
+            assert torch.equal(gr[n], gf[n]), n
+        else:
+            assert _rel(gf[n], gr[n]) < 3e-2, "%s: %g" % (n, _rel(gf[n], gr[n]))
+
+
+def test_group_backward_vs_oracle_fp32(monkeypatch):
+    """The fused path against the CPU oracle directly (two groups of a 1..128 cycle, ragged length, short segments)."""
+    EG = sub("engine")
+    from tests.test_gpu_kernels import dev, rel_err
+    dil = [1, 2, 4, 8, 16, 32, 64, 128]
+    B, T, R, S, C = 2, 300, 64, 256, 64
+    monkeypatch.setenv("SRWN_FUSE", "1")
+    monkeypatch.setenv("SRWN_SEG_ROWS", "100")
+    sp = O.init_stack_params(5, dil, 2, R, S, C, bias_scale=0.05)
+    rng = np.random.default_rng(5)
+    audio = O.synthetic_audio(B, T, seed=1).astype(np.float64)
+    codes = rng.integers(0, C, (B, T))
+    ref_logits, cache = O.stack_forward(sp, audio, shift_input=True)
+    loss = O.softmax_ce_per_timestep(ref_logits, codes)
+    grads, _ = O.stack_backward(sp, cache, O.dlogits_per_timestep(ref_logits, codes))
+    cfg = EG.StackConfig(dilations=dil, dilation_channels=R, skip_channels=S, output_channels=C, shift_input=True,
+                         dtype=torch.float32)
+    eng = EG.WaveNetEngine(cfg, B, T, DEV)
+    eng.load_oracle_params(sp)
+    assert eng.fused_bwd and eng.fuse_fwd and eng.groups == [(0, 5), (5, 8)]
+    eng.set_inputs(dev(audio), dev(codes, torch.int32))
+    logits = eng.forward(want_logits=True)
+    eng.backward()
+    torch.cuda.synchronize()
+    assert rel_err(logits.cpu().numpy(), ref_logits) < 1e-3
+    assert abs(float(eng.loss.item()) - loss) < 1e-3 * loss
+    named = eng.named_tensors(eng.grads)
+    for n, ref in O.flatten_named(grads, False):
+        g = named[n].cpu().numpy()
+        assert np.abs(g - ref).max() / max(np.abs(ref).max(), 1e-12) < 1e-3, n
+
+
 def test_group_plan():
     Kn = sub("kernels")
     d = [2 ** i for i in range(10)] * 3
