@@ -637,7 +637,10 @@ int group_geometry(const int32_t* dil, int nl, int* st_out, int* sub, int* H_out
 }
 
 // positions per segment and tiles per image for a residue class of J positions
-void choose_segments(int J, int H, int B, int st, int nt_max, int seg_rows, int* W, int* NT, int* nsub) {
+// A residue class that fits one segment needs no halo at all (the positions before / beyond it are the conv's zero
+// padding): *H becomes 0 then, which for T = 16000 turns the 32..512 groups' 17 tiles into 16 = two per wave.
+void choose_segments(int J, int* Hp, int B, int st, int nt_max, int seg_rows, int* W, int* NT, int* nsub) {
+  const int H = *Hp;
   const int wmax = nt_max * 32 - H;
   int w;
   if (seg_rows > 0) {
@@ -655,7 +658,8 @@ void choose_segments(int J, int H, int B, int st, int nt_max, int seg_rows, int*
   if (w < 1) w = 1;
   *W = w;
   *nsub = (J + w - 1) / w;
-  *NT = (H + w + 31) / 32;
+  if (*nsub == 1) *Hp = 0;
+  *NT = (*Hp + w + 31) / 32;
 }
 
 template <typename T, int RT, int MAXT, int NWB>
@@ -667,7 +671,7 @@ int launch_group_fwd(GroupFwdArgs& a, bool cond, int seg_rows, hipStream_t st) {
   if (nt_max > 8 * MAXT) nt_max = 8 * MAXT;
   if (nt_max * 32 - a.H < 32) return set_error(SRWN_E_UNSUPPORTED, "residual_group_fwd: halo %d too large", a.H);
   const int J = (a.Tlen + a.st - 1) / a.st;
-  choose_segments(J, a.H, a.B, a.st, nt_max, seg_rows, &a.W, &a.NT, &a.nsub);
+  choose_segments(J, &a.H, a.B, a.st, nt_max, seg_rows, &a.W, &a.NT, &a.nsub);
   const long long nseg = (long long)a.B * a.st * a.nsub;
   if (nseg > 0x7fffffffLL) return set_error(SRWN_E_SHAPE, "residual_group_fwd: too many segments");
   a.nseg = (int)nseg;
@@ -695,7 +699,7 @@ int launch_group_bwd(GroupBwdArgs& a, int seg_rows, hipStream_t st) {
   if (nt_max > 8 * MAXT) nt_max = 8 * MAXT;
   if (nt_max * 32 - a.H < 32) return set_error(SRWN_E_UNSUPPORTED, "residual_group_bwd: halo %d too large", a.H);
   const int J = (a.Tlen + a.st - 1) / a.st;
-  choose_segments(J, a.H, a.B, a.st, nt_max, seg_rows, &a.W, &a.NT, &a.nsub);
+  choose_segments(J, &a.H, a.B, a.st, nt_max, seg_rows, &a.W, &a.NT, &a.nsub);
   const long long nseg = (long long)a.B * a.st * a.nsub;
   if (nseg > 0x7fffffffLL) return set_error(SRWN_E_SHAPE, "residual_group_bwd: too many segments");
   a.nseg = (int)nseg;
