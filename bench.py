@@ -24,6 +24,9 @@ import numpy as np
 import torch
 
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+# HBM bytes per launch of the dominant kernel, measured with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes):
+# (dtype, B, T, R, S, L) -> (bytes, profile the number was copied from).  Filled in from profiles/ each round.
+PROFILED_TRAFFIC = {}
 PEAK_HBM_GBS = 8000.0        # HBM3E peak (same guide); ~4.9 TB/s is what a plain copy kernel reaches (tools/micro/membench.hip)
 
 
@@ -130,28 +133,58 @@ def main():
     # ---- roofline of the dominant kernel: HIP events on the launch stream, eager launches
     eng.timing = True
     eng.spans.clear()
-    for _ in range(min(args.steps, 5)):
+    npass = max(min(args.steps, 5), 1)
+    for _ in range(npass):
         eng.train_step()
     torch.cuda.synchronize()
     eng.timing = False
-    spans = {k: float(np.mean([s.elapsed_time(e) for s, e in v])) for k, v in eng.spans.items()}   # ms
+    # second timing pass: the same spans with the side-stream overlap of the real schedule left on
+    spans_serial = dict(eng.spans)
+    eng.spans = {}
+    eng.timing_overlap = True
+    for _ in range(npass):
+        eng.train_step()
+    torch.cuda.synchronize()
+    eng.timing_overlap = False
+    spans_ov_raw, eng.spans = dict(eng.spans), spans_serial
+    # median over the timing passes (a mean lets one stray pass -- a first-touch allocation, a late module load --
+    # stand for the kernel: round 1's driver record carried a 25x outlier that way), summed over the launches of a span
+    def _span_ms(v):
+        per_pass = len(v) // npass if len(v) >= npass else 1
+        tot = [sum(s.elapsed_time(e) for s, e in v[i * per_pass:(i + 1) * per_pass]) for i in range(len(v) // per_pass)]
+        return float(np.median(tot))
+    spans = {k: _span_ms(v) for k, v in eng.spans.items()}   # ms per step
+    spans_ov = {k: _span_ms(v) for k, v in spans_ov_raw.items()}
     fl = algorithmic_flops(N, L, R, S, C, Kw)
-    kflops = {"skip_sum": 2.0 * N * L * R * S, "wgrad_skip": 2.0 * N * L * R * S,
-              "fwd_layers": 2.0 * N * L * (Kw * R * R + R * R), "bwd_layers": 2.0 * N * L * (Kw * R * R + R * R + R * S),
-              "head_1x1": 2.0 * N * S * S, "head_softmax_ce": 2.0 * N * S * C, "bwd_head": 2.0 * N * (S * C + S * S)}
-    # Dominant kernel = the fused layer data-gradient kernel (layer_bwd_kernel): 31 launches per step, the largest
-    # share of the step, HBM-bound.  Algorithmic bytes per launch: per sample and layer it reads
-    # G_{l+2}, df_{l+1}, dcs_l, z_l and writes G_{l+1}, df_l = 6 x R x 2 B (bf16) = 768 B.  `traffic` is the PMC
-    # measurement of the same kernel (profiles/r01_l_hbm_traffic.md: FETCH_SIZE x2-corrected + WRITE_SIZE, in 1e6 bytes).
+    kflops = {"skip_sum": 2.0 * N * L * R * S, "wgrad_skip": 2.0 * N * L * R * S}
     es = 2 if args.dtype == "bf16" else 4
     step_ms = 1e3 * dt_s / args.steps
-    bwd_launch_ms = spans["bwd_layers"] / (L + 1)          # L DOWN(+UP) launches + the UP-only launch below layer 0
-    bwd_bytes = 6.0 * R * es * N
-    ach_bw = bwd_bytes / (bwd_launch_ms * 1e-3) / 1e9
-    roofline = {"kernel": "layer_bwd_kernel", "bound": "hbm", "achieved": ach_bw, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                "frac": ach_bw / PEAK_HBM_GBS, "traffic": 105.0e6 if (args.dtype == "bf16" and (B, T, R, S) == (8, 16000, 64, 256)) else None,
-                "bytes_per_launch": bwd_bytes, "launch_us": 1e3 * bwd_launch_ms, "launches_per_step": L + 1,
-                "share_of_step": spans["bwd_layers"] / step_ms,
+    # Dominant kernel by time = the data-gradient chain of the residual stack, HBM-bound.
+    #  fused path (default): group_bwd_kernel, one launch per layer group.  Algorithmic bytes per launch: per sample and
+    #    layer it reads z, dcs and writes df, G (4 x R x es bytes) plus the group's top gradient once (R x es);
+    #  SRWN_FUSE=0: layer_bwd_kernel, one launch per layer: reads G_{l+2}, df_{l+1}, dcs_l, z_l, writes G_{l+1}, df_l.
+    fused = eng.fused_bwd
+    if fused:
+        ngr = len(eng.groups)
+        bwd_bytes_step = sum((4.0 * (l1 - l0) + (1.0 if l1 < L else 0.0)) * R * es * N for l0, l1 in eng.groups)
+        nlaunch, kname = ngr, "group_bwd_kernel"
+        traffic, traffic_src = PROFILED_TRAFFIC.get((args.dtype, B, T, R, S, L), (None, None))
+    else:
+        bwd_bytes_step = 6.0 * R * es * N * (L + 1)
+        nlaunch, kname = L + 1, "layer_bwd_kernel"
+        traffic, traffic_src = (105.0e6, "profiles/r01_l_hbm_traffic.md") if (args.dtype, B, T, R, S, L) == ("bf16", 8, 16000, 64, 256, 30) else (None, None)
+    bwd_launch_ms = spans["bwd_layers"] / nlaunch
+    ach_bw = bwd_bytes_step / nlaunch / (bwd_launch_ms * 1e-3) / 1e9
+    roofline = {"kernel": kname, "bound": "hbm", "achieved": ach_bw, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": ach_bw / PEAK_HBM_GBS,
+                # HBM bytes per launch from the rocprofv3 PMC passes of the same command (FETCH_SIZE x 2 + WRITE_SIZE,
+                # MI355X_MICROARCH.md); copied from the profile named in traffic_source, not measured in this run
+                "traffic": traffic, "traffic_source": traffic_src,
+                "bytes_per_launch": bwd_bytes_step / nlaunch, "launch_us": 1e3 * bwd_launch_ms,
+                # the same launches timed inside the schedule the timed region replays (weight-gradient passes running
+                # beside them on the side stream): what the kernel costs in the step, vs. alone on the chip above
+                "launch_us_in_schedule": 1e3 * spans_ov["bwd_layers"] / nlaunch if "bwd_layers" in spans_ov else None,
+                "launches_per_step": nlaunch, "share_of_step": spans["bwd_layers"] / step_ms,
                 "whole_step_mfma_frac": fl["per_step"] / (dt_s / args.steps) / 1e12 / PEAK_BF16_TFLOPS,
                 "spans_ms": spans}
     # the largest single kernel by FLOPs: the skip sum as one K = L*R contraction (row-streaming MFMA GEMM)
@@ -159,8 +192,9 @@ def main():
     achieved = kflops[dom] / (spans[dom] * 1e-3) / 1e12
     roofline_gemm = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_BF16_TFLOPS,
-                     "traffic": ({"skip_sum": 573.3e6, "wgrad_skip": 632.8e6}[dom]   # profiles/r01_l_hbm_traffic.md
-                                 if (args.dtype == "bf16" and (B, T, R, S, L) == (8, 16000, 64, 256, 30)) else None)}
+                     "traffic": ({"skip_sum": 573.3e6, "wgrad_skip": 632.8e6}[dom]
+                                 if (args.dtype == "bf16" and (B, T, R, S, L) == (8, 16000, 64, 256, 30)) else None),
+                     "traffic_source": "profiles/r01_l_hbm_traffic.md"}
 
     if rank == 0:
         out = {

@@ -122,6 +122,13 @@ int srwn_residual_group_bwd(const void* g_top, void* g_out, void* df_out, const 
                             int64_t layer_stride, const void* const* wconvT, const void* const* wresT,
                             const int32_t* dilations, int32_t nlayers, int32_t B, int32_t T, int32_t R, int32_t K,
                             int32_t seg_rows, int32_t dtype, void* stream);
+/* the same cut chosen for a problem size (B clips of T steps, R channels, dtype): minimises the estimated run time of
+ * the group kernels (tile rounds per layer + a fixed cost per launch) over all cuts into runs of <= max_layers layers. */
+int32_t srwn_group_plan_auto(const int32_t* dilations, int32_t nlayers, int32_t B, int32_t T, int32_t R, int32_t dtype,
+                             int32_t max_layers, int32_t* starts);
+/* diagnostic hook for profiling builds (no reference counterpart): while a device buffer of 1024 uint64 is registered
+ * the bf16 forward group kernel appends in-kernel clock stamps of workgroup 0 to it; NULL restores production code. */
+int srwn_debug_stamp_buffer(void* device_buffer);
 /* greedy cut of a stack's dilation list (model.py:9, teacher.py:57) into such groups: starts[0..n] (starts[n] = nlayers),
  * returns n.  `starts` needs nlayers + 1 entries. */
 int32_t srwn_group_plan(const int32_t* dilations, int32_t nlayers, int32_t max_halo, int32_t max_layers,

@@ -16,7 +16,9 @@
 //   exactly as layer_fwd_kernel does them (same MFMA order: results are bit-identical to the per-layer path) ->
 //   z and the new x go through the tile's own image rows to HBM as whole rows -> barrier.  Weights of layer g+1
 //   stream into the second weight buffer while layer g computes.
+#include <cmath>
 #include <cstdlib>
+#include <vector>
 #include "srwn_common.h"
 #include "srwn_host.h"
 #include "../../include/srwn.h"
@@ -54,9 +56,10 @@ __device__ __forceinline__ void glds16_untracked(const void* g, unsigned lds_add
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // a lane-linear byte image (packed MFMA fragments) global -> LDS, 1 KiB per wave-instruction, 8 waves
-__device__ __forceinline__ void dma_image(const void* gsrc, unsigned lds_dst, int nbytes, int wave, int lane) {
+__device__ __forceinline__ void dma_image(const void* gsrc, unsigned lds_dst, int nbytes, int wave, int lane,
+                                          int nwaves = 8) {
   const char* g = reinterpret_cast<const char*>(gsrc) + lane * 16;
-  for (int p = wave; p < nbytes / 1024; p += 8) glds16_untracked(g + (size_t)p * 1024, __builtin_amdgcn_readfirstlane(lds_dst + p * 1024));
+  for (int p = wave; p < nbytes / 1024; p += nwaves) glds16_untracked(g + (size_t)p * 1024, __builtin_amdgcn_readfirstlane(lds_dst + p * 1024));
 }
 
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -77,10 +80,24 @@ struct GroupFwdArgs {
   int W, H, NT;                   // positions per segment, halo positions, 32-row tiles per segment image
   int nsub;                       // segments per sub-sequence
   int nseg;                       // B * st * nsub
+  unsigned long long* stamps;     // diagnostic builds only (srwn_debug_stamp_buffer): s_memtime stamps of workgroup 0
 };
 
-template <typename T, int RT, bool COND, int MAXT, int NWB>
-__global__ __launch_bounds__(512) void group_fwd_kernel(GroupFwdArgs a) {
+// In-kernel time stamps (MI355X guide, "In-kernel stamps"): lane 0 of waves 0 and 1 of workgroup 0 append the shader
+// clock to a buffer no other code reads.  Compiled in only when a buffer was registered (STAMP instantiation).
+template <bool STAMP> struct Stamper {
+  unsigned long long* p; int n;
+  __device__ __forceinline__ void operator()(int) {}
+};
+template <> struct Stamper<true> {
+  unsigned long long* p; int n;
+  __device__ __forceinline__ void operator()(int tag) {
+    if (p) { p[n] = ((unsigned long long)tag << 48) | (__builtin_amdgcn_s_memtime() & 0xffffffffffffull); ++n; }
+  }
+};
+
+template <typename T, int RT, bool COND, int MAXT, int NWB, int NWV = 8, bool WDMA = true, bool STAMP = false>
+__global__ __launch_bounds__(64 * NWV) void group_fwd_kernel(GroupFwdArgs a) {
   constexpr int R = 32 * RT, K = 2, KS = R / 16;
   constexpr int NCONV = RT * K * KS, NRES = RT * KS, NW = NCONV + NRES;   // weight fragments per layer
   constexpr int LS = RowStage<T>::stride(R), VEC = RowStage<T>::VEC;
@@ -96,12 +113,28 @@ __global__ __launch_bounds__(512) void group_fwd_kernel(GroupFwdArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 31, half = lane >> 5;
   const int rsub = lane / LPR, piece = lane % LPR;
+  Stamper<STAMP> stamp{nullptr, 0};
+  if (STAMP && blockIdx.x == 0 && lane == 0 && wave < 2) stamp.p = a.stamps + wave * 512;
+  stamp(1);
 
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   f32x4 breg;
+  constexpr int WPT = WDMA ? 1 : (WPIECES + 64 * NWV - 1) / (64 * NWV);
+  f32x4 wreg[WPT];
   auto wload = [&](int g, int buf) {   // layer g's [conv | res] images -> weight buffer `buf` by LDS-DMA; biases -> registers
-    dma_image(a.wconv[g], lds_base + buf * WBYTES, CPIECES * 16, wave, lane);
-    dma_image(a.wres[g], lds_base + buf * WBYTES + CPIECES * 16, (WPIECES - CPIECES) * 16, wave, lane);
+    if (WDMA) {
+      dma_image(a.wconv[g], lds_base + buf * WBYTES, CPIECES * 16, wave, lane, NWV);
+      dma_image(a.wres[g], lds_base + buf * WBYTES + CPIECES * 16, (WPIECES - CPIECES) * 16, wave, lane, NWV);
+    } else {   // through registers: the compiler tracks these loads itself
+      const f32x4* pc = reinterpret_cast<const f32x4*>(a.wconv[g]);
+      const f32x4* pr = reinterpret_cast<const f32x4*>(a.wres[g]);
+#pragma unroll
+      for (int v = 0; v < WPT; ++v) {
+        int p = tid + v * 64 * NWV;
+        p = p < WPIECES ? p : WPIECES - 1;
+        wreg[v] = p < CPIECES ? pc[p] : pr[p - CPIECES];
+      }
+    }
     if (tid < 2 * R / 4) {
       const int c = 4 * tid;
       breg = c < R ? *reinterpret_cast<const f32x4*>(a.bias_f[g] + c) : *reinterpret_cast<const f32x4*>(a.bias_r[g] + c - R);
@@ -113,7 +146,14 @@ __global__ __launch_bounds__(512) void group_fwd_kernel(GroupFwdArgs a) {
   auto wstore = [&](int buf, int younger) {
     constexpr int STP = 2 * NI;
     static_assert(MAXT <= 3 && 3 * STP < 64, "vmcnt immediates");
-    if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!WDMA) {
+      f32x4* dst = reinterpret_cast<f32x4*>(smem + (size_t)buf * WBYTES);
+#pragma unroll
+      for (int v = 0; v < WPT; ++v) {
+        const int p = tid + v * 64 * NWV;
+        if (p < WPIECES) dst[p] = wreg[v];
+      }
+    } else if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STP) : "memory");
     else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * STP) : "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * STP) : "memory");
@@ -147,8 +187,8 @@ __global__ __launch_bounds__(512) void group_fwd_kernel(GroupFwdArgs a) {
     {
       const T* x0 = reinterpret_cast<const T*>(a.x0);
       const int nrows = a.NT * 32;
-      constexpr int RPP = 512 / LPR;            // rows per pass of the whole workgroup
-      constexpr int UN = 4;
+      constexpr int RPP = 64 * NWV / LPR;            // rows per pass of the whole workgroup
+      constexpr int UN = (MAXT * NWV * 32 + RPP - 1) / RPP;   // the whole image in one batch of loads: one HBM round trip
       for (int i0 = 0; i0 < nrows; i0 += RPP * UN) {
         f32x4 v[UN];
 #pragma unroll
@@ -165,11 +205,13 @@ __global__ __launch_bounds__(512) void group_fwd_kernel(GroupFwdArgs a) {
       }
     }
     wstore(0, 0);
+    stamp(2);
     wg_barrier();
+    stamp(3);
     int nstored = 0;                 // owned tiles that store rows (wave-uniform)
 #pragma unroll
     for (int m = 0; m < MAXT; ++m) {
-      const int q = wave + 8 * m;
+      const int q = wave + NWV * m;
       int lo = a.H - 32 * q;
       lo = lo < 0 ? 0 : lo;
       int hi = a.H + Wseg - 32 * q;
@@ -185,7 +227,7 @@ __global__ __launch_bounds__(512) void group_fwd_kernel(GroupFwdArgs a) {
       Frag<T> tap0[MAXT][KS];
 #pragma unroll
       for (int m = 0; m < MAXT; ++m) {
-        const int q = wave + 8 * m;
+        const int q = wave + NWV * m;
         if (q < a.NT) {
           int src = 32 * q + col - d;
           src = src < 0 ? 0 : src;
@@ -194,7 +236,9 @@ __global__ __launch_bounds__(512) void group_fwd_kernel(GroupFwdArgs a) {
         }
       }
       if (NWB == 1 && g > 0) wstore(0, 0);
+      stamp(10);
       wg_barrier();
+      stamp(11);
       const bool more = g + 1 < a.nl;
       if (NWB == 2 && more) wload(g + 1, wb ^ 1);
 
@@ -207,7 +251,7 @@ __global__ __launch_bounds__(512) void group_fwd_kernel(GroupFwdArgs a) {
 
 #pragma unroll
       for (int m = 0; m < MAXT; ++m) {
-        const int q = wave + 8 * m;
+        const int q = wave + NWV * m;
         if (q >= a.NT) continue;
         T* trow = img + (size_t)(32 * q) * LS;           // the tile's own rows
         const int j = jbase + 32 * q + col;              // this lane's position
@@ -248,6 +292,7 @@ __global__ __launch_bounds__(512) void group_fwd_kernel(GroupFwdArgs a) {
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
           for (int mt = 0; mt < RT; ++mt) mma(accF[mt], lds_conv[(mt * (K * KS) + KS + ks) * 64 + lane], cur1[ks]);
+        if (STAMP) { asm volatile("" :: "v"(accF[0][0])); stamp(12); }
 
         // ---- tanh, gate; z leaves through the tile's own rows
         Frag<T> cf[KS];
@@ -261,6 +306,7 @@ __global__ __launch_bounds__(512) void group_fwd_kernel(GroupFwdArgs a) {
               zz[mt][qq] = z;
               cf[2 * mt + (qq >> 3)].set(qq & 7, gate_of_z<T>(z));
             }
+          if (STAMP) { asm volatile("" :: "v"(zz[0][0])); stamp(13); }
           if (st_ok) {
             wave_lds_order();             // the reads of the own rows above are done
 #pragma unroll
@@ -279,6 +325,7 @@ __global__ __launch_bounds__(512) void group_fwd_kernel(GroupFwdArgs a) {
             }
           }
         }
+        stamp(14);
         // ---- 1x1 residual from registers, scaled residual add
         f32x16 accR[RT];
 #pragma unroll
@@ -293,6 +340,7 @@ __global__ __launch_bounds__(512) void group_fwd_kernel(GroupFwdArgs a) {
         for (int s = 0; s < KS; ++s)
 #pragma unroll
           for (int mt = 0; mt < RT; ++mt) mma(accR[mt], lds_res[(mt * KS + s) * 64 + lane], cf[s]);
+        if (STAMP) { asm volatile("" :: "v"(accR[0][0])); stamp(15); }
         {
           float hv[RT][16];
           const T* crow_ = nullptr;
@@ -328,9 +376,12 @@ __global__ __launch_bounds__(512) void group_fwd_kernel(GroupFwdArgs a) {
             }
           }
         }
+        stamp(16);
       }
       if (NWB == 2 && more) wstore(wb ^ 1, nstored);
+      stamp(17);
       wg_barrier();
+      stamp(18);
     }
   }
 }
@@ -607,6 +658,7 @@ __global__ __launch_bounds__(512) void group_bwd_kernel(GroupBwdArgs a) {
   }
 }
 
+unsigned long long* g_stamps = nullptr;
 int g_cus = 0;
 int num_cus() {
   if (g_cus == 0) {
@@ -662,13 +714,13 @@ void choose_segments(int J, int* Hp, int B, int st, int nt_max, int seg_rows, in
   *NT = (*Hp + w + 31) / 32;
 }
 
-template <typename T, int RT, int MAXT, int NWB>
+template <typename T, int RT, int MAXT, int NWB, int NWV = 8, bool WDMA = true, bool STAMP = false>
 int launch_group_fwd(GroupFwdArgs& a, bool cond, int seg_rows, hipStream_t st) {
   constexpr int R = 32 * RT, KS = R / 16, NW = RT * 2 * KS + RT * KS;
   const size_t fixed = (size_t)NWB * NW * 64 * sizeof(Frag<T>) + (size_t)NWB * 2 * R * 4;
   const size_t row_bytes = (size_t)RowStage<T>::stride(R) * sizeof(T);
   int nt_max = (int)((kLdsBudget - fixed) / (32 * row_bytes));
-  if (nt_max > 8 * MAXT) nt_max = 8 * MAXT;
+  if (nt_max > NWV * MAXT) nt_max = NWV * MAXT;
   if (nt_max * 32 - a.H < 32) return set_error(SRWN_E_UNSUPPORTED, "residual_group_fwd: halo %d too large", a.H);
   const int J = (a.Tlen + a.st - 1) / a.st;
   choose_segments(J, &a.H, a.B, a.st, nt_max, seg_rows, &a.W, &a.NT, &a.nsub);
@@ -677,10 +729,10 @@ int launch_group_fwd(GroupFwdArgs& a, bool cond, int seg_rows, hipStream_t st) {
   a.nseg = (int)nseg;
   const size_t sh = fixed + (size_t)a.NT * 32 * row_bytes;
   long long blocks = nseg < num_cus() ? nseg : num_cus();
-  dim3 grid((unsigned)blocks), block(512);
+  dim3 grid((unsigned)blocks), block(64 * NWV);
 #define SRWN_GF(C)                                                                                              \
   {                                                                                                             \
-    auto kfn = group_fwd_kernel<T, RT, C, MAXT, NWB>;                                                           \
+    auto kfn = group_fwd_kernel<T, RT, C, MAXT, NWB, NWV, WDMA, STAMP>;                                                           \
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);  \
     if (e != hipSuccess) return set_error((int)e, "residual_group_fwd: LDS %zu: %s", sh, hipGetErrorString(e)); \
     hipLaunchKernelGGL(kfn, grid, block, sh, st, a);                                                            \
@@ -787,13 +839,18 @@ extern "C" int srwn_residual_group_fwd(const void* x0, void* x_out, void* z_out,
   if (any_cond && (pool_stride < 1 || cond_row_stride < R || cond_row_stride % 8 || (int64_t)cond_frames * pool_stride < T))
     return set_error(SRWN_E_SHAPE, "residual_group_fwd: cond frames %d x pool %d < T %d", cond_frames, pool_stride, T);
   a.cond_frames = cond_frames; a.pool = pool_stride > 0 ? pool_stride : 1; a.cond_stride = cond_row_stride;
-  a.nl = nlayers; a.Tlen = T; a.B = B;
+  a.nl = nlayers; a.Tlen = T; a.B = B; a.stamps = nullptr;
   if (group_geometry(dilations, nlayers, &a.st, a.sub, &a.H) != 0)
     return set_error(SRWN_E_SHAPE, "residual_group_fwd: dilations must be >= 1");
   if (a.H > 63) return set_error(SRWN_E_UNSUPPORTED, "residual_group_fwd: halo %d > 63 (sum of dilations / their gcd)", a.H);
   hipStream_t st = (hipStream_t)stream;
+  static const int waves16 = [] { const char* e = getenv("SRWN_GF_WAVES"); return e && atoi(e) == 16; }();
   if (dtype == SRWN_BF16) {
     if (R == 32) return launch_group_fwd<bf16_t, 1, 3, 2>(a, any_cond, seg_rows, st);
+    if (waves16) return launch_group_fwd<bf16_t, 2, 2, 2, 16>(a, any_cond, seg_rows, st);
+    if (g_stamps) { a.stamps = g_stamps; return launch_group_fwd<bf16_t, 2, 3, 2, 8, true, true>(a, any_cond, seg_rows, st); }
+    static const int wdma = [] { const char* e = getenv("SRWN_GF_WDMA"); return e ? atoi(e) : 1; }();
+    if (!wdma) return launch_group_fwd<bf16_t, 2, 3, 2, 8, false>(a, any_cond, seg_rows, st);
     return launch_group_fwd<bf16_t, 2, 3, 2>(a, any_cond, seg_rows, st);
   } else if (dtype == SRWN_F32) {
     if (R == 32) return launch_group_fwd<float, 1, 1, 1>(a, any_cond, seg_rows, st);
@@ -826,6 +883,58 @@ extern "C" int32_t srwn_group_plan(const int32_t* dilations, int32_t nlayers, in
     }
     l += len;
   }
+  starts[n] = nlayers;
+  return n;
+}
+
+// Diagnostic hook (no reference counterpart): registers a device buffer of 1024 uint64; while one is registered, the
+// bf16 R = 64 forward group kernel runs in its stamped instantiation and workgroup 0 appends (tag << 48 | shader clock)
+// at its phase boundaries (tools/stamp_probe.py).  Pass NULL to return to the production instantiation.
+extern "C" int srwn_debug_stamp_buffer(void* device_buffer) {
+  g_stamps = reinterpret_cast<unsigned long long*>(device_buffer);
+  return 0;
+}
+
+// Cost-based cut of a stack into groups for a given problem size: minimises  sum over groups of
+//   ceil(segments / CUs) * (fixed + layers * ceil(tiles per segment / 8))
+// (8 waves per workgroup take one 32-step tile each per round; `fixed` = launch + segment prologue in tile-rounds), with
+// the segment geometry the launchers will choose.  For 8 x 16000 steps and 3 x [1..512] it prefers {1,2,4} {8,16}
+// {32..512} (16 tiles = two full rounds per layer everywhere) to {1..16} {32..512} (17 tiles = three rounds).
+extern "C" int32_t srwn_group_plan_auto(const int32_t* dilations, int32_t nlayers, int32_t B, int32_t T, int32_t R,
+                                        int32_t dtype, int32_t max_layers, int32_t* starts) {
+  if (!dilations || !starts || nlayers < 0) return 0;
+  if (nlayers == 0) { starts[0] = 0; return 0; }
+  if (max_layers < 1) max_layers = 1;
+  if (max_layers > kMaxGroup) max_layers = kMaxGroup;
+  const int rt = R / 32, ks = R / 16, nw = rt * 2 * ks + rt * ks;
+  const size_t esz = dtype == SRWN_F32 ? 4 : 2, frag = 8 * esz * 64;
+  const int nwb = dtype == SRWN_F32 ? 1 : 2, maxt = dtype == SRWN_F32 ? 1 : 3;
+  const size_t row_bytes = (size_t)(R + 16 / esz) * esz;
+  int nt_max = (int)((kLdsBudget - (size_t)nwb * nw * frag - (size_t)nwb * 2 * R * 4) / (32 * row_bytes));
+  if (nt_max > 8 * maxt) nt_max = 8 * maxt;
+  const double fixed = 1.5;
+  std::vector<double> best(nlayers + 1, 1e300);
+  std::vector<int> prev(nlayers + 1, -1);
+  best[0] = 0.0;
+  for (int l = 0; l < nlayers; ++l) {
+    if (best[l] >= 1e300) continue;
+    for (int len = 1; len <= max_layers && l + len <= nlayers; ++len) {
+      int st = 0, H = 0, sub[kMaxGroup];
+      if (group_geometry(dilations + l, len, &st, sub, &H) != 0) break;
+      if (H > 63 || nt_max * 32 - H < 32) break;
+      int W, NT, nsub;
+      const int J = (T + st - 1) / st;
+      choose_segments(J, &H, B, st, nt_max, 0, &W, &NT, &nsub);
+      const double nseg = (double)B * st * nsub;
+      const double passes = std::ceil(nseg / num_cus());
+      const double c = passes * (fixed + len * std::ceil(NT / 8.0));
+      if (best[l] + c < best[l + len]) { best[l + len] = best[l] + c; prev[l + len] = l; }
+    }
+  }
+  std::vector<int> cuts;
+  for (int l = nlayers; l > 0; l = prev[l]) cuts.push_back(prev[l]);
+  int n = 0;
+  for (int i = (int)cuts.size() - 1; i >= 0; --i) starts[n++] = cuts[i];
   starts[n] = nlayers;
   return n;
 }

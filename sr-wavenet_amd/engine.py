@@ -67,13 +67,13 @@ class _Span:
         self.eng, self.name = eng, name
 
     def __enter__(self):
-        if self.eng.timing:
+        if self.eng.timing or self.eng.timing_overlap:
             self.s = torch.cuda.Event(enable_timing=True)
             self.s.record()
         return self
 
     def __exit__(self, *exc):
-        if self.eng.timing:
+        if self.eng.timing or self.eng.timing_overlap:
             e = torch.cuda.Event(enable_timing=True)
             e.record()
             self.eng.spans.setdefault(self.name, []).append((self.s, e))
@@ -98,7 +98,8 @@ class WaveNetEngine:
         if cfg.cond_channels and (length % cfg.pool_stride):
             raise ValueError("length %d is not a multiple of pool_stride %d" % (length, cfg.pool_stride))
         self.cfg = cfg
-        self.timing = False
+        self.timing = False           # HIP-event spans with every launch alone on the chip (no side stream)
+        self.timing_overlap = False   # the same spans inside the real schedule (side-stream work left running)
         self.spans: Dict[str, list] = {}
         import os as _os
         self.overlap = _os.environ.get("SRWN_OVERLAP", "1") != "0"
@@ -124,7 +125,14 @@ class WaveNetEngine:
         self.frames = self.T // cfg.pool_stride if self.E else 0
         self.dev = torch.device(device)
         self.dt = cfg.dtype
-        self.groups = K.group_plan(self.dil, 31, int(_os.environ.get("SRWN_GROUP_LAYERS", "8")))
+        gl = int(_os.environ.get("SRWN_GROUP_LAYERS", "8"))
+        # longest runs with a halo of at most one tile.  (SRWN_GROUP_PLAN=auto: the cost-model cut of
+        # srwn_group_plan_auto -- measured slower on the benchmark shape: every extra launch costs ~14 us of launch,
+        # segment prologue and store drain, more than the fuller tile rounds of shorter groups give back.)
+        if _os.environ.get("SRWN_GROUP_PLAN", "greedy") == "auto" and self.R in (32, 64):
+            self.groups = K.group_plan_auto(self.dil, self.B, self.T, self.R, self.dt, gl)
+        else:
+            self.groups = K.group_plan(self.dil, 31, gl)
         self.pg = process_group
         self.world = dp.world_size(process_group)
         if share_from is None:

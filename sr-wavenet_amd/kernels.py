@@ -179,6 +179,16 @@ def group_plan(dilations, max_halo: int = 31, max_layers: int = 8):
     return [(int(starts[i]), int(starts[i + 1])) for i in range(k)]
 
 
+def group_plan_auto(dilations, B: int, T: int, R: int, dtype: torch.dtype, max_layers: int = 8):
+    """The cut that minimises the estimated time of the group kernels for this problem size."""
+    import ctypes as C
+    n = len(dilations)
+    d = (C.c_int32 * max(n, 1))(*[int(v) for v in dilations])
+    starts = (C.c_int32 * (n + 1))()
+    k = _lib.load().srwn_group_plan_auto(d, n, int(B), int(T), int(R), abi_dtype(dtype), int(max_layers), starts)
+    return [(int(starts[i]), int(starts[i + 1])) for i in range(k)]
+
+
 def _ptr_array(ptrs):
     import ctypes as C
     return (C.c_void_p * len(ptrs))(*[None if p is None else int(p) for p in ptrs])

