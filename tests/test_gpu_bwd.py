@@ -17,7 +17,8 @@ def _gate_grad(z):
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("R,S", [(64, 256), (32, 64), (32, 128)])
-@pytest.mark.parametrize("B,T,d_up", [(2, 64, 1), (1, 100, 8), (2, 300, 64), (1, 50, 128), (3, 1000, 16)])
+@pytest.mark.parametrize("B,T,d_up", [(2, 64, 1), (1, 100, 8), (2, 300, 64), (1, 50, 128), (3, 1000, 16),
+                                      (1, 1100, 256), (1, 2100, 512), (2, 700, 512)])   # the benchmark's upper dilations
 def test_residual_layer_bwd(dt, R, S, B, T, d_up):
     K = sub("kernels"); P = sub("packing")
     rng = np.random.default_rng(R + T + d_up)
@@ -214,12 +215,13 @@ def test_wgrad256(dt, mode, rows):
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("with_cond", [False, True])
 @pytest.mark.parametrize("R", [64, 32])
-def test_wgrad_layers_fused(dt, with_cond, R):
-    """conv taps + 1x1 residual gradients of several layers in one pass (srwn_wgrad_layers)."""
+@pytest.mark.parametrize("T,dil", [(352, [1, 16, 300]), (1120, [256, 512, 1]), (640, [512, 2, 700])])
+def test_wgrad_layers_fused(dt, with_cond, R, T, dil):
+    """conv taps + 1x1 residual gradients of several layers in one pass (srwn_wgrad_layers); dilations up to the
+    benchmark's 512, and one beyond the clip (every delayed tap zero)."""
     K = sub("kernels")
-    L, B, T, pool = 3, 2, 352, 32
+    L, B, pool = 3, 2, 32
     rows = B * T
-    dil = [1, 16, 300]
     rng = np.random.default_rng(7)
     x = dev(rng.standard_normal((L, rows, R)), dt); z = dev(np.tanh(rng.standard_normal((L, rows, R))), dt)
     df = dev(rng.standard_normal((L, rows, R)), dt); g = dev(rng.standard_normal((L, rows, R)), dt)

@@ -1,0 +1,167 @@
+"""Oracle parity at the benchmark's DEPTH and dilations, and at the BASELINE configurations' own shapes.
+
+The stack-level tests of test_gpu_engine stop at 9-11 layers and dilations <= 128; the headline configuration runs 30
+layers with dilations up to 512 (clamped-row and tap-out-of-clip paths of the backward and weight-gradient kernels that
+shorter stacks never reach).  The CPU oracle (ii) (oracle/wavenet_torch.py, fp64 autograd) does one 30-layer
+forward + backward of a few thousand samples in about a second, so these are direct comparisons, not properties:
+
+  config 2 depth   3 x [1..512], 64 / 256 / 256, clip longer than the receptive field (3071): logits, loss, every gradient
+  config 1         2 x [1..16], 32 residual channels, 256-way mu-law, 4000-sample clips (teacher.py --train's plumbing case)
+  config 4 shape   4 flows x 30 layers, 10-component mixture-of-logistics teacher, clipped Adam step
+  config 5 shape   30-layer incremental generation across the whole receptive field, batch 32
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import wavenet_np as O
+from oracle import wavenet_torch as OT
+from tests._pkg import sub
+from tests.test_gpu_kernels import DEV, dev, rel_err
+
+pytestmark = pytest.mark.gpu
+
+DIL30 = [1, 2, 4, 8, 16, 32, 64, 128, 256, 512] * 3
+
+
+_ORACLE_CACHE = {}
+
+
+def _oracle_cached(key, sp, audio, codes):
+    if key not in _ORACLE_CACHE:
+        _ORACLE_CACHE[key] = _oracle(sp, audio, codes)
+    return _ORACLE_CACHE[key]
+
+
+def _oracle(sp, audio, codes):
+    st = OT.TorchStack(sp)
+    logits = st.forward(torch.tensor(audio), shift_input=True)
+    loss = OT.loss_per_timestep(logits, torch.tensor(codes))
+    loss.backward()
+    # (the last layer's 1x1 residual is outside the graph -- its dense output is unused, model.py:45-50 -- so autograd
+    # leaves its gradient None: the engine must leave it exactly zero)
+    grads = {n: (np.zeros(tuple(t.shape)) if t.grad is None else t.grad.numpy()) for n, t in st.named(include_cond=False)}
+    return logits.detach().numpy(), float(loss.detach()), grads
+
+
+def _engine(sp, dil, B, T, R, S, C, dt):
+    EG = sub("engine")
+    cfg = EG.StackConfig(dilations=list(dil), dilation_channels=R, skip_channels=S, output_channels=C,
+                         shift_input=True, dtype=dt)
+    eng = EG.WaveNetEngine(cfg, B, T, DEV)
+    eng.load_oracle_params(sp)
+    return eng
+
+
+def _check(eng, logits, loss, grads, dt):
+    lg = eng.forward(want_logits=True).cpu().numpy()
+    eng.backward()
+    torch.cuda.synchronize()
+    got = eng.named_tensors(eng.grads)
+    if dt == torch.float32:     # the north-star tolerance: 1e-3 relative, fp32 mode
+        assert rel_err(lg, logits) < 1e-3
+        assert abs(float(eng.loss.item()) - loss) < 1e-3 * loss
+        for n, ref in grads.items():
+            g = got[n].cpu().numpy()
+            assert np.abs(g - ref).max() < 1e-3 * max(np.abs(ref).max(), 1e-12), n
+    else:                       # bf16 mode (the timed path): every stored activation is rounded to 8 significant bits
+        assert rel_err(lg, logits) < 6e-2
+        assert abs(float(eng.loss.item()) - loss) < 2e-2 * loss
+        for n, ref in grads.items():
+            g = got[n].float().cpu().numpy().ravel().astype(np.float64)
+            r = ref.ravel()
+            if not r.any():
+                assert not g.any(), n
+                continue
+            cos = float(g @ r / (np.linalg.norm(g) * np.linalg.norm(r) + 1e-300))
+            assert cos > 0.99 and abs(np.linalg.norm(g) / np.linalg.norm(r) - 1) < 0.1, (n, cos)
+
+
+@pytest.mark.parametrize("fuse", ["1", "0"])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_config2_depth_and_dilations_vs_oracle(monkeypatch, dt, fuse):
+    """30 layers, 3 x [1..512], 64 residual / 256 skip channels, 256-way softmax; B = 2 clips of 4300 samples (the
+    receptive field is 3071).  Both launch structures: multi-layer kernels (default) and one launch per layer."""
+    monkeypatch.setenv("SRWN_FUSE", fuse)
+    B, T, R, S, C = 2, 4300, 64, 256, 256
+    sp = O.init_stack_params(3, DIL30, 2, R, S, C, bias_scale=0.05)
+    rng = np.random.default_rng(3)
+    audio = O.synthetic_audio(B, T, seed=4).astype(np.float64)
+    codes = O.mu_law_encode(audio.astype(np.float32), C).astype(np.int64)
+    logits, loss, grads = _oracle_cached("config2", sp, audio, codes)
+    eng = _engine(sp, DIL30, B, T, R, S, C, dt)
+    assert eng.fused_bwd == (fuse == "1")
+    eng.set_inputs(dev(audio), dev(codes, torch.int32))
+    _check(eng, logits, loss, grads, dt)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_config1_own_size_vs_oracle(dt):
+    """BASELINE config 1 at its own size: 2 stacks x 5 layers (dilations 1..16), 32 residual channels (teacher.py:61
+    passes skip_channels=128), 8-bit mu-law = 256 classes, 4000-sample clips, batch 4 (teacher.py:42)."""
+    dil = [1, 2, 4, 8, 16] * 2
+    B, T, R, S, C = 4, 4000, 32, 128, 256
+    sp = O.init_stack_params(8, dil, 2, R, S, C, bias_scale=0.05)
+    audio = O.synthetic_audio(B, T, seed=6, sample_rate=4000).astype(np.float64)
+    codes = O.mu_law_encode(audio.astype(np.float32), C).astype(np.int64)
+    logits, loss, grads = _oracle_cached("config1", sp, audio, codes)
+    eng = _engine(sp, dil, B, T, R, S, C, dt)
+    eng.set_inputs(dev(audio), dev(codes, torch.int32))
+    _check(eng, logits, loss, grads, dt)
+
+
+def test_config4_shape_student_vs_oracle():
+    """BASELINE config 4's shape: 4 IAF flows of 30 layers distilled against a frozen 30-layer teacher with a
+    10-component mixture-of-logistics head (student.py:70-73, model.py:290-401), one clip of 4096 samples (the
+    reference's own clip length, teacher.py:43), fp32: output, every loss term, every flow gradient, the global norm."""
+    from tests.test_gpu_student import _oracle_grads, _setup
+    stu, flows, noise, cond, truth, tl, pool, abg = _setup(torch.float32, 64, 256, 4, B=1, T=4096, pool=128, M=10,
+                                                           dil=DIL30)
+    assert len(stu.flows) == 4 and stu.teacher.C == 40 and stu.flows[0].L == 30
+    B, T = noise.shape
+    fw = O.student_forward(flows, noise, cond, pool)
+    ref = O.student_loss(fw, tl, truth, *abg)
+    stu.forward()
+    assert rel_err(stu.teacher.logits32[:, :tl.shape[-1]].cpu().numpy().reshape(tl.shape), tl) < 1e-3
+    assert rel_err(stu.out.cpu().numpy().reshape(B, T), fw["out"]) < 1e-3
+    got = stu.losses()
+    for k in ("entropy", "power_loss", "cross_entropy", "loss"):
+        assert abs(got[k] - ref[k]) < 1e-3 * max(abs(ref[k]), 1.0), (k, got[k], ref[k])
+    res, grads = _oracle_grads(flows, noise, cond, pool, tl, truth, abg)
+    stu.backward()
+    for f, g in zip(stu.flows, grads):
+        mine = f.named_tensors(f.grads)
+        for n, r in g.items():
+            a = mine[n].float().cpu().numpy()
+            assert np.abs(a - r).max() < 1e-3 * (np.abs(r).max() + 1e-30), n
+    flat = [g[n] for g in grads for n in g]
+    _, gn = O.clip_by_global_norm(flat, 1.0)
+    stu.optimizer_step()
+    assert abs(float(stu.clip[1].item()) - gn) < 1e-3 * gn
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-3), (torch.bfloat16, 6e-2)])
+def test_config5_shape_generation_crosses_the_receptive_field(dt, tol):
+    """BASELINE config 5's shape: the 30-layer teacher generated incrementally for 3200 steps (receptive field 3071),
+    32 utterances (one workgroup's worth): teacher-forced incremental logits == the full forward's at every step, and
+    the deepest ring (d = 512) has wrapped six times."""
+    EG = sub("engine")
+    B, T, R, S, C = 32, 3200, 64, 256, 256
+    sp = O.init_stack_params(4, DIL30, 2, R, S, C, bias_scale=0.05)
+    eng = _engine(sp, DIL30, B, T, R, S, C, dt)
+    audio = O.synthetic_audio(B, T, seed=9)
+    codes = O.mu_law_encode(audio, C)
+    eng.set_inputs(dev(audio), dev(codes, torch.int32))
+    full = eng.forward(want_logits=True)
+    a, c, inc = eng.generate(T, mode="argmax", forced=dev(audio), want_logits=True)
+    assert torch.isfinite(inc).all()
+    err = float((inc - full).abs().max() / full.abs().max())
+    assert err < tol, err
+    late = slice(3072, T)          # steps whose receptive field is entirely inside the clip
+    err_late = float((inc[:, late] - full[:, late]).abs().max() / full[:, late].abs().max())
+    assert err_late < tol, err_late
+    if dt == torch.float32:
+        ref = OT.TorchStack(sp, requires_grad=False).forward(torch.tensor(audio[:2].astype(np.float64)), shift_input=True)
+        assert rel_err(inc[:2].cpu().numpy(), ref.numpy()) < tol
+        dec = O.mu_law_decode(c.cpu().numpy(), C)
+        assert np.array_equal(a.cpu().numpy().view(np.uint32), dec.view(np.uint32))

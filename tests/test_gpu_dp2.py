@@ -1,0 +1,77 @@
+"""The engine's data-parallel step with TWO real ranks: two fresh child processes share
+the box's one GPU, the gradient all-reduce goes through gloo, each rank takes half of a fixed global batch.  After one
+eager and two graph-replayed steps both ranks must hold the same parameters, equal to a single process stepping on the
+whole batch: mean losses (model.py:29) average the shard gradients (Adam's 1/world), the mixture-of-logistics SUM loss
+(ops.py:171-172) adds them, the student clips AFTER the mean (model.py:384-385).  Both all-reduce schedules of the
+engine run: one bucket, and two buckets with the first overlapped with the lower backward pass."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from tests._pkg import ROOT
+
+pytestmark = pytest.mark.gpu
+
+WORKER = os.path.join(ROOT, "tests", "dp_worker.py")
+
+
+def _run(mode, world, tmp_path, tag, buckets, port):
+    outs, procs = [], []
+    for r in range(world):
+        out = str(tmp_path / ("%s_%s_w%d_r%d.pt" % (mode, tag, world, r)))
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), SRWN_DIST_BACKEND="gloo", SRWN_BUCKETS=buckets,
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, WORKER, mode, out], env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        outs.append(out)
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o.decode(errors="replace")[-3000:])
+    for p, l in zip(procs, logs):
+        assert p.returncode == 0, l
+    return [torch.load(o, weights_only=True) for o in outs]
+
+
+@pytest.mark.parametrize("mode,buckets", [("softmax", "0"), ("softmax", "1"), ("mol", "1"), ("student", "0")])
+def test_two_ranks_equal_one_process_on_the_global_batch(tmp_path, mode, buckets):
+    port = 29600 + (os.getpid() % 200) + {"softmax": 0, "mol": 1, "student": 2}[mode] * 3 + int(buckets)
+    ref = _run(mode, 1, tmp_path, "ref", "0", port)[0]
+    r0, r1 = _run(mode, 2, tmp_path, "dp" + buckets, buckets, port + 400)
+    assert r0["info"]["world"] == 2 and r1["info"]["world"] == 2
+    if mode != "student":
+        assert r0["info"]["bucketed"] == (buckets == "1"), r0["info"]
+        assert r0["info"]["fused"]
+    assert torch.equal(r0["params"], r1["params"]), "ranks diverged"
+    # the all-reduced gradient buffer of the FIRST step (identical parameters everywhere): SUM over ranks of the shard
+    # gradients.  Mean losses: sum / world is the global-batch gradient; the mixture-of-logistics SUM loss: the sum
+    # itself.  (Adam is invariant to the scale of the gradient, so the parameters alone would not show a wrong 1/world.)
+    g, gref = r0["grads1"].double(), ref["grads1"].double()
+    assert torch.equal(r0["grads1"], r1["grads1"])
+    scale = 1.0 if mode == "mol" else 0.5
+    gerr = float((g * scale - gref).abs().max() / gref.abs().max())
+    assert gerr < 1e-5, gerr
+    # parameters after the first Adam step and after the two graph-replayed ones, where the gradient is not numerically
+    # zero (Adam turns the sign of a ~1e-9 gradient entry into a 1e-3 step, and later steps amplify that)
+    live = gref.abs() > 1e-4 * gref.abs().max()
+    err1 = float((r0["params1"].double() - ref["params1"].double())[live].abs().max())
+    assert err1 < 1e-6, err1
+    p, q = r0["params"].double(), ref["params"].double()
+    err = float((p - q)[live].abs().max())
+    assert err < 3e-4, err
+    # losses: each rank reports its shard's loss; mean losses average to the global one, sum losses add
+    l2 = float(r0["loss"]) + float(r1["loss"])
+    lg = float(ref["loss"])
+    if mode == "mol":
+        assert abs(l2 - lg) < 1e-4 * abs(lg)
+    else:
+        assert abs(l2 / 2 - lg) < 1e-4 * abs(lg)

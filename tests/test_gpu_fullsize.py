@@ -1,5 +1,7 @@
 """BASELINE config 2 at FULL size (30 layers, 64/256 ch, 256-way softmax, batch 8 x 16000) through size-independent
-properties -- the oracle cannot run these shapes in seconds, so parity here is structural:
+properties.  (The direct oracle comparison at this depth and these dilations, on clips longer than the receptive
+field, is tests/test_gpu_depth.py; a full 8 x 16000 batch would take the fp64 CPU oracle about a minute per pass, so
+at the full batch the checks are structural.)
 
   causality          logits before a perturbed sample do not change (bit-exact)
   batch separability the batch-8 gradient is the mean of the two batch-4 half gradients; losses average
