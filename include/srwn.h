@@ -126,6 +126,27 @@ int srwn_residual_group_bwd(const void* g_top, void* g_out, void* df_out, const 
  * the group kernels (tile rounds per layer + a fixed cost per launch) over all cuts into runs of <= max_layers layers. */
 int32_t srwn_group_plan_auto(const int32_t* dilations, int32_t nlayers, int32_t B, int32_t T, int32_t R, int32_t dtype,
                              int32_t max_layers, int32_t* starts);
+/* ---- the remaining free functions of ops.py (none on the timed path; fp32, plain VALU kernels):
+ * log_prob_from_logits (ops.py:111-115) -> y [rows,C] and / or log_sum_exp (ops.py:117-122) -> lse [rows] (either NULL) */
+int srwn_log_softmax(const float* x, float* y, float* lse, int64_t rows, int32_t C, void* stream);
+/* categorical_sample (ops.py:106-109): one index per row drawn from softmax(logits) (tf.multinomial's stream is not
+ * reproducible; this one is counter-based: the same seed gives the same draws) */
+int srwn_categorical_sample(const float* logits, int32_t* out, int64_t rows, int32_t C, uint64_t seed, void* stream);
+/* probs_logistic (ops.py:203-214): sigmoid((y-mu+h)/s) - sigmoid((y-mu-h)/s), h = 1/(num_classes-1),
+ * s = max(scale, exp(log_scale_min)) */
+int srwn_probs_logistic(const float* scale, const float* mu, const float* y, float* out, int64_t n,
+                        int32_t num_classes, float log_scale_min, void* stream);
+/* pieces of ResidualDilationLayer / ResidualDilationLayerNC for shapes outside the fused kernels (any filter_width, any
+ * channel counts; ops.py:232-236 builds an 8-channel layer on a 1-channel input): z = tanh(f), c = z*sigmoid(z)
+ * (ops.py:28,33,36); dense = (inputs + residual)*sqrt(.5) with a 1-channel input broadcast (ops.py:40); relu (ops.py:49,52) */
+int srwn_tanh_gate(const float* f, float* z, float* c, int64_t n, void* stream);
+int srwn_residual_combine(const float* x, int32_t cin, const float* res, int32_t R, float* out, int64_t rows,
+                          void* stream);
+int srwn_relu(const float* x, float* y, int64_t n, void* stream);
+/* discretized_mix_logistic_loss with sum_all=False (ops.py:174-175): out[row] = -log_sum_exp_m(log p_m(x) + log pi_m) */
+int srwn_mol_nll_rows(const float* logits, int64_t ldl, const float* x, int32_t M, float* out, int64_t rows,
+                      void* stream);
+
 /* diagnostic hook for profiling builds (no reference counterpart): while a device buffer of 1024 uint64 is registered
  * the bf16 forward group kernel appends in-kernel clock stamps of workgroup 0 to it; NULL restores production code. */
 int srwn_debug_stamp_buffer(void* device_buffer);

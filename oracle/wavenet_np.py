@@ -164,6 +164,15 @@ def log_sum_exp(x: np.ndarray) -> np.ndarray:
     return m + np.log(np.sum(np.exp(x - m2), axis=-1))
 
 
+def probs_logistic(scale, mu, y, num_classes: int = 256, log_scale_min: float = -14.0):
+    """``probs_logistic`` (ops.py:203-214): mass of the bin of half-width 1/(num_classes-1) around y under a logistic
+    with mean mu and scale clipped below at exp(log_scale_min)."""
+    scale = np.clip(np.asarray(scale, dtype=np.float64), np.exp(log_scale_min), np.inf)
+    c = np.asarray(y, dtype=np.float64) - np.asarray(mu, dtype=np.float64)
+    h = 1.0 / (num_classes - 1)
+    return sigmoid((c + h) / scale) - sigmoid((c - h) / scale)
+
+
 # --------------------------------------------------------------------------
 # parameters
 # --------------------------------------------------------------------------

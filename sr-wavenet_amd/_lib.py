@@ -35,6 +35,13 @@ SIGNATURES = {
     "srwn_residual_group_bwd": (C.c_int, [_p, _p, _p, _p, _p, _i64, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "srwn_debug_stamp_buffer": (C.c_int, [_p]),
     "srwn_group_plan_auto": (_i32, [_p, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    "srwn_log_softmax": (C.c_int, [_p, _p, _p, _i64, _i32, _p]),
+    "srwn_categorical_sample": (C.c_int, [_p, _p, _i64, _i32, C.c_uint64, _p]),
+    "srwn_probs_logistic": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _f32, _p]),
+    "srwn_tanh_gate": (C.c_int, [_p, _p, _p, _i64, _p]),
+    "srwn_residual_combine": (C.c_int, [_p, _i32, _p, _i32, _p, _i64, _p]),
+    "srwn_relu": (C.c_int, [_p, _p, _i64, _p]),
+    "srwn_mol_nll_rows": (C.c_int, [_p, _i64, _p, _i32, _p, _i64, _p]),
     "srwn_group_plan": (_i32, [_p, _i32, _i32, _i32, _p]),
     "srwn_pw_linear": (C.c_int, [_p, _i64, _i64, _i32, _i32, _p, _p, _p, _i64, _i32, _i32, _i64, _p, _i64, _i32,
                                  _i32, _i32, _p]),

@@ -6,6 +6,7 @@
 //             (repeated scalars are accepted packed or unpacked)
 // The file is mapped once and indexed (offset of every record); batches are decoded by a small thread pool straight
 // into the caller's arrays.  C-ABI in include/srwn_io.h.
+#include <mutex>
 #include <algorithm>
 #include <cstdarg>
 #include <cstdint>
@@ -34,9 +35,8 @@ int fail(int code, const char* fmt, ...) {
 
 // CRC-32C (Castagnoli, reflected polynomial 0x82F63B78), slice-by-8 tables
 uint32_t g_tab[8][256];
-bool g_tab_ready = false;
-void crc_init() {
-  if (g_tab_ready) return;
+std::once_flag g_tab_once;
+void crc_build() {
   for (uint32_t i = 0; i < 256; ++i) {
     uint32_t c = i;
     for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : (c >> 1);
@@ -44,8 +44,8 @@ void crc_init() {
   }
   for (uint32_t i = 0; i < 256; ++i)
     for (int t = 1; t < 8; ++t) g_tab[t][i] = (g_tab[t - 1][i] >> 8) ^ g_tab[0][g_tab[t - 1][i] & 0xff];
-  g_tab_ready = true;
 }
+void crc_init() { std::call_once(g_tab_once, crc_build); }   // first callers may arrive on several threads
 uint32_t crc32c(const uint8_t* p, size_t n) {
   uint32_t c = 0xffffffffu;
   while (n >= 8) {
@@ -100,9 +100,11 @@ bool sub(Span& s, Span& out) {   // length-delimited field body
   return true;
 }
 
-// finds Feature `key` in an Example payload; returns its (kind, list body) -- kind 1 bytes, 2 float, 3 int64
+// finds Feature `key` in an Example payload; returns its (kind, list body) -- kind 1 bytes, 2 float, 3 int64.
+// A key that occurs more than once resolves to its LAST entry (protobuf map semantics: what tf.parse_single_example sees).
 int find_feature(Span ex, const char* key, size_t klen, int& kind, Span& list) {
   uint64_t tag;
+  bool found = false;
   while (ex.p < ex.e) {
     if (!varint(ex, tag)) return SRWN_IO_E_PARSE;
     if (tag == ((1u << 3) | 2)) {   // Example.features
@@ -130,13 +132,13 @@ int find_feature(Span ex, const char* key, size_t klen, int& kind, Span& list) {
           if ((tag & 7) == 2 && f >= 1 && f <= 3) { kind = (int)f; if (!sub(val, list)) return SRWN_IO_E_PARSE; }
           else if (!skip(val, tag & 7)) return SRWN_IO_E_PARSE;
         }
-        return 0;
+        found = true;                // keep scanning: a later entry with the same key replaces this one
       }
     } else if (!skip(ex, tag & 7)) {
       return SRWN_IO_E_PARSE;
     }
   }
-  return SRWN_IO_E_NOKEY;
+  return found ? 0 : SRWN_IO_E_NOKEY;
 }
 
 int read_floats(Span list, float* out, int64_t max_n, int64_t& n) {

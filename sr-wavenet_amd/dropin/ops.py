@@ -14,3 +14,10 @@ ResizeEmbeddingNearestNeighbor = _o.ResizeEmbeddingNearestNeighbor
 RightShift = _o.RightShift
 mu_law_encode = _o.mu_law_encode
 mu_law_decode = _o.mu_law_decode
+ResidualDilationLayerNC = _o.ResidualDilationLayerNC
+categorical_sample = _o.categorical_sample
+log_prob_from_logits = _o.log_prob_from_logits
+log_sum_exp = _o.log_sum_exp
+discretized_mix_logistic_loss = _o.discretized_mix_logistic_loss
+sample_from_discretized_mix_logistic = _o.sample_from_discretized_mix_logistic
+probs_logistic = _o.probs_logistic

@@ -88,9 +88,9 @@ def _read_state(logdir, params_fn):
         get = lambda k: state[k]
     for k, dst in params.items():
         src = get(k)
-        if src.numel() != dst.numel():
+        if tuple(src.shape) != tuple(dst.shape):     # same element count in another layout would load scrambled weights
             raise ValueError("checkpoint variable %s has shape %s, the model's is %s" % (k, tuple(src.shape), tuple(dst.shape)))
-        dst.copy_(src.to(dst.device).reshape(dst.shape))
+        dst.copy_(src.to(dst.device))
     return True
 
 

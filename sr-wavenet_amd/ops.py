@@ -54,27 +54,47 @@ def DilatedCausalConv1d(inputs, kernel_size, channels, dilation_rate=1, name="",
     return K.causal_conv1d_fwd(x, filters, bias, dilation_rate)
 
 
-def ResidualDilationLayer(inputs, kernel_size, dilation_channels, skip_channels, dilation_rate=1, name="",
-                          dtype=None, use_bias=True):
-    """ops.py:23-46 -> (dense, skip), through the fused HIP layer kernel (fp32 MFMA).
-
-    Like ops.py:33 the gate conv is created but its result is discarded (kept for checkpoint parity).
-    """
-    x = _dev(inputs)
-    B, T, R = x.shape
-    if R != dilation_channels or R not in (32, 64) or kernel_size != 2 or skip_channels % 32:
-        raise NotImplementedError("fused layer: input channels == dilation_channels in {32,64}, kernel_size 2, "
-                                  "skip_channels multiple of 32 (got %d -> %d, K=%d, S=%d)"
-                                  % (R, dilation_channels, kernel_size, skip_channels))
-    wf = get_variable(name + "_filter/" + name + "_Kernel", (kernel_size, R, R))
+def _layer_variables(name, kernel_size, cin, R, skip_channels):
+    wf = get_variable(name + "_filter/" + name + "_Kernel", (kernel_size, cin, R))
     bf = get_variable(name + "_filter/" + name + "_Bias", (1, 1, R), init="zeros").reshape(-1)
-    get_variable(name + "_gate/" + name + "_Kernel", (kernel_size, R, R))       # dead (ops.py:32-33)
+    get_variable(name + "_gate/" + name + "_Kernel", (kernel_size, cin, R))       # dead (ops.py:32-33)
     get_variable(name + "_gate/" + name + "_Bias", (1, 1, R), init="zeros")
     wr = get_variable(name + "/residual/kernel", (1, R, R)); br = get_variable(name + "/residual/bias", (R,), "zeros")
     ws = get_variable(name + "/skip/kernel", (1, R, skip_channels))
     bs = get_variable(name + "/skip/bias", (skip_channels,), "zeros")
+    return wf, bf, wr, br, ws, bs
+
+
+def ResidualDilationLayer(inputs, kernel_size, dilation_channels, skip_channels, dilation_rate=1, name="",
+                          dtype=None, use_bias=True):
+    """ops.py:23-46 -> (dense, skip).
+
+    Like ops.py:33 the gate conv is created but its result is discarded (kept for checkpoint parity).
+    The stack's shape (input channels == dilation_channels in {32, 64}, kernel_size 2, skip_channels a multiple of 32)
+    runs on the fused MFMA layer kernel; every other shape the reference accepts -- any filter width, any channel
+    counts, a 1-channel input that broadcasts in ``inputs + residual`` (the self-check of ops.py:232-236) -- runs the
+    same arithmetic on the generic kernels.
+    """
+    x = _dev(inputs)
+    B, T, cin = x.shape
+    R = dilation_channels
+    wf, bf, wr, br, ws, bs = _layer_variables(name, kernel_size, cin, R, skip_channels)
     if not use_bias:
         bf = torch.zeros_like(bf)
+    if cin != R or R not in (32, 64) or kernel_size != 2 or skip_channels % 32:
+        if cin not in (1, R):
+            raise ValueError("ResidualDilationLayer: inputs with %d channels cannot be added to a %d-channel residual "
+                             "(ops.py:40)" % (cin, R))
+        from ._lib import call
+        st = K._stream()
+        f = K.causal_conv1d_fwd(x, wf, bf, dilation_rate)                                   # ops.py:27
+        z = torch.empty_like(f); c = torch.empty_like(f)
+        call("srwn_tanh_gate", f.data_ptr(), z.data_ptr(), c.data_ptr(), f.numel(), st)     # ops.py:28,33,36
+        res = K.causal_conv1d_fwd(c, wr, br.reshape(-1), 1)                                 # ops.py:39
+        dense = torch.empty_like(res)
+        call("srwn_residual_combine", x.data_ptr(), cin, res.data_ptr(), R, dense.data_ptr(), B * T, st)   # ops.py:40
+        skip = K.causal_conv1d_fwd(c, ws, bs.reshape(-1), 1)                                # ops.py:44
+        return dense, skip
     flat = torch.cat([wf.reshape(-1), wr.reshape(-1), ws.reshape(-1)])
     pk = K.Packer(x.device)
     oc = P.pack_conv(pk, 0, 2, R)
@@ -90,6 +110,29 @@ def ResidualDilationLayer(inputs, kernel_size, dilation_channels, skip_channels,
     K.pw_linear(z.data_ptr(), R, 0, R, R, buf.data_ptr() + 4 * osk, bs.reshape(-1), skip, skip_channels,
                 skip_channels, B * T, pro=K.PRO_GATE)
     return dense, skip.view(B, T, skip_channels)
+
+
+def ResidualDilationLayerNC(inputs, kernel_size, dilation_channels, skip_channels, dilation_rate=1, name="",
+                            dtype=None, use_bias=True):
+    """ops.py:48-57 -> (residual, skip): relu -> tf.layers.conv1d(kernel_size, 'SAME') -> relu, then a 1x1 residual and
+    a 1x1 skip.  ``dilation_rate`` is accepted and, as in the reference, never used.  (The encoder of
+    WaveNetAutoEncoder runs these layers on the MFMA kernels of encoder.py; this is the ops-level function.)"""
+    from ._lib import call
+    x = _dev(inputs)
+    B, T, cin = x.shape
+    R = dilation_channels
+    w = get_variable(name + "_NC/conv1d/kernel", (kernel_size, cin, R))
+    b = get_variable(name + "_NC/conv1d/bias", (R,), "zeros")
+    wr = get_variable(name + "/residual_nc/kernel", (1, R, R)); br = get_variable(name + "/residual_nc/bias", (R,), "zeros")
+    ws = get_variable(name + "/skip_nc/kernel", (1, R, skip_channels))
+    bs = get_variable(name + "/skip_nc/bias", (skip_channels,), "zeros")
+    st = K._stream()
+    r = torch.empty_like(x)
+    call("srwn_relu", x.data_ptr(), r.data_ptr(), x.numel(), st)                            # ops.py:49
+    # SAME padding of a stride-1 conv: pad_left = (K-1)//2 -> the causal kernel with its taps moved ceil((K-1)/2) ahead
+    a = K.causal_conv1d_fwd(r, w, b.reshape(-1), 1, shift=-((kernel_size - 1) - (kernel_size - 1) // 2))   # ops.py:51
+    call("srwn_relu", a.data_ptr(), a.data_ptr(), a.numel(), st)                            # ops.py:52
+    return K.causal_conv1d_fwd(a, wr, br.reshape(-1), 1), K.causal_conv1d_fwd(a, ws, bs.reshape(-1), 1)    # ops.py:54-55
 
 
 def ResizeEmbeddingNearestNeighbor(inputs, output_size):
@@ -117,3 +160,84 @@ def mu_law_encode(audio, quantization_channels):
 def mu_law_decode(output, quantization_channels):
     """ops.py:96-104."""
     return K.mu_law_decode(_dev(output, torch.int32), quantization_channels)
+
+
+def _rows(x):
+    x = _dev(x)
+    C = x.shape[-1]
+    return x.reshape(-1, C), x.shape
+
+
+def categorical_sample(logits, d=None, seed=0):
+    """ops.py:106-109: one class index per row of ``logits`` [rows, C], drawn from softmax(logits) (``d`` is unused there
+    too).  tf.multinomial's random stream cannot be reproduced; draws here are counter-based per (seed, row, class)."""
+    from ._lib import call
+    x, shp = _rows(logits)
+    out = torch.empty(x.shape[0], dtype=torch.int32, device=x.device)
+    call("srwn_categorical_sample", x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], int(seed), K._stream())
+    return out.reshape(shp[:-1]).long()
+
+
+def log_prob_from_logits(x):
+    """ops.py:111-115: numerically stable log-softmax over the last axis."""
+    from ._lib import call
+    r, shp = _rows(x)
+    y = torch.empty_like(r)
+    call("srwn_log_softmax", r.data_ptr(), y.data_ptr(), None, r.shape[0], r.shape[1], K._stream())
+    return y.reshape(shp)
+
+
+def log_sum_exp(x):
+    """ops.py:117-122: log-sum-exp over the last axis."""
+    from ._lib import call
+    r, shp = _rows(x)
+    lse = torch.empty(r.shape[0], dtype=torch.float32, device=r.device)
+    call("srwn_log_softmax", r.data_ptr(), None, lse.data_ptr(), r.shape[0], r.shape[1], K._stream())
+    return lse.reshape(shp[:-1])
+
+
+def discretized_mix_logistic_loss(x, l, sum_all=True):
+    """ops.py:124-175: x [B,T,1] in [-1,1], l [B,T,4*nr_mix] -> -sum of the log-likelihood (sum_all) or the
+    per-position negative log-likelihood [B,T,1]."""
+    from ._lib import call
+    lg = _dev(l)
+    B, T, C4 = lg.shape
+    M = C4 // 4
+    xv = _dev(x).reshape(B * T)
+    out = torch.empty(B * T, dtype=torch.float32, device=lg.device)
+    call("srwn_mol_nll_rows", lg.data_ptr(), C4, xv.data_ptr(), M, out.data_ptr(), B * T, K._stream())
+    if not sum_all:
+        return out.reshape(B, T, 1)
+    # (the training path fuses this sum and the gradient into srwn_mol_loss; here the rows are summed in a fixed order)
+    tot = torch.empty(1, dtype=torch.float32, device=lg.device)
+    K.reduce_loss(out, B * T, 1.0, tot)
+    return tot[0]
+
+
+def sample_from_discretized_mix_logistic(l, nr_mix, seed=None):
+    """ops.py:178-201 -> x [B,T,1] in [-1,1]; the two uniform draws come from the device generator
+    (tf.random_uniform(minval=1e-5, maxval=1-1e-5), ops.py:187,196)."""
+    from ._lib import call
+    lg = _dev(l)
+    B, T, C4 = lg.shape
+    gen = None
+    if seed is not None:
+        gen = torch.Generator(device=lg.device); gen.manual_seed(int(seed))
+    lo, hi = 1e-5, 1.0 - 1e-5
+    u1 = torch.rand((B * T, nr_mix), device=lg.device, generator=gen) * (hi - lo) + lo
+    u2 = torch.rand((B * T,), device=lg.device, generator=gen) * (hi - lo) + lo
+    out = torch.empty(B * T, dtype=torch.float32, device=lg.device)
+    call("srwn_mol_sample", lg.data_ptr(), C4, nr_mix, u1.data_ptr(), u2.data_ptr(), out.data_ptr(), B * T, K._stream())
+    return out.reshape(B, T, 1)
+
+
+def probs_logistic(scale, mu, y, num_classes=256, log_scale_min=-14):
+    """ops.py:203-214: probability mass of the bin around y under logistic(mu, scale)."""
+    from ._lib import call
+    s, m, yy = _dev(scale), _dev(mu), _dev(y)
+    s, m, yy = torch.broadcast_tensors(s, m, yy)
+    s, m, yy = s.contiguous(), m.contiguous(), yy.contiguous()
+    out = torch.empty_like(s)
+    call("srwn_probs_logistic", s.data_ptr(), m.data_ptr(), yy.data_ptr(), out.data_ptr(), s.numel(), int(num_classes),
+         float(log_scale_min), K._stream())
+    return out

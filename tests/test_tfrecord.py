@@ -262,3 +262,25 @@ def test_parser_survives_mutated_payloads(nsynth_file, tmp_path):
         with pytest.raises(RuntimeError):
             g.feature(0, "audio")
         g.close()
+
+
+def test_duplicate_feature_key_resolves_to_the_last_entry(tmp_path):
+    """protobuf map semantics (what tf.parse_single_example sees, nsynth.py:27): a key written twice keeps its LAST
+    value; and the CRC table is built once however many threads arrive first."""
+    import threading
+    NS = sub("nsynth")
+    entry = lambda k, v: ld(1, ld(1, k.encode()) + ld(2, feature(v)))
+    ex = ld(1, entry("pitch", [10]) + entry("audio", np.arange(4, dtype=np.float32)) + entry("pitch", [77]))
+    path = tmp_path / "dup.tfrecord"
+    with open(path, "wb") as f:
+        f.write(record(ex))
+    r = NS.TFRecordFile(str(path))
+    assert r.feature(0, "pitch").tolist() == [77]
+    assert r.feature(0, "audio").tolist() == [0.0, 1.0, 2.0, 3.0]
+    r.close()
+    out = []
+    def work():
+        f2 = NS.TFRecordFile(str(path)); out.append(f2.feature(0, "pitch").tolist()); f2.close()
+    ts = [threading.Thread(target=work) for _ in range(8)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert out == [[77]] * 8
