@@ -26,7 +26,9 @@ import torch
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
 # HBM bytes per launch of the dominant kernel, measured with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes):
 # (dtype, B, T, R, S, L) -> (bytes, profile the number was copied from).  Filled in from profiles/ each round.
-PROFILED_TRAFFIC = {}
+PROFILED_TRAFFIC = {
+    ("bf16", 8, 16000, 64, 256, 30): (391.8e6, "profiles/r02_c_hbm_traffic.md (group_bwd_kernel: 214.3 MB read + 177.5 MB written per launch)"),
+}
 PEAK_HBM_GBS = 8000.0        # HBM3E peak (same guide); ~4.9 TB/s is what a plain copy kernel reaches (tools/micro/membench.hip)
 
 
@@ -210,7 +212,9 @@ def main():
             "roofline_gemm": roofline_gemm,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(dil, R, S, C, threads=min(os.cpu_count() or 1, 16))
+            # the CPU restatement on the box's host cores, and the same on ONE thread (half the time budget)
+            out["cpu_baseline"] = cpu_baseline(dil, R, S, C, threads=min(os.cpu_count() or 1, 16), seconds_budget=16.0)
+            out["cpu_baseline_1thread"] = cpu_baseline(dil, R, S, C, threads=1, seconds_budget=8.0)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

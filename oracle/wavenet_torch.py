@@ -145,7 +145,7 @@ def cpu_train_steps(sp, audio_np: np.ndarray, codes_np: np.ndarray, steps: int, 
         loss = loss_per_timestep(st.forward(audio, shift_input=True), codes)
         loss.backward()
         opt.step()
-        return float(loss)
+        return float(loss.detach())
 
     one()  # warm-up
     t0 = time.perf_counter()
