@@ -208,5 +208,17 @@ template <typename T> __device__ __forceinline__ float dgate_df(float z) {
   float s = Math<T>::sigmoid_(z);
   return (s + z * s * (1.0f - s)) * (1.0f - z * z);
 }
+// bf16 mode: the same function as ONE polynomial on z in [-1, 1] (z is a tanh output).  With u = z^2 the even part of
+// d c / d f is exactly (1 - u)/2 (sigmoid(-z) = 1 - sigmoid(z)) and the odd part is z r(u); r fitted to degree 4:
+// max error 9e-7 (the sigmoid-polynomial form above: 2.5e-6), 7 FMAs instead of 10 operations -- this derivative is a
+// quarter of the backward kernels' VALU work.
+template <> __device__ __forceinline__ float dgate_df<bf16_t>(float z) {
+  const float u = z * z;
+  float r = fmaf(u, 0.00142598f, -0.01381972f);
+  r = fmaf(u, r, 0.0957148f);
+  r = fmaf(u, r, -0.5833199f);
+  r = fmaf(u, r, 0.49999976f);
+  return fmaf(z, r, fmaf(u, -0.5f, 0.5f));
+}
 
 }  // namespace srwn

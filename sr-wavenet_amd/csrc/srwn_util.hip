@@ -245,19 +245,23 @@ extern "C" int srwn_causal_conv1d_fwd(const float* x, const float* w, const floa
 // ------------------------------------------------------------------------------------------
 constexpr int kIcRows = 256;
 
-template <typename T>
+// KT > 0: the filter width as a compile-time constant (accumulators stay in registers; with a run-time K the
+// acc[9][8] array lived in scratch memory: 68 MB of scratch traffic per launch at the benchmark size); KT = 0: any K <= 8
+template <typename T, int KT>
 __global__ __launch_bounds__(256) void init_conv_wgrad_stage1(const float* __restrict__ audio,
                                                               const T* __restrict__ g, float* __restrict__ partials,
-                                                              int B, int Tlen, int R, int K, int shift) {
+                                                              int B, int Tlen, int R, int Krt, int shift) {
+  const int K = KT > 0 ? KT : Krt;
+  constexpr int KA = KT > 0 ? KT + 1 : 9;
   // thread = (8-channel group cg, row group rg): 16-byte loads of g, K+1 running sums per channel
   extern __shared__ float red[];  // [nrg][(K+1)*R]
   const int ncg = R / 8, nrg = 256 / ncg;
   const int cg = threadIdx.x % ncg, rg = threadIdx.x / ncg;
   const int64_t rows = (int64_t)B * Tlen;
   const int64_t r0 = (int64_t)blockIdx.x * kIcRows;
-  float acc[9][8];  // K <= 8
+  float acc[KA][8];  // K <= 8
 #pragma unroll
-  for (int k = 0; k < 9; ++k)
+  for (int k = 0; k < KA; ++k)
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[k][e] = 0.0f;
   const int t_block = (int)(r0 % Tlen);   // one 64-bit modulo per block; rows inside use 32-bit arithmetic
@@ -277,8 +281,8 @@ __global__ __launch_bounds__(256) void init_conv_wgrad_stage1(const float* __res
       for (int e = 0; e < 4; ++e) { gv[e] = v0[e]; gv[4 + e] = v1[e]; }
     }
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      if (k > K) break;
+    for (int k = 0; k < KA; ++k) {
+      if (KT == 0 && k > K) break;
       float xv = 1.0f;                       // k == K: bias gradient (sum of g)
       if (k < K) {
         const int tk = t - (K - 1 - k) - shift;   // shift < 0: taps ahead of t (the non-causal encoder input conv)
@@ -289,8 +293,8 @@ __global__ __launch_bounds__(256) void init_conv_wgrad_stage1(const float* __res
     }
   }
 #pragma unroll
-  for (int k = 0; k < 9; ++k) {
-    if (k > K) break;
+  for (int k = 0; k < KA; ++k) {
+    if (KT == 0 && k > K) break;
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[(rg * (K + 1) + k) * R + cg * 8 + e] = acc[k][e];
   }
@@ -333,14 +337,17 @@ extern "C" int srwn_init_conv_wgrad(const float* audio, const void* g, float* pa
   int64_t nparts = (rows + kIcRows - 1) / kIcRows;
   size_t sh = (size_t)(256 / (R / 8)) * (K + 1) * R * sizeof(float);
   if (sh > 65536) return set_error(SRWN_E_UNSUPPORTED, "init_conv_wgrad: K=%d too large for the reduction buffer", K);
-  if (dtype == SRWN_F32)
-    hipLaunchKernelGGL(init_conv_wgrad_stage1<float>, dim3((unsigned)nparts), dim3(256), sh, (hipStream_t)stream,
-                       audio, (const float*)g, partials, B, T, R, K, shift);
-  else if (dtype == SRWN_BF16)
-    hipLaunchKernelGGL(init_conv_wgrad_stage1<bf16_t>, dim3((unsigned)nparts), dim3(256), sh, (hipStream_t)stream,
-                       audio, (const bf16_t*)g, partials, B, T, R, K, shift);
-  else
+#define SRWN_IC(TT, KT_)                                                                                       \
+  hipLaunchKernelGGL((init_conv_wgrad_stage1<TT, KT_>), dim3((unsigned)nparts), dim3(256), sh, (hipStream_t)stream, \
+                     audio, (const TT*)g, partials, B, T, R, K, shift)
+  if (dtype == SRWN_F32) {
+    if (K == 2) SRWN_IC(float, 2); else SRWN_IC(float, 0);
+  } else if (dtype == SRWN_BF16) {
+    if (K == 2) SRWN_IC(bf16_t, 2); else SRWN_IC(bf16_t, 0);
+  } else {
     return set_error(SRWN_E_DTYPE, "init_conv_wgrad: dtype %d", dtype);
+  }
+#undef SRWN_IC
   int rc = check_launch("init_conv_wgrad_stage1");
   if (rc) return rc;
   int n = (K + 1) * R;
