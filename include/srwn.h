@@ -188,6 +188,19 @@ int srwn_head_softmax_ce(const void* x, int64_t x_row_stride, int32_t Cin, const
                          void* stream);
 int srwn_reduce_loss(const float* loss_partials, int64_t n, float scale, float* loss_out, void* stream);
 
+/* ---- the whole head of the softmax teacher, forward and backward, in one launch (bf16, S = cout_pad = 256):
+ *   r1 = relu(r0 @ W1 + b1)                      model.py:53-54
+ *   logits = r1 @ W2 + b2; loss_row / dlogits as srwn_head_softmax_ce      model.py:56, 100-112
+ *   da1 = (dlogits @ W2^T) * (r1 > 0);  dtotal = (da1 @ W1^T) * (r0 > 0)   (autodiff of model.py:51-56)
+ * A wave carries 32 rows through the four products in registers; r1, dlogits, da1, dtotal ([rows, 256] each) are
+ * written for the weight-gradient passes.  w1 is the srwn_pack image of W1 in natural k order; w2_perm, w2T_perm,
+ * w1T_perm are the images of W2, W2^T, W1^T in the accumulator's (permuted) k order.  loss_partials as
+ * srwn_head_softmax_ce.  Other shapes/dtypes: SRWN_E_UNSUPPORTED (the four separate entry points remain). */
+int srwn_head_chain(const void* r0, const void* w1, const void* w2_perm, const void* w2T_perm, const void* w1T_perm,
+                    const float* b1, const float* b2, const int32_t* targets, float* loss_partials, void* r1,
+                    void* dlogits, void* da1, void* dtotal, int32_t S, int32_t cout_pad, int32_t cout_valid,
+                    int64_t rows, float grad_scale, int32_t dtype, void* stream);
+
 /* ---- fused residual layer backward: autodiff of ResidualDilationLayer (ops.py:23-46); TF builds
  * these gradients in tf.train.AdamOptimizer.minimize (model.py:31).  One call per layer, top down:
  *   has_up  : G_{l+1}[t] = g_in[t]*sqrt(.5) + sum_k Wf_{l+1}[k] . df_up[t + (K-1-k)*dilation_up]  -> g_out

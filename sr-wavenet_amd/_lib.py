@@ -49,6 +49,8 @@ SIGNATURES = {
     "srwn_softmax_ce_partials": (_i64, [_i64]),
     "srwn_head_softmax_ce": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _p, _p, _p, _i32, _i32, _i64, _f32, _i32, _p]),
     "srwn_reduce_loss": (C.c_int, [_p, _i64, _f32, _p, _p]),
+    "srwn_head_chain": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i64, _f32,
+                                  _i32, _p]),
     "srwn_residual_layer_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32,
                                           _i32, _i32, _i32, _p]),
     "srwn_wgrad_slabs": (_i32, [_i64]),

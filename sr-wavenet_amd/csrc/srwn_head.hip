@@ -1,0 +1,287 @@
+// The head of the softmax teacher, forward AND backward, in one launch (bf16, 256 skip channels, <= 256 classes):
+//   r1      = relu(r0 . W1 + b1)                                   model.py:53-54
+//   logits  = r1 . W2 + b2 ; loss_row = logsumexp(logits) - logits[target]        model.py:56 + softmax-CE (model.py:100-112)
+//   dlogits = (softmax(logits) - onehot(target)) * grad_scale
+//   da1     = (dlogits . W2^T) * (r1 > 0)                          autodiff of model.py:56, 54
+//   dtotal  = (da1 . W1^T) * (r0 > 0)                              autodiff of model.py:53, 51
+// Every product is row-local, so a wave takes 32 rows through all four of them: the accumulator tile of one product
+// (channels on registers, time on lanes) is the B operand of the next (srwn_common.h), and only what the weight-gradient
+// passes need later (r1, dlogits, da1, dtotal) is written.  The four 256x256 weight images (the last three packed in
+// the accumulator's k order) stream through LDS as ONE pipeline of sixteen 32-KB chunks, LDS-DMA double-buffered, shared
+// by the eight waves of the workgroup.  Replaces four launches (head 1x1, softmax head, two head data gradients:
+// 232 us, 666 MB) -- same values up to the summation order inside an MFMA k-step.
+// gfx950 (MI355X) only.
+#include <cstdlib>
+#include "srwn_common.h"
+#include "srwn_host.h"
+#include "../../include/srwn.h"
+
+using namespace srwn;
+
+namespace {
+
+__device__ __forceinline__ void glds16_untracked(const void* g, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(g), "s"(lds_addr) : "memory");
+}
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {       // one v_cvt_pk_bf16_f32
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
+}
+
+struct HcArgs {
+  const void* r0;            // [rows, 256] relu'd skip sum
+  const void* w[4];          // packed [8][16] images: W1 (natural k), W2, W2^T, W1^T (permuted k)
+  const float* b1; const float* b2;
+  const int32_t* targets; float* loss_partials; float grad_scale; int cout_valid;
+  void* r1; void* dlogits; void* da1; void* dtotal;   // [rows, 256] each
+  int64_t rows;
+};
+
+constexpr int kHcWaves = 8;
+template <int V> struct IC { static constexpr int value = V; };
+
+template <typename T>
+__global__ __launch_bounds__(64 * kHcWaves) void headchain_kernel(HcArgs a) {
+  constexpr int MT = 8, KS = 16, KSC = 4, NCH = KS / KSC, C = 256;
+  constexpr int FB = (int)sizeof(Frag<T>) * 64, CHUNK_B = MT * KSC * FB, PIECES = CHUNK_B / 1024;
+  static_assert(PIECES % kHcWaves == 0, "chunk must split evenly over the waves");
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][CHUNK_B] weights | 8 row stages
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int col = lane & 31, half = lane >> 5;
+  const int64_t tile = (int64_t)blockIdx.x * kHcWaves + wave;
+  const int64_t r0row = tile * 32;
+  const int64_t row = r0row + col;
+  const bool valid = row < a.rows;
+  const int64_t rowc = valid ? row : (a.rows - 1);
+  const int rows_valid = (a.rows - r0row) < 32 ? (int)(a.rows - r0row) : 32;   // <= 0: idle wave (still in the barriers)
+  T* rstage = reinterpret_cast<T*>(smem + 2 * CHUNK_B) + wave * (32 * RowStage<T>::stride(64));
+  float* lbias = reinterpret_cast<float*>(smem + 2 * CHUNK_B + kHcWaves * 32 * RowStage<T>::stride(64) * sizeof(T));   // b1 | b2
+  if (threadIdx.x < 2 * C) lbias[threadIdx.x] = threadIdx.x < C ? a.b1[threadIdx.x] : (threadIdx.x - C < a.cout_valid ? a.b2[threadIdx.x - C] : 0.0f);
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+  auto stage = [&](int g, int buf) __attribute__((always_inline)) {      // chunk c = g % 4 of image g / 4 -> weight buffer `buf`
+    const char* wbase = reinterpret_cast<const char*>(a.w[g / NCH]);
+    const int c = g % NCH;
+#pragma unroll
+    for (int i = 0; i < PIECES / kHcWaves; ++i) {
+      const int p = wave * (PIECES / kHcWaves) + i;
+      const int mt = p / (KSC * FB / 1024), within = (p % (KSC * FB / 1024)) * 1024;
+      const char* gsrc = wbase + ((size_t)mt * KS + (size_t)c * KSC) * FB + within + lane * 16;
+      glds16_untracked(gsrc, __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(buf * CHUNK_B + mt * (KSC * FB) + within)));
+    }
+  };
+
+  // B operand of the running product: sixteen k-steps of 16 channels for this lane's row
+  Frag<T> bfr[KS];
+  stage(0, 0);
+  {
+    const T* xr = reinterpret_cast<const T*>(a.r0) + rowc * C + 8 * half;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) bfr[ks] = load_nat(xr + 16 * ks);
+  }
+  // r0 > 0 (r0 is relu'd: nonzero magnitude), kept as bits for the last epilogue.  The lane loaded channels
+  // 16ks + 8*half + e (natural k order); the accumulator layout it will mask holds 32mt + 8g + 4*half + r: group g of
+  // tile mt comes from k-step 2mt + g/2 of the lane half g%2, elements 4*half + r -> one exchange with the partner lane.
+  unsigned m0[4];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    unsigned nat = 0u;
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+      const u32x4 wd = __builtin_bit_cast(u32x4, bfr[4 * w + k4].v);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        nat |= (min(wd[i] & 0x7fffu, 1u) << (8 * k4 + 2 * i)) | (min((wd[i] >> 16) & 0x7fffu, 1u) << (8 * k4 + 2 * i + 1));
+    }
+    const unsigned oth = (unsigned)__shfl_xor((int)nat, 32);
+    const unsigned even = (half == 0 ? nat : oth) >> (4 * half), odd = (half == 1 ? nat : oth) >> (4 * half);
+    unsigned out = 0u;
+#pragma unroll
+    for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        out |= ((((g & 1) ? odd : even) >> (16 * a2 + 8 * (g >> 1))) & 0xfu) << (16 * a2 + 4 * g);
+    m0[w] = out;
+  }
+  f32x16 acc[MT];
+  // (the biases are added in the epilogues, from LDS: fetching 128 of them per lane into the accumulators up front
+  // overlaps their live range with the previous product's tile and spills ~150 registers at every stage boundary)
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[mt][q] = 0.0f;
+  };
+  zero_acc();
+  unsigned m1[4] = {0u, 0u, 0u, 0u};     // r1 > 0, word mt/2, bit 16*(mt%2) + q (accumulator layout)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // Stage epilogue, 64 channels (two accumulator tiles) at a time: value = fn(mt, q, acc) -> bf16 rows in HBM and the
+  // next product's B fragments (k-steps 4j..4j+3 come from tiles 2j, 2j+1), then the two tiles restart at zero.
+  // (Rewriting all 128 accumulators in place and re-reading them needs a second set of 16-register tuples at the
+  // stage boundary: ~150 spills in a 256-register kernel.)
+  auto finish = [&](void* dst, auto fn, auto post, bool frags) __attribute__((always_inline)) {
+    constexpr int LS = RowStage<T>::stride(64);
+    T* ytile = reinterpret_cast<T*>(dst) + (rows_valid > 0 ? r0row : 0) * C;
+    const int rsub = lane >> 3, piece = lane & 7;             // 8 lanes x 16 B per 64-channel row piece
+    const int rv = __builtin_amdgcn_readfirstlane(rows_valid);
+#pragma unroll
+    for (int j = 0; j < MT / 2; ++j) {
+      unsigned pk[2][8];                                       // channel pairs, packed once for both consumers
+#pragma unroll
+      for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          pk[m2][i] = pack2(fn(2 * j + m2, 2 * i, acc[2 * j + m2][2 * i]), fn(2 * j + m2, 2 * i + 1, acc[2 * j + m2][2 * i + 1]));
+      post(j, pk);
+      wave_lds_order();
+#pragma unroll
+      for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<u32x2*>(rstage + col * LS + 32 * m2 + 8 * g + 4 * half) = u32x2{pk[m2][2 * g], pk[m2][2 * g + 1]};
+      wave_lds_order();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {                            // rows past the end repeat the last one (same bytes, same address)
+        const int r = min(8 * i + rsub, rv - 1);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(rstage + r * LS + piece * 8);
+        if (rv > 0) *reinterpret_cast<f32x4*>(ytile + r * C + 64 * j + piece * 8) = v;
+      }
+      if (frags) {
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            const u32x4 w{pk[m2][4 * h2], pk[m2][4 * h2 + 1], pk[m2][4 * h2 + 2], pk[m2][4 * h2 + 3]};
+            bfr[2 * (2 * j + m2) + h2].v = __builtin_bit_cast(bf16x8, w);
+          }
+      }
+#pragma unroll
+      for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[2 * j + m2][q] = 0.0f;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto nopost = [](int, const unsigned (&)[2][8]) {};
+  // channel of accumulator register q of tile mt = cn(mt, q) + 4*half: the lane half goes into bases and bounds once
+  auto cn = [](int mt, int q) { return 32 * mt + crow(q, 0); };
+  auto lb = [&](const float* base, int mt, int q) __attribute__((always_inline)) { return (base + 4 * half)[cn(mt, q)]; };
+
+  auto step = [&](auto gc) __attribute__((always_inline)) {
+    constexpr int g = decltype(gc)::value;
+    constexpr int s = g / NCH, c = g % NCH;
+    if (g + 1 < 4 * NCH) stage(g + 1, (g + 1) & 1);
+    const Frag<T>* lw = reinterpret_cast<const Frag<T>*>(smem + (g & 1) * CHUNK_B) + lane;
+    {
+      // weight fragments two MFMAs ahead of their use (a ring of three fragments: 12 registers; a whole k-step ahead
+      // would need 64 beside the 128 accumulators and the 64 registers of the running B operand)
+      constexpr int NF = KSC * MT;
+      Frag<T> af[3];
+      af[0] = lw[0];                                  // fragment f = ks*MT + mt lives at (mt*KSC + ks)*64
+      af[1] = lw[(1 * KSC) * 64];
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        const int ks = f / MT, mt = f % MT;
+        if (f + 2 < NF) {
+          const int ks2 = (f + 2) / MT, mt2 = (f + 2) % MT;
+          af[(f + 2) % 3] = lw[(mt2 * KSC + ks2) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mma(acc[mt], af[f % 3], bfr[c * KSC + ks]);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // chunk g+1 has landed (and this wave's older stores are out)
+    if constexpr (c == NCH - 1) {
+      if constexpr (s == 0) {            // r1 = relu(. + b1), its sign bits for the way back
+        finish(a.r1, [&](int mt, int q, float x) { return fmaxf(x + lb(lbias, mt, q), 0.0f); },
+               [&](int j, const unsigned (&pk)[2][8]) {                  // +0 or positive: nonzero bits <=> r1 > 0
+                 unsigned bits = 0u;
+#pragma unroll
+                 for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                   for (int i = 0; i < 8; ++i)
+                     bits |= (min(pk[m2][i] & 0xffffu, 1u) << (16 * m2 + 2 * i)) | (min(pk[m2][i] >> 16, 1u) << (16 * m2 + 2 * i + 1));
+                 m1[j] = bits; }, true);
+      } else if constexpr (s == 1) {     // softmax cross-entropy over the class axis: registers x two lane halves
+        const int tgt = valid ? a.targets[row] : -1;
+        auto opaque = [](int x) { asm volatile("" : "+v"(x)); return x; };
+        float m = -INFINITY, vt = 0.0f;
+        const int cvh = opaque(a.cout_valid - 4 * half), tgh = opaque(tgt - 4 * half);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            acc[mt][q] += lb(lbias + C, mt, q);
+            if (cn(mt, q) < cvh) m = fmaxf(m, acc[mt][q]);
+            if (cn(mt, q) == tgh) vt = acc[mt][q];
+          }
+        m = fmaxf(m, __shfl_xor(m, 32));
+        vt += __shfl_xor(vt, 32);
+        float sum = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            acc[mt][q] = (cn(mt, q) < cvh) ? __expf(acc[mt][q] - m) : 0.0f;
+            sum += acc[mt][q];
+          }
+        sum += __shfl_xor(sum, 32);
+        const float lse = m + __logf(sum);
+        float loss = (valid && half == 0) ? (lse - vt) : 0.0f;
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) loss += __shfl_xor(loss, off);
+        if (lane == 0 && rows_valid > 0) a.loss_partials[tile] = loss;
+        const float ps = a.grad_scale / sum;
+        finish(a.dlogits, [&](int mt, int q, float x) {
+          return fmaf(x, ps, cn(mt, q) == tgh ? -a.grad_scale : 0.0f); }, nopost, true);
+      } else if constexpr (s == 2) {     // da1 = (.) * (r1 > 0)
+        finish(a.da1, [&](int mt, int q, float x) {
+          return __uint_as_float(__float_as_uint(x) & (0u - ((m1[mt >> 1] >> (16 * (mt & 1) + q)) & 1u))); }, nopost, true);
+      } else {                           // dtotal = (.) * (r0 > 0)
+        finish(a.dtotal, [&](int mt, int q, float x) {
+          return __uint_as_float(__float_as_uint(x) & (0u - ((m0[mt >> 1] >> (16 * (mt & 1) + q)) & 1u))); }, nopost, false);
+      }
+    }
+    __syncthreads();
+  };
+  step(IC<0>{}); step(IC<1>{}); step(IC<2>{}); step(IC<3>{});
+  step(IC<4>{}); step(IC<5>{}); step(IC<6>{}); step(IC<7>{});
+  step(IC<8>{}); step(IC<9>{}); step(IC<10>{}); step(IC<11>{});
+  step(IC<12>{}); step(IC<13>{}); step(IC<14>{}); step(IC<15>{});
+}
+
+}  // namespace
+
+extern "C" int srwn_head_chain(const void* r0, const void* w1, const void* w2_perm, const void* w2T_perm,
+                               const void* w1T_perm, const float* b1, const float* b2, const int32_t* targets,
+                               float* loss_partials, void* r1, void* dlogits, void* da1, void* dtotal, int32_t S,
+                               int32_t cout_pad, int32_t cout_valid, int64_t rows, float grad_scale, int32_t dtype,
+                               void* stream) {
+  if (rows == 0) return 0;
+  if (!r0 || !w1 || !w2_perm || !w2T_perm || !w1T_perm || !b1 || !b2 || !targets || !loss_partials || !r1 ||
+      !dlogits || !da1 || !dtotal)
+    return set_error(SRWN_E_NULL, "head_chain: null pointer");
+  if (dtype != SRWN_BF16) return set_error(SRWN_E_UNSUPPORTED, "head_chain: built for bf16 (fp32 keeps the four launches)");
+  if (S != 256 || cout_pad != 256) return set_error(SRWN_E_UNSUPPORTED, "head_chain: built for 256 skip channels and <= 256 classes (S=%d, cout_pad=%d)", S, cout_pad);
+  if (rows < 0 || cout_valid < 1 || cout_valid > 256 || (rows + 31) / 32 / kHcWaves + 1 > 0x7fffffffLL)
+    return set_error(SRWN_E_SHAPE, "head_chain: rows=%lld cout_valid=%d", (long long)rows, cout_valid);
+  HcArgs a{r0, {w1, w2_perm, w2T_perm, w1T_perm}, b1, b2, targets, loss_partials, grad_scale, cout_valid,
+           r1, dlogits, da1, dtotal, rows};
+  const int64_t tiles = (rows + 31) / 32;
+  const size_t sh = 2 * (size_t)(8 * 4 * 1024) + (size_t)kHcWaves * 32 * RowStage<bf16_t>::stride(64) * sizeof(bf16_t) + 2 * 256 * sizeof(float);
+  auto kfn = headchain_kernel<bf16_t>;
+  hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+  if (e != hipSuccess) return set_error((int)e, "head_chain: LDS %zu: %s", sh, hipGetErrorString(e));
+  hipLaunchKernelGGL(kfn, dim3((unsigned)((tiles + kHcWaves - 1) / kHcWaves)), dim3(64 * kHcWaves), sh,
+                     (hipStream_t)stream, a);
+  return check_launch("head_chain");
+}

@@ -108,6 +108,10 @@ class WaveNetEngine:
         self.fuse_fwd = fuse not in ("0", "bwd")
         self.fuse_bwd = fuse not in ("0", "fwd")
         self.seg_rows = int(_os.environ.get("SRWN_SEG_ROWS", "0"))
+        # head 1x1 + softmax-CE + head data gradients as one launch (SRWN_HEAD_CHAIN=0: the four separate ones)
+        self.head_chain = (_os.environ.get("SRWN_HEAD_CHAIN", "1") != "0" and cfg.head_mode == "per_timestep"
+                           and cfg.dtype == torch.bfloat16 and cfg.skip_channels == 256)
+        self._head_bwd_done = False
         self.side = None
         if torch.cuda.is_available() and self.overlap:
             # weight-gradient passes are throughput work: lowest priority, so the latency-critical dgrad
@@ -142,7 +146,7 @@ class WaveNetEngine:
             for a in ("sections", "nparams", "params", "grads", "adam_m", "adam_v", "adam_step", "dead_gate",
                       "packer", "packed", "o_conv", "o_res", "o_convT", "o_resT", "o_skipT", "o_skipT_all", "o_skip", "o_gen", "o_skip_gen",
                       "o_w1", "o_w2",
-                      "o_w1T", "o_w2T"):
+                      "o_w1T", "o_w2T", "o_w2p", "o_w2Tp", "o_w1Tp"):
                 setattr(self, a, getattr(share_from, a))
             if self.E:
                 self.o_wc = share_from.o_wc
@@ -346,6 +350,12 @@ class WaveNetEngine:
         self.o_w2 = P.pack_linear(pk, sec["head_w2"].offset, S, Cp, Cp)
         self.o_w1T = P.pack_linear_T(pk, sec["head_w1"].offset, S, S, S)
         self.o_w2T = P.pack_linear_T(pk, sec["head_w2"].offset, S, Cp, S)
+        # the same three in the accumulator's k order, for the one-launch head (csrc/srwn_head.hip)
+        self.o_w2p = self.o_w2Tp = self.o_w1Tp = None
+        if S == 256 and Cp == 256:
+            self.o_w2p = P.pack_linear(pk, sec["head_w2"].offset, S, Cp, Cp, perm=True)
+            self.o_w2Tp = P.pack_linear_T(pk, sec["head_w2"].offset, S, Cp, S, perm=True)
+            self.o_w1Tp = P.pack_linear_T(pk, sec["head_w1"].offset, S, S, S, perm=True)
 
     def wptr(self, off: int) -> int:
         return self.packed.data_ptr() + off * self.packed.element_size()
@@ -452,6 +462,16 @@ class WaveNetEngine:
         with _Span(self, "skip_sum"):
             K.pw_linear(self.zs.data_ptr(), R, N * R, R, L * R, self.wptr(self.o_skip), self.bs_sum, self.r0, S, S,
                         N, pro=K.PRO_GATE, epi=K.EPI_RELU)                            # model.py:50-51
+        self._head_bwd_done = False
+        if self.head_chain and self.o_w2p is not None and not want_logits and with_loss:
+            # model.py:53-56 + softmax CE + the two head data gradients: rows never leave the registers in between
+            with _Span(self, "head_chain"):
+                K.head_chain(self.r0, self.wptr(self.o_w1), self.wptr(self.o_w2p), self.wptr(self.o_w2Tp),
+                             self.wptr(self.o_w1Tp), v("head_b1"), v("head_b2"), self.targets, self.loss_parts,
+                             self.r1, self.dlogits, self.da1, self.dtotal, self.C, 1.0 / N)
+            self._head_bwd_done = True
+            K.reduce_loss(self.loss_parts, self.loss_parts.numel(), 1.0 / N, self.loss)
+            return None
         with _Span(self, "head_1x1"):
             K.pw_linear(self.r0.data_ptr(), S, 0, S, S, self.wptr(self.o_w1), v("head_b1"), self.r1, S, S, N,
                         epi=K.EPI_RELU)                                               # model.py:53-54
@@ -686,6 +706,8 @@ class WaveNetEngine:
 
     def _bwd_head(self):
         B, T, N, S, Cp = self.B, self.T, self.N, self.S, self.Cp
+        if self._head_bwd_done:     # da1, dtotal came out of the forward's head launch
+            return
         with _Span(self, "bwd_head"):   # relu masks against the saved activations
             if self.pooled:
                 from ._lib import call

@@ -311,6 +311,25 @@ def head_softmax_ce(x: torch.Tensor, wpack_ptr: int, bias: torch.Tensor, targets
          float(grad_scale), abi_dtype(x.dtype), _stream())
 
 
+def head_chain(r0: torch.Tensor, w1_ptr: int, w2p_ptr: int, w2Tp_ptr: int, w1Tp_ptr: int, b1: torch.Tensor,
+               b2: torch.Tensor, targets: torch.Tensor, loss_partials: torch.Tensor, r1: torch.Tensor,
+               dlogits: torch.Tensor, da1: torch.Tensor, dtotal: torch.Tensor, cout_valid: int, grad_scale: float):
+    """srwn_head_chain: head 1x1 + softmax-CE + both head data gradients for [rows, 256] bf16 rows."""
+    rows, S = r0.shape
+    px = _chk(r0, "r0")
+    outs = [_chk(t, n, r0.dtype, (rows, S)) for t, n in ((r1, "r1"), (dlogits, "dlogits"), (da1, "da1"), (dtotal, "dtotal"))]
+    pb1 = _chk(b1, "b1", torch.float32)
+    pb2 = _chk(b2, "b2", torch.float32)
+    if b1.numel() < S or b2.numel() < cout_valid:
+        raise ValueError("head_chain: bias too short")
+    pt = _chk(targets, "targets", torch.int32, (rows,))
+    pl = _chk(loss_partials, "loss_partials", torch.float32)
+    if loss_partials.numel() < (rows + 31) // 32:
+        raise ValueError("head_chain: loss_partials needs %d floats" % ((rows + 31) // 32))
+    call("srwn_head_chain", px, w1_ptr, w2p_ptr, w2Tp_ptr, w1Tp_ptr, pb1, pb2, pt, pl, *outs, int(S), int(S),
+         int(cout_valid), rows, float(grad_scale), abi_dtype(r0.dtype), _stream())
+
+
 def reduce_loss(loss_partials: torch.Tensor, n: int, scale: float, out: torch.Tensor):
     call("srwn_reduce_loss", _chk(loss_partials, "loss_partials", torch.float32), int(n), float(scale),
          _chk(out, "loss", torch.float32), _stream())

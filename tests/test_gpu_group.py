@@ -154,3 +154,45 @@ def test_group_plan():
     assert Kn.group_plan([1, 2, 4, 8, 16] * 2, 31, 3) == [(0, 3), (3, 6), (6, 9), (9, 10)]
     assert Kn.group_plan([512, 1], 31, 8) == [(0, 1), (1, 2)]
     assert Kn.group_plan([], 31, 8) == []
+
+
+@pytest.mark.parametrize("B,T,C", [(2, 700, 256), (1, 333, 250), (3, 1, 256), (1, 8191, 256)])
+def test_head_chain_equals_separate_launches(monkeypatch, B, T, C):
+    """One-launch head (csrc/srwn_head.hip) against head 1x1 + softmax head + two head data gradients: the same
+    products, every intermediate rounded to bf16 before it feeds the next product in both paths; the bias joins the sum
+    last instead of first, so values agree to a bf16 ulp, not bit for bit.  Ragged row counts, classes padded to 256,
+    T = 1."""
+    EG = sub("engine")
+    cfg = EG.StackConfig(dilations=[1, 2, 4], dilation_channels=64, skip_channels=256, output_channels=C,
+                         shift_input=True, dtype=torch.bfloat16)
+    monkeypatch.setenv("SRWN_HEAD_CHAIN", "0")
+    ref = EG.WaveNetEngine(cfg, B, T, DEV, seed=9)
+    monkeypatch.setenv("SRWN_HEAD_CHAIN", "1")
+    fus = EG.WaveNetEngine(cfg, B, T, DEV, seed=9)
+    assert fus.head_chain and not ref.head_chain
+    g = torch.Generator(device="cpu").manual_seed(9)
+    for name in ("BS", "head_b1", "head_b2"):
+        ref.view(name).copy_(0.2 * torch.randn(ref.view(name).shape, generator=g))
+    ref.view("head_b2")[C:] = 0
+    fus.params.copy_(ref.params)
+    ref.repack(); fus.repack()
+    rng = np.random.default_rng(9)
+    audio = torch.tensor(np.clip(0.3 * rng.normal(size=(B, T)), -1, 1), dtype=torch.float32, device=DEV)
+    tg = torch.tensor(rng.integers(0, C, size=(B, T)), dtype=torch.int32, device=DEV)
+    for e in (ref, fus):
+        e.set_inputs(audio, tg)
+        e.forward(); e.backward()
+    torch.cuda.synchronize()
+    assert fus._head_bwd_done and not ref._head_bwd_done
+    assert torch.equal(ref.r0, fus.r0)
+    for name in ("r1", "dlogits", "da1", "dtotal"):
+        a, b = getattr(ref, name).float(), getattr(fus, name).float()
+        assert torch.isfinite(b).all()
+        assert _rel(b, a) < 6e-3, "%s: %g" % (name, _rel(b, a))
+        # element-wise: one bf16 ulp of the larger values, except where a relu mask flips on a ~0 activation
+        bad = ((a - b).abs() > 2.0 ** -7 * a.abs().clamp_min(float(a.abs().max()) * 2.0 ** -6)).float().mean()
+        assert float(bad) < 1e-3, "%s: %g of the elements off by more than an ulp" % (name, float(bad))
+    assert abs(float(ref.loss) - float(fus.loss)) < 1e-4 * abs(float(ref.loss))
+    gr, gf = ref.named_tensors(ref.grads), fus.named_tensors(fus.grads)
+    for n in gr:
+        assert _rel(gf[n], gr[n]) < 2e-2, "%s: %g" % (n, _rel(gf[n], gr[n]))
