@@ -890,6 +890,7 @@ extern "C" int32_t srwn_group_plan(const int32_t* dilations, int32_t nlayers, in
 // Diagnostic hook (no reference counterpart): registers a device buffer of 1024 uint64; while one is registered, the
 // bf16 R = 64 forward group kernel runs in its stamped instantiation and workgroup 0 appends (tag << 48 | shader clock)
 // at its phase boundaries (tools/stamp_probe.py).  Pass NULL to return to the production instantiation.
+namespace srwn { unsigned long long* debug_stamps() { return g_stamps; } }
 extern "C" int srwn_debug_stamp_buffer(void* device_buffer) {
   g_stamps = reinterpret_cast<unsigned long long*>(device_buffer);
   return 0;

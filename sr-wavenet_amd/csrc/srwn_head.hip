@@ -34,6 +34,25 @@ __device__ __forceinline__ unsigned pack2(float lo, float hi) {       // one v_c
   return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
 }
 
+typedef short i16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+// on packed bf16 pairs: relu (a negative bf16 is a negative int16; -0 -> +0), "is nonzero" as 0/1 per half (the pair is
+// +0 or positive), and 0/1 -> 0/0xffff per half
+__device__ __forceinline__ unsigned pk_relu(unsigned w) {
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2_t, w), i16x2_t{0, 0}));
+}
+// (asm: the builtin forms are canonicalised into compare / select / permute chains, 4x the instructions)
+__device__ __forceinline__ unsigned pk_nonzero(unsigned w) {
+  unsigned d;
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(w), "s"(0x00010001u));
+  return d;
+}
+__device__ __forceinline__ unsigned pk_ones(unsigned b) {
+  unsigned d;
+  asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(d) : "v"(b), "s"(0xffffffffu));
+  return d;
+}
+
 struct HcArgs {
   const void* r0;            // [rows, 256] relu'd skip sum
   const void* w[4];          // packed [8][16] images: W1 (natural k), W2, W2^T, W1^T (permuted k)
@@ -41,12 +60,21 @@ struct HcArgs {
   const int32_t* targets; float* loss_partials; float grad_scale; int cout_valid;
   void* r1; void* dlogits; void* da1; void* dtotal;   // [rows, 256] each
   int64_t rows;
+  unsigned long long* stamps;   // diagnostic builds only (srwn_debug_stamp_buffer)
 };
 
 constexpr int kHcWaves = 8;
+constexpr int kHcBufs = 3;       // weight chunks in flight: the one being read + two on their way (an L2 round trip is longer than a step)
 template <int V> struct IC { static constexpr int value = V; };
 
-template <typename T>
+template <bool STAMP> struct HcStamper {
+  unsigned long long* p; int n;
+  __device__ __forceinline__ void operator()(int tag) {
+    if (STAMP && p) { p[n] = ((unsigned long long)tag << 48) | (__builtin_amdgcn_s_memtime() & 0xffffffffffffull); ++n; }
+  }
+};
+
+template <typename T, bool STAMP = false>
 __global__ __launch_bounds__(64 * kHcWaves) void headchain_kernel(HcArgs a) {
   constexpr int MT = 8, KS = 16, KSC = 4, NCH = KS / KSC, C = 256;
   constexpr int FB = (int)sizeof(Frag<T>) * 64, CHUNK_B = MT * KSC * FB, PIECES = CHUNK_B / 1024;
@@ -61,10 +89,14 @@ __global__ __launch_bounds__(64 * kHcWaves) void headchain_kernel(HcArgs a) {
   const bool valid = row < a.rows;
   const int64_t rowc = valid ? row : (a.rows - 1);
   const int rows_valid = (a.rows - r0row) < 32 ? (int)(a.rows - r0row) : 32;   // <= 0: idle wave (still in the barriers)
-  T* rstage = reinterpret_cast<T*>(smem + 2 * CHUNK_B) + wave * (32 * RowStage<T>::stride(64));
-  float* lbias = reinterpret_cast<float*>(smem + 2 * CHUNK_B + kHcWaves * 32 * RowStage<T>::stride(64) * sizeof(T));   // b1 | b2
-  if (threadIdx.x < 2 * C) lbias[threadIdx.x] = threadIdx.x < C ? a.b1[threadIdx.x] : (threadIdx.x - C < a.cout_valid ? a.b2[threadIdx.x - C] : 0.0f);
+  T* rstage = reinterpret_cast<T*>(smem + kHcBufs * CHUNK_B) + wave * (32 * RowStage<T>::stride(64));
+  float* lbias = reinterpret_cast<float*>(smem + kHcBufs * CHUNK_B + kHcWaves * 32 * RowStage<T>::stride(64) * sizeof(T));   // b1 | b2
+  unsigned char* gbits = reinterpret_cast<unsigned char*>(lbias + 2 * C) + wave * (32 * 33);   // r0 > 0: [row][channel / 8], rows 33 B apart
+  for (int i = threadIdx.x; i < 2 * C; i += 64 * kHcWaves) lbias[i] = i < C ? a.b1[i] : (i - C < a.cout_valid ? a.b2[i - C] : -1e30f);
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  HcStamper<STAMP> stamp{nullptr, 0};
+  if (STAMP && blockIdx.x == 0 && lane == 0 && wave < 2) stamp.p = a.stamps + wave * 512;
+  stamp(1);
 
   auto stage = [&](int g, int buf) __attribute__((always_inline)) {      // chunk c = g % 4 of image g / 4 -> weight buffer `buf`
     const char* wbase = reinterpret_cast<const char*>(a.w[g / NCH]);
@@ -78,70 +110,65 @@ __global__ __launch_bounds__(64 * kHcWaves) void headchain_kernel(HcArgs a) {
     }
   };
 
+  const int tgt = valid ? a.targets[row] : -1;
   // B operand of the running product: sixteen k-steps of 16 channels for this lane's row
   Frag<T> bfr[KS];
   stage(0, 0);
+  if (kHcBufs > 2) stage(1, 1);
   {
     const T* xr = reinterpret_cast<const T*>(a.r0) + rowc * C + 8 * half;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) bfr[ks] = load_nat(xr + 16 * ks);
   }
-  // r0 > 0 (r0 is relu'd: nonzero magnitude), kept as bits for the last epilogue.  The lane loaded channels
-  // 16ks + 8*half + e (natural k order); the accumulator layout it will mask holds 32mt + 8g + 4*half + r: group g of
-  // tile mt comes from k-step 2mt + g/2 of the lane half g%2, elements 4*half + r -> one exchange with the partner lane.
-  unsigned m0[4];
+  // r0 > 0 (the gate of the last product's output) as one bit per channel in LDS: the lane holds channels
+  // 16ks + 8*half .. +8 of its row = byte 2ks + half; the last epilogue reads bytes in its own (row-piece) layout.
+  // (Re-reading r0 there instead costs an HBM round trip per 64-channel pass: the rows have left L2 by then.)
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    unsigned nat = 0u;
+  for (int ks = 0; ks < KS; ++ks) {
+    const u32x4 wd = __builtin_bit_cast(u32x4, bfr[ks].v);
+    unsigned b = 0u;
 #pragma unroll
-    for (int k4 = 0; k4 < 4; ++k4) {
-      const u32x4 wd = __builtin_bit_cast(u32x4, bfr[4 * w + k4].v);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        nat |= (min(wd[i] & 0x7fffu, 1u) << (8 * k4 + 2 * i)) | (min((wd[i] >> 16) & 0x7fffu, 1u) << (8 * k4 + 2 * i + 1));
-    }
-    const unsigned oth = (unsigned)__shfl_xor((int)nat, 32);
-    const unsigned even = (half == 0 ? nat : oth) >> (4 * half), odd = (half == 1 ? nat : oth) >> (4 * half);
-    unsigned out = 0u;
-#pragma unroll
-    for (int a2 = 0; a2 < 2; ++a2)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        out |= ((((g & 1) ? odd : even) >> (16 * a2 + 8 * (g >> 1))) & 0xfu) << (16 * a2 + 4 * g);
-    m0[w] = out;
+    for (int e = 3; e >= 0; --e) b = (b << 2) | pk_nonzero(pk_relu(wd[e]));     // bits 2e and 2e + 16
+    gbits[col * 33 + 2 * ks + half] = (unsigned char)(b | (b >> 15));
   }
   f32x16 acc[MT];
-  // (the biases are added in the epilogues, from LDS: fetching 128 of them per lane into the accumulators up front
-  // overlaps their live range with the previous product's tile and spills ~150 registers at every stage boundary)
-  auto zero_acc = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[mt][q] = 0.0f;
-  };
-  zero_acc();
-  unsigned m1[4] = {0u, 0u, 0u, 0u};     // r1 > 0, word mt/2, bit 16*(mt%2) + q (accumulator layout)
+  unsigned m1[4] = {0u, 0u, 0u, 0u};     // r1 > 0: word j = tiles 2j, 2j+1; packed pair idx = 8*(mt%2) + i -> bits 15-idx, 31-idx
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  stamp(2);
+  // channel of accumulator register q of tile mt = cn(mt, q) + 4*half: the lane half goes into bases and bounds once
+  auto cn = [](int mt, int q) { return 32 * mt + crow(q, 0); };
+  // accumulators start at the bias (as the separate launches do): 32 floats per 64 channels, fetched when the tile is free
+  auto seed = [&](int mt, const float* nb) __attribute__((always_inline)) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 b = nb ? *reinterpret_cast<const f32x4*>(nb + 4 * half + 32 * mt + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[mt][4 * g + r] = b[r];
+    }
+  };
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) seed(mt, lbias);
 
-  // Stage epilogue, 64 channels (two accumulator tiles) at a time: value = fn(mt, q, acc) -> bf16 rows in HBM and the
-  // next product's B fragments (k-steps 4j..4j+3 come from tiles 2j, 2j+1), then the two tiles restart at zero.
+  // Stage epilogue, 64 channels (two accumulator tiles) at a time: packed bf16 pairs = fn(j, idx, a0, a1) -> rows in
+  // HBM (through `rd`, which sees each 16-byte row piece on its way out) and the next product's B fragments (k-steps
+  // 4j..4j+3 come from tiles 2j, 2j+1); then the two tiles restart at the next product's bias.
   // (Rewriting all 128 accumulators in place and re-reading them needs a second set of 16-register tuples at the
   // stage boundary: ~150 spills in a 256-register kernel.)
-  auto finish = [&](void* dst, auto fn, auto post, bool frags) __attribute__((always_inline)) {
+  auto finish = [&](void* dst, auto fn, bool gated, const float* nextbias, bool frags) __attribute__((always_inline)) {
     constexpr int LS = RowStage<T>::stride(64);
     T* ytile = reinterpret_cast<T*>(dst) + (rows_valid > 0 ? r0row : 0) * C;
     const int rsub = lane >> 3, piece = lane & 7;             // 8 lanes x 16 B per 64-channel row piece
     const int rv = __builtin_amdgcn_readfirstlane(rows_valid);
+    // gated: dtotal = (.) * (r0 > 0), the bits from the prologue meet the 16-byte row pieces on their way out
 #pragma unroll
     for (int j = 0; j < MT / 2; ++j) {
-      unsigned pk[2][8];                                       // channel pairs, packed once for both consumers
+      unsigned pk[2][8];
 #pragma unroll
       for (int m2 = 0; m2 < 2; ++m2)
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-          pk[m2][i] = pack2(fn(2 * j + m2, 2 * i, acc[2 * j + m2][2 * i]), fn(2 * j + m2, 2 * i + 1, acc[2 * j + m2][2 * i + 1]));
-      post(j, pk);
+          pk[m2][i] = fn(j, 8 * m2 + i, acc[2 * j + m2][2 * i], acc[2 * j + m2][2 * i + 1]);
       wave_lds_order();
 #pragma unroll
       for (int m2 = 0; m2 < 2; ++m2)
@@ -152,8 +179,14 @@ __global__ __launch_bounds__(64 * kHcWaves) void headchain_kernel(HcArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {                            // rows past the end repeat the last one (same bytes, same address)
         const int r = min(8 * i + rsub, rv - 1);
-        const f32x4 v = *reinterpret_cast<const f32x4*>(rstage + r * LS + piece * 8);
-        if (rv > 0) *reinterpret_cast<f32x4*>(ytile + r * C + 64 * j + piece * 8) = v;
+        u32x4 v = *reinterpret_cast<const u32x4*>(rstage + r * LS + piece * 8);
+        if (gated) {
+          const int b = gbits[max(r, 0) * 33 + 8 * j + piece];
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            v[e] &= __builtin_amdgcn_perm((unsigned)__builtin_amdgcn_sbfe(b, 2 * e + 1, 1), (unsigned)__builtin_amdgcn_sbfe(b, 2 * e, 1), 0x05040100u);
+        }
+        if (rv > 0) *reinterpret_cast<u32x4*>(ytile + r * C + 64 * j + piece * 8) = v;
       }
       if (frags) {
 #pragma unroll
@@ -164,23 +197,19 @@ __global__ __launch_bounds__(64 * kHcWaves) void headchain_kernel(HcArgs a) {
             bfr[2 * (2 * j + m2) + h2].v = __builtin_bit_cast(bf16x8, w);
           }
       }
-#pragma unroll
-      for (int m2 = 0; m2 < 2; ++m2)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc[2 * j + m2][q] = 0.0f;
+      seed(2 * j, nextbias);
+      seed(2 * j + 1, nextbias);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  auto nopost = [](int, const unsigned (&)[2][8]) {};
-  // channel of accumulator register q of tile mt = cn(mt, q) + 4*half: the lane half goes into bases and bounds once
-  auto cn = [](int mt, int q) { return 32 * mt + crow(q, 0); };
-  auto lb = [&](const float* base, int mt, int q) __attribute__((always_inline)) { return (base + 4 * half)[cn(mt, q)]; };
 
   auto step = [&](auto gc) __attribute__((always_inline)) {
     constexpr int g = decltype(gc)::value;
     constexpr int s = g / NCH, c = g % NCH;
-    if (g + 1 < 4 * NCH) stage(g + 1, (g + 1) & 1);
-    const Frag<T>* lw = reinterpret_cast<const Frag<T>*>(smem + (g & 1) * CHUNK_B) + lane;
+    constexpr int AHEAD = kHcBufs - 1;
+    if (g + AHEAD < 4 * NCH) stage(g + AHEAD, (g + AHEAD) % kHcBufs);
+    stamp(10);
+    const Frag<T>* lw = reinterpret_cast<const Frag<T>*>(smem + (g % kHcBufs) * CHUNK_B) + lane;
     {
       // weight fragments two MFMAs ahead of their use (a ring of three fragments: 12 registers; a whole k-step ahead
       // would need 64 beside the 128 accumulators and the 64 registers of the running B operand)
@@ -191,47 +220,44 @@ __global__ __launch_bounds__(64 * kHcWaves) void headchain_kernel(HcArgs a) {
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
         const int ks = f / MT, mt = f % MT;
-        if (f + 2 < NF) {
-          const int ks2 = (f + 2) / MT, mt2 = (f + 2) % MT;
-          af[(f + 2) % 3] = lw[(mt2 * KSC + ks2) * 64];
-        }
+        if (f + 2 < NF) af[(f + 2) % 3] = lw[(((f + 2) % MT) * KSC + (f + 2) / MT) * 64];
         __builtin_amdgcn_sched_barrier(0);
         mma(acc[mt], af[f % 3], bfr[c * KSC + ks]);
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // chunk g+1 has landed (and this wave's older stores are out)
+    stamp(11);
+    // chunk g+1 has landed (and this wave's older stores are out); the pieces of chunk g+2 are the youngest in flight
+    if constexpr (AHEAD > 1 && g + AHEAD < 4 * NCH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES / kHcWaves) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp(12);
     if constexpr (c == NCH - 1) {
-      if constexpr (s == 0) {            // r1 = relu(. + b1), its sign bits for the way back
-        finish(a.r1, [&](int mt, int q, float x) { return fmaxf(x + lb(lbias, mt, q), 0.0f); },
-               [&](int j, const unsigned (&pk)[2][8]) {                  // +0 or positive: nonzero bits <=> r1 > 0
-                 unsigned bits = 0u;
-#pragma unroll
-                 for (int m2 = 0; m2 < 2; ++m2)
-#pragma unroll
-                   for (int i = 0; i < 8; ++i)
-                     bits |= (min(pk[m2][i] & 0xffffu, 1u) << (16 * m2 + 2 * i)) | (min(pk[m2][i] >> 16, 1u) << (16 * m2 + 2 * i + 1));
-                 m1[j] = bits; }, true);
+      if constexpr (s == 0) {            // r1 = relu(.): on the packed pair (a negative bf16 is a negative int16), its > 0 bits
+        finish(a.r1, [&](int j, int idx, float a0, float a1) {
+          const unsigned w = pk_relu(pack2(a0, a1));
+          m1[j] = (m1[j] << 1) | pk_nonzero(w);
+          asm volatile("" : "+v"(m1[j]));     // built now: left to the optimiser the 64 terms are spilled and summed at the use
+          return w; }, false, lbias + C, true);
       } else if constexpr (s == 1) {     // softmax cross-entropy over the class axis: registers x two lane halves
-        const int tgt = valid ? a.targets[row] : -1;
-        auto opaque = [](int x) { asm volatile("" : "+v"(x)); return x; };
-        float m = -INFINITY, vt = 0.0f;
-        const int cvh = opaque(a.cout_valid - 4 * half), tgh = opaque(tgt - 4 * half);
+        auto opaque = [](int x) { asm volatile("" : "+v"(x)); return x; };   // the 128 class compares are redone per pass,
+        const int tgh = opaque(tgt - 4 * half);                               // not kept as 128 lane masks
+        float m = -INFINITY, vt = 0.0f;  // (classes past cout_valid carry a bias of -1e30: they never win, exp() = 0)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int q = 0; q < 16; ++q) {
-            acc[mt][q] += lb(lbias + C, mt, q);
-            if (cn(mt, q) < cvh) m = fmaxf(m, acc[mt][q]);
-            if (cn(mt, q) == tgh) vt = acc[mt][q];
+          for (int q = 0; q < 16; q += 2) {
+            m = fmaxf(fmaxf(m, acc[mt][q]), acc[mt][q + 1]);
+            vt = cn(mt, q) == tgh ? acc[mt][q] : vt;
+            vt = cn(mt, q + 1) == tgh ? acc[mt][q + 1] : vt;
           }
         m = fmaxf(m, __shfl_xor(m, 32));
         vt += __shfl_xor(vt, 32);
+        const float ml = -m * 1.4426950408889634f;
         float sum = 0.0f;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int q = 0; q < 16; ++q) {
-            acc[mt][q] = (cn(mt, q) < cvh) ? __expf(acc[mt][q] - m) : 0.0f;
+            acc[mt][q] = __builtin_amdgcn_exp2f(fmaf(acc[mt][q], 1.4426950408889634f, ml));
             sum += acc[mt][q];
           }
         sum += __shfl_xor(sum, 32);
@@ -240,22 +266,28 @@ __global__ __launch_bounds__(64 * kHcWaves) void headchain_kernel(HcArgs a) {
 #pragma unroll
         for (int off = 16; off > 0; off >>= 1) loss += __shfl_xor(loss, off);
         if (lane == 0 && rows_valid > 0) a.loss_partials[tile] = loss;
-        const float ps = a.grad_scale / sum;
-        finish(a.dlogits, [&](int mt, int q, float x) {
-          return fmaf(x, ps, cn(mt, q) == tgh ? -a.grad_scale : 0.0f); }, nopost, true);
+        const float ps = a.grad_scale / sum, ngs = -a.grad_scale;
+        const int tgc = opaque(tgt - 4 * half);
+        finish(a.dlogits, [&](int j, int idx, float a0, float a1) {
+          const int n = cn(2 * j + (idx >> 3), 2 * (idx & 7));
+          return pack2(fmaf(a0, ps, n == tgc ? ngs : 0.0f), fmaf(a1, ps, n + 1 == tgc ? ngs : 0.0f)); }, false, nullptr, true);
       } else if constexpr (s == 2) {     // da1 = (.) * (r1 > 0)
-        finish(a.da1, [&](int mt, int q, float x) {
-          return __uint_as_float(__float_as_uint(x) & (0u - ((m1[mt >> 1] >> (16 * (mt & 1) + q)) & 1u))); }, nopost, true);
+        finish(a.da1, [&](int j, int idx, float a0, float a1) {
+          const unsigned k0 = (unsigned)__builtin_amdgcn_sbfe((int)m1[j], 15 - idx, 1);     // 0 or ~0
+          const unsigned k1 = (unsigned)__builtin_amdgcn_sbfe((int)m1[j], 31 - idx, 1);
+          return pack2(__uint_as_float(__float_as_uint(a0) & k0), __uint_as_float(__float_as_uint(a1) & k1)); },
+               false, nullptr, true);
       } else {                           // dtotal = (.) * (r0 > 0)
-        finish(a.dtotal, [&](int mt, int q, float x) {
-          return __uint_as_float(__float_as_uint(x) & (0u - ((m0[mt >> 1] >> (16 * (mt & 1) + q)) & 1u))); }, nopost, false);
+        finish(a.dtotal, [&](int j, int idx, float a0, float a1) { return pack2(a0, a1); }, true, nullptr, false);
       }
     }
+    if constexpr (c == NCH - 1) stamp(13);
     __syncthreads();
+    stamp(14);
   };
-  step(IC<0>{}); step(IC<1>{}); step(IC<2>{}); step(IC<3>{});
-  step(IC<4>{}); step(IC<5>{}); step(IC<6>{}); step(IC<7>{});
-  step(IC<8>{}); step(IC<9>{}); step(IC<10>{}); step(IC<11>{});
+  step(IC<0>{});  step(IC<1>{});  step(IC<2>{});  step(IC<3>{});
+  step(IC<4>{});  step(IC<5>{});  step(IC<6>{});  step(IC<7>{});
+  step(IC<8>{});  step(IC<9>{});  step(IC<10>{}); step(IC<11>{});
   step(IC<12>{}); step(IC<13>{}); step(IC<14>{}); step(IC<15>{});
 }
 
@@ -275,10 +307,10 @@ extern "C" int srwn_head_chain(const void* r0, const void* w1, const void* w2_pe
   if (rows < 0 || cout_valid < 1 || cout_valid > 256 || (rows + 31) / 32 / kHcWaves + 1 > 0x7fffffffLL)
     return set_error(SRWN_E_SHAPE, "head_chain: rows=%lld cout_valid=%d", (long long)rows, cout_valid);
   HcArgs a{r0, {w1, w2_perm, w2T_perm, w1T_perm}, b1, b2, targets, loss_partials, grad_scale, cout_valid,
-           r1, dlogits, da1, dtotal, rows};
+           r1, dlogits, da1, dtotal, rows, debug_stamps()};
   const int64_t tiles = (rows + 31) / 32;
-  const size_t sh = 2 * (size_t)(8 * 4 * 1024) + (size_t)kHcWaves * 32 * RowStage<bf16_t>::stride(64) * sizeof(bf16_t) + 2 * 256 * sizeof(float);
-  auto kfn = headchain_kernel<bf16_t>;
+  const size_t sh = kHcBufs * (size_t)(8 * 4 * 1024) + (size_t)kHcWaves * 32 * RowStage<bf16_t>::stride(64) * sizeof(bf16_t) + 2 * 256 * sizeof(float) + (size_t)kHcWaves * 32 * 33;
+  auto kfn = a.stamps ? headchain_kernel<bf16_t, true> : headchain_kernel<bf16_t, false>;
   hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
   if (e != hipSuccess) return set_error((int)e, "head_chain: LDS %zu: %s", sh, hipGetErrorString(e));
   hipLaunchKernelGGL(kfn, dim3((unsigned)((tiles + kHcWaves - 1) / kHcWaves)), dim3(64 * kHcWaves), sh,

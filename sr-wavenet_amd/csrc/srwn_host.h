@@ -14,4 +14,6 @@ int rowgemm_dispatch(const void* x, int64_t x_row_stride, int64_t x_chunk_stride
                      int cout_valid, int64_t rows, const void* aux, int64_t aux_row_stride, const int32_t* targets,
                      float* loss_partials, float* logits_out, float grad_scale, int pro, int epi, int dtype,
                      hipStream_t st, int* rc);
+// srwn_group.hip: the buffer registered with srwn_debug_stamp_buffer (nullptr = production kernels)
+unsigned long long* debug_stamps();
 }  // namespace srwn
