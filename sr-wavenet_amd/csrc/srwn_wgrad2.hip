@@ -49,7 +49,7 @@ template <> struct Ld2<float> {
   }
 };
 
-constexpr int kRows = 32;      // rows per staged chunk
+constexpr int kRows = 32;      // rows per staged chunk (64 rows per chunk for the single-chunk blocks measured the same: 46 us)
 constexpr int kStride = 288;   // LDS row stride in elements: 576 B (bf16) puts 4 consecutive rows on disjoint banks
 
 // DW = width of D (256, or 128 for the reference scripts' skip_channels); CW = width of one A chunk (64, or 32 for
@@ -147,14 +147,7 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(Wg2Args a) {
     }
   };
 
-  if (nit > 0) {
-    gload(0);
-    lstore(0);
-  }
-  __syncthreads();
-  for (int it = 0; it < nit; ++it) {
-    const int buf = it & 1;
-    if (it + 1 < nit) gload(it + 1);
+  auto multiply = [&](int buf) {
     const T* ta = tileA(buf); const T* td = tileD(buf);
     if (do_bias) {
 #pragma unroll
@@ -176,8 +169,92 @@ __global__ __launch_bounds__(512) void wgrad256_kernel(Wg2Args a) {
 #pragma unroll
         for (int n = 0; n < NTW; ++n) mma(acc[m][n], af[m], bf[n]);
     }
-    if (it + 1 < nit) lstore(buf ^ 1);
+  };
+  if constexpr (sizeof(T) == 2) {
+    // bf16: a ring of three register sets -- chunk it+4 is requested while chunk it is multiplied, three steps before
+    // it moves to LDS (as wgrad_layer_kernel).  With one set in flight a workgroup had 20-32 KB outstanding against an
+    // HBM round trip of ~2 us: 2.1 TB/s for the head gradients, 2.8 for the skip gradients.  The loads are
+    // unconditional (rows and chunks clamped into the tensors, zeroed on their way to LDS) so that hipcc counts them.
+    struct Ring { f32x4 a[NVA], d[NV]; };
+    auto rload = [&](int it, Ring& r) {
+      const int64_t r0 = r_begin + (int64_t)it * kRows;
+#pragma unroll
+      for (int v = 0; v < NVA; ++v) {
+        int idx = tid + v * 512;
+        idx = idx < kRows * VPRA ? idx : kRows * VPRA - 1;
+        const int rr = idx / VPRA, cv = (idx % VPRA) * VEC;
+        int64_t row = r0 + rr;
+        row = row < a.rows ? row : a.rows - 1;
+        int chunk = (mblk * AW + cv) / CW;
+        chunk = chunk < a.m_chunks ? chunk : a.m_chunks - 1;
+        r.a[v] = *reinterpret_cast<const f32x4*>(abase + (int64_t)chunk * a.a_chunk_stride + row * a.a_row_stride + (cv % CW));
+      }
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int idx = tid + v * 512;
+        const int rr = idx / VPR, cv = (idx % VPR) * VEC;
+        int64_t row = r0 + rr;
+        row = row < a.rows ? row : a.rows - 1;
+        r.d[v] = *reinterpret_cast<const f32x4*>(dbase + row * a.d_row_stride + cv);
+      }
+    };
+    auto rstore = [&](int it, const Ring& r) {
+      const int64_t r0 = r_begin + (int64_t)it * kRows;
+      T* ta = tileA(it & 1); T* td = tileD(it & 1);
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int idx = tid + v * 512;
+        const int rr = idx / VPR, cv = (idx % VPR) * VEC;
+        *reinterpret_cast<f32x4*>(td + rr * kStride + cv) = (r0 + rr < r_end) ? r.d[v] : zero;
+      }
+#pragma unroll
+      for (int v = 0; v < NVA; ++v) {
+        const int idx = tid + v * 512;
+        if (idx >= kRows * VPRA) continue;
+        const int rr = idx / VPRA, cv = (idx % VPRA) * VEC;
+        const bool ok = (r0 + rr < r_end) && ((mblk * AW + cv) / CW < a.m_chunks);
+        f32x4 x = ok ? r.a[v] : zero;
+        if (PRO == SRWN_PRO_GATE) {
+          bf16x8 b = __builtin_bit_cast(bf16x8, x);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) b[e] = (bf16_t)gate_of_z<T>((float)b[e]);
+          x = __builtin_bit_cast(f32x4, b);
+        }
+        *reinterpret_cast<f32x4*>(ta + rr * kStride + cv) = x;
+      }
+    };
+    Ring q0, q1, q2;            // chunk c waits in set c % 3
+    rload(0, q0);
+    rload(1, q1);
+    rload(2, q2);
+    if (nit > 0) rstore(0, q0);
+    rload(3, q0);
     __syncthreads();
+    auto step = [&](int it, Ring& nxt) {
+      if (it < nit) multiply(it & 1);
+      if (it + 1 < nit) rstore(it + 1, nxt);
+      rload(it + 4, nxt);
+      __syncthreads();
+    };
+    for (int it = 0; it < nit; it += 3) {
+      step(it, q1);
+      step(it + 1, q2);
+      step(it + 2, q0);
+    }
+  } else {
+    if (nit > 0) {
+      gload(0);
+      lstore(0);
+    }
+    __syncthreads();
+    for (int it = 0; it < nit; ++it) {
+      const int buf = it & 1;
+      if (it + 1 < nit) gload(it + 1);
+      multiply(buf);
+      if (it + 1 < nit) lstore(buf ^ 1);
+      __syncthreads();
+    }
   }
 
   const int col = lane & 31, half = lane >> 5;
