@@ -102,11 +102,15 @@ class WaveNetEngine:
         self.timing_overlap = False   # the same spans inside the real schedule (side-stream work left running)
         self.spans: Dict[str, list] = {}
         import os as _os
-        self.overlap = _os.environ.get("SRWN_OVERLAP", "1") != "0"
         # multi-layer kernels (csrc/srwn_group.hip): SRWN_FUSE=0 keeps one launch per layer (the parity twin)
         fuse = _os.environ.get("SRWN_FUSE", "1")
         self.fuse_fwd = fuse not in ("0", "bwd")
         self.fuse_bwd = fuse not in ("0", "fwd")
+        # weight-gradient passes on a side stream beside the data-gradient chain: worth 11 % with one launch per layer
+        # (short latency-bound chain kernels), but with the group kernels every kernel of the backward phase is
+        # bandwidth-bound and running two at once is slower than one after the other (2.15 vs 2.13 ms; the skip data
+        # gradient beside the skip weight gradient: 446 us together, 347 us in turn) -> off by default there.
+        self.overlap = _os.environ.get("SRWN_OVERLAP", "0" if self.fuse_bwd else "1") != "0"
         self.seg_rows = int(_os.environ.get("SRWN_SEG_ROWS", "0"))
         # head 1x1 + softmax-CE + head data gradients as one launch (SRWN_HEAD_CHAIN=0: the four separate ones)
         self.head_chain = (_os.environ.get("SRWN_HEAD_CHAIN", "1") != "0" and cfg.head_mode == "per_timestep"
