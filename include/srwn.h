@@ -233,6 +233,13 @@ int srwn_wgrad(const void* in, int64_t in_batch_stride, int32_t cin, const void*
                void* stream);
 int srwn_reduce_partials(const float* partials, int32_t nslabs, int64_t n, int32_t nbatch, int32_t partials_batched,
                          float scale, float* out, int64_t out_batch_stride, void* stream);
+/* Up to 16 such reductions as ONE launch (host array of jobs; each job's result is bit-identical to its own
+ * srwn_reduce_partials call). */
+typedef struct SrwnReduceJob {
+  const float* partials; int32_t nslabs; int64_t n; int32_t nbatch; int32_t partials_batched; float scale;
+  float* out; int64_t out_batch_stride;
+} SrwnReduceJob;
+int srwn_reduce_partials_multi(const SrwnReduceJob* jobs, int32_t njobs, void* stream);
 
 /* ---- adjoint of ResizeEmbeddingNearestNeighbor (ops.py:64-74): out[b,e,c] = sum_{t in frame e} g[b,t,c] */
 /* x[b,t,c] += bias[b, t/pool_stride, c] in place (h = h + upsampled, model.py:181-183, for the first layer) */

@@ -57,6 +57,7 @@ SIGNATURES = {
     "srwn_wgrad": (C.c_int, [_p, _i64, _i32, _p, _i64, _i32, _p, _i64, _i32, _i32, _i32, _p, _i32, _p, _p, _i64,
                              _i32, _i32, _i32, _i32, _p]),
     "srwn_reduce_partials": (C.c_int, [_p, _i32, _i64, _i32, _i32, _f32, _p, _i64, _p]),
+    "srwn_reduce_partials_multi": (C.c_int, [_p, _i32, _p]),
     "srwn_add_frame_bias": (C.c_int, [_p, _p, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "srwn_frame_sum": (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "srwn_frame_sum_batched": (C.c_int, [_p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _p]),

@@ -683,6 +683,81 @@ __global__ __launch_bounds__(256) void reduce_partials_wide_kernel(const float* 
   if (i < n && sub == 0) out[(int64_t)l * out_batch_stride + i] = (float)(s * (double)scale);
 }
 
+// Several reductions in one launch (a training step finishes eleven partial buffers; launched one by one they cost
+// ~6 us each plus a dependent-launch boundary).  A block finds its job by its index and does exactly what the
+// single-job kernels do: the same slab order, the same bits.
+constexpr int kRpMaxJobs = 16;
+struct RpJob {
+  const float* partials; float* out; int64_t n; int64_t out_batch_stride;
+  int nslabs, nbatch, part_batch_mul; float scale; int wide; unsigned blocks_x, block0;
+};
+struct RpMulti { RpJob j[kRpMaxJobs]; int njobs; };
+
+__global__ __launch_bounds__(256) void reduce_partials_multi_kernel(RpMulti m) {
+  int k = 0;
+  while (k + 1 < m.njobs && blockIdx.x >= m.j[k + 1].block0) ++k;
+  const RpJob& job = m.j[k];
+  const unsigned b = blockIdx.x - job.block0;
+  const unsigned bx = b % job.blocks_x;
+  const int l = (int)(b / job.blocks_x);
+  const int nslabs = job.nslabs;
+  const int64_t n = job.n;
+  if (job.wide) {
+    const int64_t i = (int64_t)bx * 16 + (threadIdx.x >> 4);
+    const int sub = threadIdx.x & 15;
+    double s = 0.0;
+    if (i < n) {
+      const float* p = job.partials + (int64_t)l * job.part_batch_mul * nslabs * n + i;
+      for (int q = sub; q < nslabs; q += 16) s += (double)p[(int64_t)q * n];
+    }
+#pragma unroll
+    for (int w = 8; w > 0; w >>= 1) s += __shfl_xor(s, w, 64);
+    if (i < n && sub == 0) job.out[(int64_t)l * job.out_batch_stride + i] = (float)(s * (double)job.scale);
+  } else {
+    const int64_t i = (int64_t)bx * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float* p = job.partials + (int64_t)l * job.part_batch_mul * nslabs * n + i;
+    double s = 0.0;
+    int q = 0;
+    for (; q + 8 <= nslabs; q += 8) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = p[(int64_t)(q + j) * n];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += (double)v[j];
+    }
+    for (; q < nslabs; ++q) s += (double)p[(int64_t)q * n];
+    job.out[(int64_t)l * job.out_batch_stride + i] = (float)(s * (double)job.scale);
+  }
+}
+
+extern "C" int srwn_reduce_partials_multi(const SrwnReduceJob* jobs, int32_t njobs, void* stream) {
+  if (njobs == 0) return 0;
+  if (!jobs) return set_error(SRWN_E_NULL, "reduce_partials_multi: null pointer");
+  if (njobs < 0 || njobs > kRpMaxJobs) return set_error(SRWN_E_SHAPE, "reduce_partials_multi: %d jobs (1..%d)", njobs, kRpMaxJobs);
+  RpMulti m;
+  m.njobs = 0;
+  uint64_t blocks = 0;
+  for (int k = 0; k < njobs; ++k) {
+    const SrwnReduceJob& q = jobs[k];
+    if (q.n == 0 || q.nbatch == 0) continue;
+    if (!q.partials || !q.out) return set_error(SRWN_E_NULL, "reduce_partials_multi: job %d: null pointer", k);
+    if (q.nslabs < 1 || q.n < 0 || q.nbatch < 0 || q.nbatch > 65535)
+      return set_error(SRWN_E_SHAPE, "reduce_partials_multi: job %d: nslabs=%d n=%lld nbatch=%d", k, q.nslabs, (long long)q.n, q.nbatch);
+    RpJob& j = m.j[m.njobs++];
+    j.partials = q.partials; j.out = q.out; j.n = q.n; j.out_batch_stride = q.out_batch_stride;
+    j.nslabs = q.nslabs; j.nbatch = q.nbatch; j.part_batch_mul = q.partials_batched ? 1 : 0; j.scale = q.scale;
+    j.wide = (q.n <= 4096 && q.nslabs >= 32) ? 1 : 0;           // the choice srwn_reduce_partials makes
+    j.blocks_x = (unsigned)(j.wide ? (q.n + 15) / 16 : (q.n + 255) / 256);
+    j.block0 = (unsigned)blocks;
+    blocks += (uint64_t)j.blocks_x * (uint64_t)q.nbatch;
+    if (blocks > 0x7fffffffull) return set_error(SRWN_E_SHAPE, "reduce_partials_multi: grid too large");
+  }
+  if (m.njobs == 0) return 0;
+  hipLaunchKernelGGL(reduce_partials_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, m);
+  return check_launch("reduce_partials_multi");
+}
+
 extern "C" int srwn_reduce_partials(const float* partials, int32_t nslabs, int64_t n, int32_t nbatch,
                                     int32_t partials_batched, float scale, float* out, int64_t out_batch_stride,
                                     void* stream) {

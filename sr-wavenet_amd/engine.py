@@ -60,6 +60,11 @@ class Section:
         self.numel = int(np.prod(shape))
 
 
+def _os_environ_flag(name: str, default: bool) -> bool:
+    import os
+    return os.environ.get(name, "1" if default else "0") != "0"
+
+
 class _Span:
     """Optional HIP-event bracket around a group of launches on the current stream (bench.py roofline)."""
 
@@ -431,6 +436,11 @@ class WaveNetEngine:
             big = max(big, -(-max(self.ns_skip * L * R * S, self.ns_head * S * 256) // self.nslabs))
         self.wg_parts = z(self.nslabs * big, dt=torch.float32)
         self.wg_bparts = z(max(self.nslabs * max(L * S, Cp), 256 * 256), dt=torch.float32)
+        # the two head products keep partials of their own, so that skip + head finish in ONE reduction launch
+        self.batch_reduce = self.use_w256 and not self.pooled and Cp == 256 and _os_environ_flag("SRWN_BATCH_REDUCE", True)
+        if self.batch_reduce:
+            self.hd_parts = [z(self.ns_head * S * 256, dt=torch.float32) for _ in range(2)]
+            self.hd_bparts = [z(self.ns_head * 256, dt=torch.float32) for _ in range(2)]
 
     # ------------------------------------------------------------------------------------------
     # forward
@@ -742,10 +752,11 @@ class WaveNetEngine:
         NR = N * R
         xs_p, zs_p, dfs_p, gs_p = self.xs.data_ptr(), self.zs.data_ptr(), self.dfs.data_ptr(), self.gs.data_ptr()
         if self.use_wl:
-            K.reduce_partials(self.pl_f, ns, Kw * R * R, L, True, 1.0, gp + 4 * sec["WF"].offset, Kw * R * R)
-            K.reduce_partials(self.pl_bf, ns, R, L, True, 1.0, gp + 4 * sec["BF"].offset, R)
-            K.reduce_partials(self.pl_r, ns, R * R, L, True, SQRT_HALF, gp + 4 * sec["WR"].offset, R * R)
-            K.reduce_partials(self.pl_br, ns, R, L, True, SQRT_HALF, gp + 4 * sec["BR"].offset, R)
+            K.reduce_partials_multi([
+                (self.pl_f, ns, Kw * R * R, L, True, 1.0, gp + 4 * sec["WF"].offset, Kw * R * R),
+                (self.pl_bf, ns, R, L, True, 1.0, gp + 4 * sec["BF"].offset, R),
+                (self.pl_r, ns, R * R, L, True, SQRT_HALF, gp + 4 * sec["WR"].offset, R * R),
+                (self.pl_br, ns, R, L, True, SQRT_HALF, gp + 4 * sec["BR"].offset, R)])
             return
         for k in range(Kw):                                                          # dilated conv taps (legacy)
             shifts = [(Kw - 1 - k) * d for d in self.dil]
@@ -767,6 +778,21 @@ class WaveNetEngine:
         gp, sec, ns, dt = self.grads.data_ptr(), self.sections, self.nslabs, self.dt
         NR = N * R
         zs_p = self.zs.data_ptr()
+        if self.batch_reduce:
+            with _Span(self, "wgrad_skip"):
+                K.wgrad256(zs_p, NR, R, L, self.dtotal, self.wg_parts, self.wg_bparts, N, self.ns_skip,
+                           pro=K.PRO_GATE, chunk_width=R)
+            K.wgrad256(self.r0.data_ptr(), 64, S, S // 64, self.da1, self.hd_parts[0], self.hd_bparts[0], N, self.ns_head)
+            K.wgrad256(self.r1.data_ptr(), 64, S, S // 64, self.dlogits, self.hd_parts[1], self.hd_bparts[1], N,
+                       self.ns_head)                                                  # last 1x1 (S->C)
+            K.reduce_partials_multi([
+                (self.wg_parts, self.ns_skip, L * R * S, 1, True, 1.0, gp + 4 * sec["WS"].offset, 0),
+                (self.wg_bparts, self.ns_skip, S, L, False, 1.0, gp + 4 * sec["BS"].offset, S),
+                (self.hd_parts[0], self.ns_head, S * S, 1, True, 1.0, gp + 4 * sec["head_w1"].offset, 0),
+                (self.hd_bparts[0], self.ns_head, S, 1, True, 1.0, gp + 4 * sec["head_b1"].offset, 0),
+                (self.hd_parts[1], self.ns_head, S * Cp, 1, True, 1.0, gp + 4 * sec["head_w2"].offset, 0),
+                (self.hd_bparts[1], self.ns_head, Cp, 1, True, 1.0, gp + 4 * sec["head_b2"].offset, 0)])
+            return
         if self.use_w256:
             # every skip 1x1 at once: out[L*R, S] = c_all^T . dtotal (dtotal re-read once per 4 layers)
             with _Span(self, "wgrad_skip"):

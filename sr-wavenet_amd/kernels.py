@@ -8,6 +8,8 @@ from __future__ import annotations
 
 from typing import List, Optional, Tuple
 
+import ctypes as _ct
+
 import torch
 
 from . import _lib
@@ -453,6 +455,23 @@ def reduce_partials(partials: torch.Tensor, nslabs: int, n: int, nbatch: int, pa
                     out_ptr: int, out_batch_stride: int):
     call("srwn_reduce_partials", _chk(partials, "partials", torch.float32), int(nslabs), int(n), int(nbatch),
          int(bool(partials_batched)), float(scale), out_ptr, int(out_batch_stride), _stream())
+
+
+class _ReduceJob(_ct.Structure):
+    """include/srwn.h: SrwnReduceJob"""
+    _fields_ = [("partials", _ct.c_void_p), ("nslabs", _ct.c_int32), ("n", _ct.c_int64), ("nbatch", _ct.c_int32),
+                ("partials_batched", _ct.c_int32), ("scale", _ct.c_float), ("out", _ct.c_void_p),
+                ("out_batch_stride", _ct.c_int64)]
+
+
+def reduce_partials_multi(jobs):
+    """jobs: the argument tuples of `reduce_partials`, finished by one launch (at most 16)."""
+    arr = (_ReduceJob * len(jobs))()
+    for j, (partials, nslabs, n, nbatch, batched, scale, out_ptr, out_stride) in zip(arr, jobs):
+        j.partials = _chk(partials, "partials", torch.float32)
+        j.nslabs, j.n, j.nbatch, j.partials_batched = int(nslabs), int(n), int(nbatch), int(bool(batched))
+        j.scale, j.out, j.out_batch_stride = float(scale), int(out_ptr), int(out_stride)
+    call("srwn_reduce_partials_multi", _ct.addressof(arr), len(jobs), _stream())
 
 
 def frame_sum(g: torch.Tensor, frames: int, pool_stride: int) -> torch.Tensor:

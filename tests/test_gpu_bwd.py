@@ -289,3 +289,33 @@ def test_wgrad_wide_reference_widths(dt, R, S, L, rows):
         o2 = torch.empty((128, 128), dtype=torch.float32, device=DEV)
         K.reduce_partials(p2, ns2, 128 * 128, 1, True, 1.0, o2.data_ptr(), 0)
         assert rel_err(o2.cpu().numpy(), x.double().cpu().numpy().T @ d.double().cpu().numpy()) < TOL[dt]
+
+
+def test_reduce_partials_multi_matches_single_launches():
+    """Several partial buffers finished by one launch: every job bit-identical to its own srwn_reduce_partials call
+    (both kernel shapes: few outputs x many slabs, many outputs x few slabs; batched and shared partials)."""
+    Kn = sub("kernels")
+    g = torch.Generator(device="cpu").manual_seed(3)
+    specs = [  # nslabs, n, nbatch, partials_batched, scale, out_batch_stride
+        (42, 2 * 64 * 64, 5, True, 1.0, 2 * 64 * 64),
+        (42, 64, 5, True, 0.70710678, 64),
+        (32, 30 * 64 * 256, 1, True, 1.0, 0),
+        (32, 256, 30, False, 1.0, 256),
+        (64, 256 * 256, 1, True, 1.0, 0),
+        (7, 100, 3, True, 2.0, 128),
+    ]
+    jobs, singles = [], []
+    for ns, n, nb, batched, scale, stride in specs:
+        parts = torch.randn((nb if batched else 1) * ns * n, generator=g).to(DEV)
+        out_a = torch.zeros(max(stride, n) * nb, device=DEV)
+        out_b = torch.zeros_like(out_a)
+        Kn.reduce_partials(parts, ns, n, nb, batched, scale, out_a.data_ptr(), stride)
+        jobs.append((parts, ns, n, nb, batched, scale, out_b.data_ptr(), stride))
+        singles.append((out_a, out_b))
+    Kn.reduce_partials_multi(jobs)
+    torch.cuda.synchronize()
+    for k, (a, b) in enumerate(singles):
+        assert torch.equal(a, b), "job %d" % k
+        assert float(a.abs().max()) > 0
+    with pytest.raises(RuntimeError):
+        Kn.reduce_partials_multi(jobs * 3)       # 18 jobs: more than one launch takes
