@@ -27,7 +27,7 @@ PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-
 # HBM bytes per launch of the dominant kernel, measured with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes):
 # (dtype, B, T, R, S, L) -> (bytes, profile the number was copied from).  Filled in from profiles/ each round.
 PROFILED_TRAFFIC = {
-    ("bf16", 8, 16000, 64, 256, 30): (391.8e6, "profiles/r02_c_hbm_traffic.md (group_bwd_kernel: 214.3 MB read + 177.5 MB written per launch)"),
+    ("bf16", 8, 16000, 64, 256, 30): (385.7e6, "profiles/r02_f_hbm_traffic.md (group_bwd_kernel: 209.3 MB read + 176.4 MB written per launch)"),
 }
 PEAK_HBM_GBS = 8000.0        # HBM3E peak (same guide); ~4.9 TB/s is what a plain copy kernel reaches (tools/micro/membench.hip)
 
@@ -140,15 +140,18 @@ def main():
         eng.train_step()
     torch.cuda.synchronize()
     eng.timing = False
-    # second timing pass: the same spans with the side-stream overlap of the real schedule left on
+    # second timing pass: the same spans with the side-stream overlap of the real schedule left on (only where the
+    # schedule has one: with the group kernels the default schedule runs one kernel at a time, SRWN_OVERLAP)
     spans_serial = dict(eng.spans)
-    eng.spans = {}
-    eng.timing_overlap = True
-    for _ in range(npass):
-        eng.train_step()
-    torch.cuda.synchronize()
-    eng.timing_overlap = False
-    spans_ov_raw, eng.spans = dict(eng.spans), spans_serial
+    spans_ov_raw = spans_serial
+    if eng.overlap:
+        eng.spans = {}
+        eng.timing_overlap = True
+        for _ in range(npass):
+            eng.train_step()
+        torch.cuda.synchronize()
+        eng.timing_overlap = False
+        spans_ov_raw, eng.spans = dict(eng.spans), spans_serial
     # median over the timing passes (a mean lets one stray pass -- a first-touch allocation, a late module load --
     # stand for the kernel: round 1's driver record carried a 25x outlier that way), summed over the launches of a span
     def _span_ms(v):
@@ -194,9 +197,9 @@ def main():
     achieved = kflops[dom] / (spans[dom] * 1e-3) / 1e12
     roofline_gemm = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_BF16_TFLOPS,
-                     "traffic": ({"skip_sum": 573.3e6, "wgrad_skip": 632.8e6}[dom]
+                     "traffic": ({"skip_sum": 573.1e6, "wgrad_skip": 661.9e6}[dom]
                                  if (args.dtype == "bf16" and (B, T, R, S, L) == (8, 16000, 64, 256, 30)) else None),
-                     "traffic_source": "profiles/r01_l_hbm_traffic.md"}
+                     "traffic_source": "profiles/r02_f_hbm_traffic.md"}
 
     if rank == 0:
         out = {
