@@ -390,6 +390,14 @@ class WaveNetEngine:
         self.gs = z(L + 1, B, T, R)   # gs[L] is never written by the teacher: its last dense output is unused
         self.nslabs = K.wgrad_slabs(N)
         self.use_wl = (R in (32, 64) and self.Kw == 2)
+        import os as _os
+        if self.use_wl and self.fuse_bwd and "SRWN_WG_SLAB_ROWS" not in _os.environ and self.groups:
+            # the layer weight-gradient pass is launched per layer group with one workgroup per (layer, slab): cut the
+            # rows so that the widest group's launch is one workgroup per CU (5-layer groups at 3072 rows per slab left
+            # 46 of 256 CUs idle: 578 -> 503 us per step), slabs of at least 256 rows
+            cus = torch.cuda.get_device_properties(self.dev).multi_processor_count if torch.cuda.is_available() else 256
+            widest = max(l1 - l0 for l0, l1 in self.groups)
+            self.nslabs = int(max(1, min(cus // widest, (N + 255) // 256, 256)))
         if self.use_wl:
             ns = self.nslabs
             self.pl_f = z(L * ns * 2 * R * R, dt=torch.float32); self.pl_r = z(L * ns * R * R, dt=torch.float32)

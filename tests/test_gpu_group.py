@@ -18,6 +18,7 @@ def _pair(monkeypatch, dil, B, T, R, S, C, dt, E=0, pool=1, seg_rows=0, seed=3):
     EG = sub("engine")
     cfg = EG.StackConfig(dilations=list(dil), dilation_channels=R, skip_channels=S, output_channels=C,
                          cond_channels=E, pool_stride=pool, shift_input=True, dtype=dt)
+    monkeypatch.setenv("SRWN_WG_SLAB_ROWS", "3072")   # the same partial-sum slabs on both sides (the fused path sizes its own)
     monkeypatch.setenv("SRWN_FUSE", "0")
     ref = EG.WaveNetEngine(cfg, B, T, DEV, seed=seed)
     monkeypatch.setenv("SRWN_FUSE", "1")
