@@ -1,6 +1,5 @@
 #!/usr/bin/env python3
-"""In-kernel phase timing of the one-launch head (workgroup 0, waves 0 and 1): cycles between stamps.
-usage: head_probe.py [head|colgemm]"""
+"""In-kernel phase timing of the one-launch head (workgroup 0, waves 0 and 1): cycles between stamps."""
 import importlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -19,18 +18,9 @@ eng.forward()
 buf = torch.zeros(1024, dtype=torch.int64, device="cuda")
 L.call("srwn_debug_stamp_buffer", buf.data_ptr())
 names = {1: "start", 2: "prologue", 10: "dma issued", 11: "32 mfma", 12: "dma wait", 13: "epilogue", 14: "barrier"}
-if len(sys.argv) > 1 and sys.argv[1] == "colgemm":
-    names = {1: "start", 10: "dma issued", 11: "32 mfma", 13: "epilogue+stores", 12: "dma wait", 14: "barrier"}
-WHICH = sys.argv[1] if len(sys.argv) > 1 else "head"      # head | colgemm (kernels that carry stamps in a diagnostic build)
-eng.backward()
-torch.cuda.synchronize()
 for _ in range(3):
     buf.zero_()
-    if WHICH == "head":
-        eng.forward()
-    else:
-        N, R, S, Lyr = eng.N, eng.R, eng.S, eng.L
-        KN.skip_dgrad_all(eng.dtotal, eng.wptr(eng.o_skipT_all), eng.dcs.view(Lyr, N, R), R, S)
+    eng.forward()
     torch.cuda.synchronize()
 h = buf.cpu().numpy().astype("uint64")
 for w in (0, 1):
