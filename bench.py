@@ -197,7 +197,7 @@ def main():
     achieved = kflops[dom] / (spans[dom] * 1e-3) / 1e12
     roofline_gemm = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_BF16_TFLOPS,
-                     "traffic": ({"skip_sum": 573.1e6, "wgrad_skip": 661.9e6}[dom]
+                     "traffic": ({"skip_sum": 573.1e6, "wgrad_skip": 662.2e6}[dom]
                                  if (args.dtype == "bf16" and (B, T, R, S, L) == (8, 16000, 64, 256, 30)) else None),
                      "traffic_source": "profiles/r02_f_hbm_traffic.md"}
 
