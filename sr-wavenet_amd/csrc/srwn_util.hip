@@ -173,36 +173,67 @@ __global__ void causal_conv_kernel(const float* __restrict__ x, const float* __r
     if (o0 + q < Cout) yr[q] = (TOut)acc[q];
 }
 
-// Cin = 1 (the input conv of every stack, model.py:40,173,424): 8 output channels per thread, one 16-byte store (bf16)
-template <typename TOut>
+// Cin = 1 (the input conv of every stack, model.py:40,173,424): 8 output channels per thread, one 16-byte store (bf16).
+// KT > 0: filter width known at compile time -- the thread keeps its 8 x (K + 1) weights and biases in registers and
+// walks kCin1Rows rows (a block covers 32*kCin1Rows consecutive rows; at one row per thread the 24 weight loads per
+// 16-byte store made the kernel instruction-bound: 15 us for 16 MB).
+constexpr int kCin1Rows = 8;
+template <typename TOut, int KT>
 __global__ __launch_bounds__(256) void causal_conv_cin1_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                const float* __restrict__ bias, TOut* __restrict__ y,
-                                                               int B, int T, int Cout, int K, int dilation, int shift) {
+                                                               int B, int T, int Cout, int Krt, int dilation, int shift) {
+  const int K = KT > 0 ? KT : Krt;
   const int lpr = Cout / 8;
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t row = idx / lpr;
-  const int sub = (int)(idx % lpr);
-  if (row >= (int64_t)B * T) return;
-  const int t = (int)(row % T);
-  float v[8];
+  const int rpb = 256 / lpr;                               // rows a block covers per pass
+  const int sub = threadIdx.x % lpr, rloc = threadIdx.x / lpr;
+  const int64_t rows = (int64_t)B * T;
+  float bv[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] = bias ? bias[8 * sub + j] : 0.0f;
-  for (int k = 0; k < K; ++k) {
-    const int tk = t - (K - 1 - k) * dilation - shift;
-    if (tk < 0 || tk >= T) continue;
-    const float xv = x[row - t + tk];
+  for (int j = 0; j < 8; ++j) bv[j] = bias ? bias[8 * sub + j] : 0.0f;
+  constexpr int KR = KT > 0 ? KT : 1;
+  float wv[KR][8];
+  if (KT > 0) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = fmaf(xv, w[k * Cout + 8 * sub + j], v[j]);
+    for (int k = 0; k < KR; ++k)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wv[k][j] = w[k * Cout + 8 * sub + j];
   }
-  TOut* yr = y + row * Cout + 8 * sub;
-  if (sizeof(TOut) == 2) {
-    bf16x8 r;
+  const int64_t row0 = (int64_t)blockIdx.x * rpb * kCin1Rows + rloc;
+#pragma unroll 2
+  for (int it = 0; it < kCin1Rows; ++it) {
+    const int64_t row = row0 + (int64_t)it * rpb;
+    if (row >= rows) return;
+    const int t = (int)(row % T);
+    float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = (bf16_t)v[j];
-    *reinterpret_cast<bf16x8*>(yr) = r;
-  } else {
+    for (int j = 0; j < 8; ++j) v[j] = bv[j];
+    if (KT > 0) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) yr[j] = (TOut)v[j];
+      for (int k = 0; k < KR; ++k) {
+        const int tk = t - (K - 1 - k) * dilation - shift;
+        const float xv = (tk >= 0 && tk < T) ? x[row - t + tk] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaf(xv, wv[k][j], v[j]);
+      }
+    } else {
+      for (int k = 0; k < K; ++k) {
+        const int tk = t - (K - 1 - k) * dilation - shift;
+        if (tk < 0 || tk >= T) continue;
+        const float xv = x[row - t + tk];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaf(xv, w[k * Cout + 8 * sub + j], v[j]);
+      }
+    }
+    TOut* yr = y + row * Cout + 8 * sub;
+    if (sizeof(TOut) == 2) {
+      bf16x8 r;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r[j] = (bf16_t)v[j];
+      *reinterpret_cast<bf16x8*>(yr) = r;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) yr[j] = (TOut)v[j];
+    }
   }
 }
 
@@ -214,15 +245,15 @@ extern "C" int srwn_causal_conv1d_fwd(const float* x, const float* w, const floa
   if (B < 0 || T < 0 || Cin < 1 || Cout < 1 || K < 1 || dilation < 1 || shift < -(1 << 30) || shift > (1 << 30))
     return set_error(SRWN_E_SHAPE, "causal_conv1d_fwd: B=%d T=%d Cin=%d Cout=%d K=%d d=%d shift=%d", B, T, Cin, Cout,
                      K, dilation, shift);
-  if (Cin == 1 && Cout % 8 == 0 && (dtype_out == SRWN_F32 || dtype_out == SRWN_BF16)) {
-    const int64_t tot = (int64_t)B * T * (Cout / 8);
-    dim3 g1((unsigned)((tot + 255) / 256)), b1(256);
-    if (dtype_out == SRWN_F32)
-      hipLaunchKernelGGL(causal_conv_cin1_kernel<float>, g1, b1, 0, (hipStream_t)stream, x, w, bias, (float*)y, B, T, Cout,
-                         K, dilation, shift);
-    else
-      hipLaunchKernelGGL(causal_conv_cin1_kernel<bf16_t>, g1, b1, 0, (hipStream_t)stream, x, w, bias, (bf16_t*)y, B, T,
-                         Cout, K, dilation, shift);
+  if (Cin == 1 && Cout % 8 == 0 && 256 % (Cout / 8) == 0 && (dtype_out == SRWN_F32 || dtype_out == SRWN_BF16)) {
+    const int64_t rows_per_block = (int64_t)(256 / (Cout / 8)) * kCin1Rows;
+    dim3 g1((unsigned)(((int64_t)B * T + rows_per_block - 1) / rows_per_block)), b1(256);
+#define SRWN_C1(TT, KT_)                                                                                      \
+    hipLaunchKernelGGL((causal_conv_cin1_kernel<TT, KT_>), g1, b1, 0, (hipStream_t)stream, x, w, bias, (TT*)y, B, T, Cout, \
+                       K, dilation, shift)
+    if (dtype_out == SRWN_F32) { if (K == 2) SRWN_C1(float, 2); else SRWN_C1(float, 0); }
+    else { if (K == 2) SRWN_C1(bf16_t, 2); else SRWN_C1(bf16_t, 0); }
+#undef SRWN_C1
     return check_launch("causal_conv1d_fwd");
   }
   int64_t total = (int64_t)B * T * ((Cout + 3) / 4);
