@@ -37,7 +37,7 @@ int main() {
   unsigned long long* d;
   hipMalloc(&d, 4096 * sizeof(unsigned long long));
   const char* names[] = {"v_fma_f32", "v_exp_f32", "v_rcp_f32", "v_pk_fma_f32", "v_exp_f16", "v_rcp_f16", "v_cvt_pk_bf16_f32", "v_pk_mul_f32", "v_pk_fma_f16", "v_sqrt_f32"};
-  for (int waves = 1; waves <= 2; ++waves) {           // waves per SIMD (block of 256 or 512 threads, one block per CU)
+  for (int waves = 1; waves <= 4; waves *= 2) {        // waves per SIMD (block of 256, 512 or 1024 threads, one block per CU)
     for (int k = 0; k < 10; ++k) {
       std::vector<unsigned long long> h(1024);
       for (int rep = 0; rep < 2; ++rep) {
@@ -54,6 +54,25 @@ int main() {
       const double n = 16.0 * 64 * 4;
       printf("%-20s %d wave(s)/SIMD: %.2f s_memtime ticks per instruction per wave\n", names[k], waves, s / 256 / n);
     }
+  }
+  // chip-wide throughput: 2048 blocks of 1024 threads (two resident per CU = 8 waves per SIMD), timed with events
+  for (int k : {0, 3, 1}) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rep = 0; rep < 2; ++rep) {
+      hipEventRecord(e0, 0);
+      dim3 g(2048), b(1024);
+      switch (k) {
+        C(0) C(1) C(3)
+      }
+      hipEventRecord(e1, 0);
+      hipEventSynchronize(e1);
+    }
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double winstr = 2048.0 * 16 * 16.0 * 64 * 4;      // wave-instructions
+    printf("%-20s 8 waves/SIMD: %.3f ms -> %.2f wave-instructions per ns chip-wide = %.3f per SIMD per ns\n", names[k], ms,
+           winstr / (ms * 1e6), winstr / (ms * 1e6) / 1024);
   }
   return 0;
 }
