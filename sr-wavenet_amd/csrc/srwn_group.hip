@@ -410,8 +410,8 @@ struct GroupBwdArgs {
   int W, H, NT, nsub, nseg;
 };
 
-template <typename T, int RT, bool DCS, int MAXT, int NWB>
-__global__ __launch_bounds__(512) void group_bwd_kernel(GroupBwdArgs a) {
+template <typename T, int RT, bool DCS, int MAXT, int NWB, int NWV = 8>
+__global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
   constexpr int R = 32 * RT, K = 2, KS = R / 16;
   constexpr int NCONV = RT * K * KS, NRES = RT * KS, NW = NCONV + NRES;
   constexpr int LS = RowStage<T>::stride(R), VEC = RowStage<T>::VEC;
@@ -429,10 +429,10 @@ __global__ __launch_bounds__(512) void group_bwd_kernel(GroupBwdArgs a) {
 
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   auto wload = [&](int g, int buf) {   // layer g's [convT | resT] images -> weight buffer `buf` by LDS-DMA
-    dma_image(a.wconvT[g], lds_base + buf * WBYTES, CPIECES * 16, wave, lane);
-    dma_image(a.wresT[g], lds_base + buf * WBYTES + CPIECES * 16, (WPIECES - CPIECES) * 16, wave, lane);
+    dma_image(a.wconvT[g], lds_base + buf * WBYTES, CPIECES * 16, wave, lane, NWV);
+    dma_image(a.wresT[g], lds_base + buf * WBYTES + CPIECES * 16, (WPIECES - CPIECES) * 16, wave, lane, NWV);
   };
-  const int ntw = (a.NT - wave + 7) / 8;          // tiles this wave owns: q = wave + 8m, m < ntw
+  const int ntw = (a.NT - wave + NWV - 1) / NWV;  // tiles this wave owns: q = wave + NWV*m, m < ntw
 
   for (int seg = blockIdx.x; seg < a.nseg; seg += gridDim.x) {
     const int per_clip = a.st * a.nsub;
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(512) void group_bwd_kernel(GroupBwdArgs a) {
     wload(gtop, 0);
 #pragma unroll
     for (int m = 0; m < MAXT; ++m) {
-      const int q = wave + 8 * m;
+      const int q = wave + NWV * m;
 #pragma unroll
       for (int mt = 0; mt < RT; ++mt)
 #pragma unroll
@@ -556,7 +556,7 @@ __global__ __launch_bounds__(512) void group_bwd_kernel(GroupBwdArgs a) {
       // ---- phase A: df of every owned tile
 #pragma unroll
       for (int m = 0; m < MAXT; ++m) {
-        const int q = wave + 8 * m;
+        const int q = wave + NWV * m;
         if (q >= a.NT) continue;
         T* trow = img + (size_t)(32 * q) * LS;
         const bool ok = (jbase + 32 * q + col) < Jr;
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(512) void group_bwd_kernel(GroupBwdArgs a) {
       // ---- phase B: G_g = G_{g+1} sqrt(.5) + taps of df_g
 #pragma unroll
       for (int m = 0; m < MAXT; ++m) {
-        const int q = wave + 8 * m;
+        const int q = wave + NWV * m;
         if (q >= a.NT) continue;
         const int i0 = 32 * q + col;
         const int j = jbase + i0;
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(512) void group_bwd_kernel(GroupBwdArgs a) {
     // ---- the group's bottom gradient
 #pragma unroll
     for (int m = 0; m < MAXT; ++m) {
-      const int q = wave + 8 * m;
+      const int q = wave + NWV * m;
       if (q >= a.NT) continue;
       int hi = Wseg - 32 * q;
       hi = hi > 32 ? 32 : hi;
@@ -742,13 +742,13 @@ int launch_group_fwd(GroupFwdArgs& a, bool cond, int seg_rows, hipStream_t st) {
 #undef SRWN_GF
 }
 
-template <typename T, int RT, int MAXT, int NWB>
+template <typename T, int RT, int MAXT, int NWB, int NWV = 8>
 int launch_group_bwd(GroupBwdArgs& a, int seg_rows, hipStream_t st) {
   constexpr int R = 32 * RT, KS = R / 16, NW = RT * 2 * KS + RT * KS;
   const size_t fixed = (size_t)NWB * NW * 64 * sizeof(Frag<T>);
   const size_t row_bytes = (size_t)RowStage<T>::stride(R) * sizeof(T);
   int nt_max = (int)((kLdsBudget - fixed) / (32 * row_bytes));
-  if (nt_max > 8 * MAXT) nt_max = 8 * MAXT;
+  if (nt_max > NWV * MAXT) nt_max = NWV * MAXT;
   if (nt_max * 32 - a.H < 32) return set_error(SRWN_E_UNSUPPORTED, "residual_group_bwd: halo %d too large", a.H);
   const int J = (a.Tlen + a.st - 1) / a.st;
   choose_segments(J, &a.H, a.B, a.st, nt_max, seg_rows, &a.W, &a.NT, &a.nsub);
@@ -757,10 +757,10 @@ int launch_group_bwd(GroupBwdArgs& a, int seg_rows, hipStream_t st) {
   a.nseg = (int)nseg;
   const size_t sh = fixed + (size_t)a.NT * 32 * row_bytes;
   long long blocks = nseg < num_cus() ? nseg : num_cus();
-  dim3 grid((unsigned)blocks), block(512);
+  dim3 grid((unsigned)blocks), block(64 * NWV);
 #define SRWN_GB(D)                                                                                              \
   {                                                                                                             \
-    auto kfn = group_bwd_kernel<T, RT, D, MAXT, NWB>;                                                           \
+    auto kfn = group_bwd_kernel<T, RT, D, MAXT, NWB, NWV>;                                                       \
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);  \
     if (e != hipSuccess) return set_error((int)e, "residual_group_bwd: LDS %zu: %s", sh, hipGetErrorString(e)); \
     hipLaunchKernelGGL(kfn, grid, block, sh, st, a);                                                            \
@@ -800,6 +800,7 @@ extern "C" int srwn_residual_group_bwd(const void* g_top, void* g_out, void* df_
   hipStream_t st = (hipStream_t)stream;
   if (dtype == SRWN_BF16) {
     if (R == 32) return launch_group_bwd<bf16_t, 1, 3, 2>(a, seg_rows, st);
+    // (twelve waves of two tiles, as the forward kernel runs, need 65 spilled registers here: 0.56 -> 0.73 ms per step)
     return launch_group_bwd<bf16_t, 2, 3, 2>(a, seg_rows, st);
   } else if (dtype == SRWN_F32) {
     if (R == 32) return launch_group_bwd<float, 1, 1, 1>(a, seg_rows, st);
@@ -844,11 +845,16 @@ extern "C" int srwn_residual_group_fwd(const void* x0, void* x_out, void* z_out,
     return set_error(SRWN_E_SHAPE, "residual_group_fwd: dilations must be >= 1");
   if (a.H > 63) return set_error(SRWN_E_UNSUPPORTED, "residual_group_fwd: halo %d > 63 (sum of dilations / their gcd)", a.H);
   hipStream_t st = (hipStream_t)stream;
-  static const int waves16 = [] { const char* e = getenv("SRWN_GF_WAVES"); return e && atoi(e) == 16; }();
+  // waves per workgroup (bf16, R = 64).  The kernel is bound by the instructions one wave can issue (one per ~5 cycles;
+  // tools/micro/valubench.hip): twelve waves of <= 168 registers and two tiles each fill the VALU pipe that eight
+  // waves of three tiles leave ~30 % idle (forward groups 412 -> 377 us per step); sixteen (128 registers) spill.
+  static const int gf_waves = [] { const char* e = getenv("SRWN_GF_WAVES"); const int v = e ? atoi(e) : 12; return (v == 8 || v == 16) ? v : 12; }();
+  const bool waves16 = gf_waves == 16, waves12 = gf_waves == 12;
   if (dtype == SRWN_BF16) {
     if (R == 32) return launch_group_fwd<bf16_t, 1, 3, 2>(a, any_cond, seg_rows, st);
-    if (waves16) return launch_group_fwd<bf16_t, 2, 2, 2, 16>(a, any_cond, seg_rows, st);
     if (g_stamps) { a.stamps = g_stamps; return launch_group_fwd<bf16_t, 2, 3, 2, 8, true, true>(a, any_cond, seg_rows, st); }
+    if (waves16) return launch_group_fwd<bf16_t, 2, 2, 2, 16>(a, any_cond, seg_rows, st);
+    if (waves12) return launch_group_fwd<bf16_t, 2, 2, 2, 12>(a, any_cond, seg_rows, st);
     static const int wdma = [] { const char* e = getenv("SRWN_GF_WDMA"); return e ? atoi(e) : 1; }();
     if (!wdma) return launch_group_fwd<bf16_t, 2, 3, 2, 8, false>(a, any_cond, seg_rows, st);
     return launch_group_fwd<bf16_t, 2, 3, 2>(a, any_cond, seg_rows, st);
