@@ -568,8 +568,8 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
         acc_get(trow, zz);
         if (DCS) { rows_put(trow, dr); acc_get(trow, dc0); }
         {   // next operands: the wave's next tile of this layer, or its first tile of the layer below
-          const bool same = (m + 1 < MAXT) && (q + 8 < a.NT);
-          if (same) issue(g, q + 8);
+          const bool same = (m + 1 < MAXT) && (q + NWV < a.NT);
+          if (same) issue(g, q + NWV);
           else if (g > 0) issue(g - 1, wave < a.NT ? wave : a.NT - 1);
         }
         f32x16 accC[RT];
