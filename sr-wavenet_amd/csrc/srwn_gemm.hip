@@ -342,7 +342,22 @@ __global__ __launch_bounds__(64 * NW) void colgemm_kernel(CgArgs a) {
   const int rows_valid = (a.rows - row0) < 32 ? (int)(a.rows - row0) : 32;   // may be <= 0 for idle waves
   const char* wbase = reinterpret_cast<const char*>(a.wpack);
 
-  lds_dma_copy(wbase, smem, CHUNK_B, wave, lane, NW);
+  // bf16: the weight DMA is issued from inline asm and retired by a counted wait that leaves the layer's four row
+  // stores in flight.  (__syncthreads() carries s_waitcnt vmcnt(0): every layer then waited for its 4 KB of stores to
+  // be acknowledged before the next layer's MFMAs could start -- 30 store round trips per wave.)
+  constexpr bool COUNTED = sizeof(T) == 2 && NBUF == 2;
+  constexpr int PIECES = CHUNK_B / 1024;
+  static_assert(!COUNTED || PIECES % NW == 0, "weight image must split evenly over the waves");
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  auto dma = [&](int l, int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < PIECES / NW; ++i) {
+      const int p = wave * (PIECES / NW) + i;
+      glds16_untracked(wbase + (size_t)l * CHUNK_B + (size_t)p * 1024 + lane * 16,
+                       __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(buf * CHUNK_B + p * 1024)));
+    }
+  };
+  if constexpr (COUNTED) dma(0, 0); else lds_dma_copy(wbase, smem, CHUNK_B, wave, lane, NW);
   Frag<T> bf[KSS];
   {
     const T* p = reinterpret_cast<const T*>(a.x) + (valid ? row : 0) * a.x_row_stride + 8 * half;
@@ -351,11 +366,14 @@ __global__ __launch_bounds__(64 * NW) void colgemm_kernel(CgArgs a) {
 #pragma unroll
     for (int ks = 0; ks < KSS; ++ks) bf[ks] = valid ? bf[ks] : zero_frag<T>();
   }
+  if constexpr (COUNTED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int l = 0; l < a.nlayers; ++l) {
     const int buf = (NBUF == 2) ? (l & 1) : 0;
-    if (NBUF == 2 && l + 1 < a.nlayers)
-      lds_dma_copy(wbase + (size_t)(l + 1) * CHUNK_B, smem + ((l + 1) & 1) * CHUNK_B, CHUNK_B, wave, lane, NW);
+    if (NBUF == 2 && l + 1 < a.nlayers) {
+      if constexpr (COUNTED) dma(l + 1, (l + 1) & 1);
+      else lds_dma_copy(wbase + (size_t)(l + 1) * CHUNK_B, smem + ((l + 1) & 1) * CHUNK_B, CHUNK_B, wave, lane, NW);
+    }
     const Frag<T>* lw = reinterpret_cast<const Frag<T>*>(smem + buf * CHUNK_B) + lane;
     f32x16 acc[RT];
 #pragma unroll
@@ -390,8 +408,19 @@ __global__ __launch_bounds__(64 * NW) void colgemm_kernel(CgArgs a) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) v[mt][q] = acc[mt][q];
     T* ytile = reinterpret_cast<T*>(a.y) + (int64_t)l * a.y_layer_stride + (rows_valid > 0 ? row0 : 0) * R;
-    store_rows_via_lds<T, RT>(stage, ytile, R, v, rows_valid, lane);
-    __syncthreads();
+    if constexpr (COUNTED) {
+      constexpr int STORES = 32 / (64 / (R / RowStage<T>::VEC));    // store instructions of one tile (whole rows, 16 B per lane)
+      if (rows_valid > 0) {                                         // (wave-uniform)
+        store_rows_via_lds<T, RT, true>(stage, ytile, R, v, rows_valid, lane);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STORES) : "memory");   // next image landed, older stores out; these fly on
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else {
+      store_rows_via_lds<T, RT>(stage, ytile, R, v, rows_valid, lane);
+      __syncthreads();
+    }
     if (NBUF == 1 && l + 1 < a.nlayers) {
       lds_dma_copy(wbase + (size_t)(l + 1) * CHUNK_B, smem, CHUNK_B, wave, lane, NW);
       __syncthreads();
