@@ -758,9 +758,13 @@ int launch_group_bwd(GroupBwdArgs& a, int seg_rows, hipStream_t st) {
   const size_t sh = fixed + (size_t)a.NT * 32 * row_bytes;
   long long blocks = nseg < num_cus() ? nseg : num_cus();
   dim3 grid((unsigned)blocks), block(64 * NWV);
+  // segments of at most two tiles per wave (the halo-free residue-class groups: 16 tiles) run the two-tile body: 16 fewer
+  // live registers for G, no third (empty) tile iteration
+  constexpr int MT2 = MAXT > 2 ? 2 : MAXT;
+  const bool two = MAXT > 2 && a.NT <= 2 * NWV;
 #define SRWN_GB(D)                                                                                              \
   {                                                                                                             \
-    auto kfn = group_bwd_kernel<T, RT, D, MAXT, NWB, NWV>;                                                       \
+    auto kfn = two ? group_bwd_kernel<T, RT, D, MT2, NWB, NWV> : group_bwd_kernel<T, RT, D, MAXT, NWB, NWV>;                                                       \
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);  \
     if (e != hipSuccess) return set_error((int)e, "residual_group_bwd: LDS %zu: %s", sh, hipGetErrorString(e)); \
     hipLaunchKernelGGL(kfn, grid, block, sh, st, a);                                                            \
