@@ -552,12 +552,21 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
       T* dfg = reinterpret_cast<T*>(a.df_out) + (size_t)g * a.layer_stride;
       T* gprev = reinterpret_cast<T*>(a.g_out) + (size_t)(g + 1) * a.layer_stride;   // where G_{g+1} goes (n > 0)
       const bool haveg = (n > 0) || (a.g_top != nullptr);
+      // The halo shrinks on the way down: the layers below g reach hb = sum of their sub-dilations beyond the segment,
+      // so G_g is needed for positions < Wseg + hb and df_g for positions < Wseg + hb + sub_g.  Tiles beyond that are
+      // skipped (for 500 + 31 positions the 17th tile is live in three of the ten phases of a 1..16 group only --
+      // with eight waves it is a whole third round of its phase).
+      int hb = 0;
+      for (int h = 0; h < g; ++h) hb += a.sub[h];
+      int ntA = (Wseg + hb + d + 31) / 32, ntB = (Wseg + hb + 31) / 32;
+      ntA = (a.H == 0 || ntA > a.NT) ? a.NT : ntA;
+      ntB = (a.H == 0 || ntB > a.NT) ? a.NT : ntB;
 
       // ---- phase A: df of every owned tile
 #pragma unroll
       for (int m = 0; m < MAXT; ++m) {
         const int q = wave + NWV * m;
-        if (q >= a.NT) continue;
+        if (q >= ntA) continue;
         T* trow = img + (size_t)(32 * q) * LS;
         const bool ok = (jbase + 32 * q + col) < Jr;
         int hi = Wseg - 32 * q;
@@ -568,7 +577,7 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
         acc_get(trow, zz);
         if (DCS) { rows_put(trow, dr); acc_get(trow, dc0); }
         {   // next operands: the wave's next tile of this layer, or its first tile of the layer below
-          const bool same = (m + 1 < MAXT) && (q + NWV < a.NT);
+          const bool same = (m + 1 < MAXT) && (q + NWV < ntA);
           if (same) issue(g, q + NWV);
           else if (g > 0) issue(g - 1, wave < a.NT ? wave : a.NT - 1);
         }
@@ -607,7 +616,7 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
 #pragma unroll
       for (int m = 0; m < MAXT; ++m) {
         const int q = wave + NWV * m;
-        if (q >= a.NT) continue;
+        if (q >= ntB) continue;
         const int i0 = 32 * q + col;
         const int j = jbase + i0;
         const bool ok = j < Jr;
