@@ -27,7 +27,7 @@ PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-
 # HBM bytes per launch of the dominant kernel, measured with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes):
 # (dtype, B, T, R, S, L) -> (bytes, profile the number was copied from).  Filled in from profiles/ each round.
 PROFILED_TRAFFIC = {
-    ("bf16", 8, 16000, 64, 256, 30): (385.7e6, "profiles/r02_f_hbm_traffic.md (group_bwd_kernel: 209.3 MB read + 176.4 MB written per launch)"),
+    ("bf16", 8, 16000, 64, 256, 30): (365.0e6, "profiles/r02_f_hbm_traffic.md (group_bwd_kernel, mean of the six launches of a step: 213.8 MB read + 176.4 written for the 1..16 groups, 176.0 + 163.8 for the halo-free 32..512 groups)"),
 }
 PEAK_HBM_GBS = 8000.0        # HBM3E peak (same guide); ~4.9 TB/s is what a plain copy kernel reaches (tools/micro/membench.hip)
 
