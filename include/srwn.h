@@ -122,6 +122,23 @@ int srwn_residual_group_bwd(const void* g_top, void* g_out, void* df_out, const 
                             int64_t layer_stride, const void* const* wconvT, const void* const* wresT,
                             const int32_t* dilations, int32_t nlayers, int32_t B, int32_t T, int32_t R, int32_t K,
                             int32_t seg_rows, int32_t dtype, void* stream);
+/* the backward chain of a group AND the group's layer weight gradients in one launch: the chain of
+ * srwn_residual_group_bwd plus, from df_g and G_{g+1} while they are on the chip, the sums srwn_wgrad_layers makes from
+ * their HBM copies (tf.gradients of ops.py:27,39):
+ *   part_f [g][slab][k*R+i][o] = sum x_g[t-(1-k)*d_g, i] * df_g[t, o]      part_bf[g][slab][o] = sum df_g[t, o]
+ *   part_r [g][slab][i][o]     = sum c_g[t, i] * G_{g+1}[t, o]             part_br[g][slab][o] = sum G_{g+1}[t, o]
+ * (c = z sigmoid z; one slab per workgroup, `nslabs` >= srwn_group_wgrad_slabs() slabs per layer of which the launch
+ * writes the first <number of workgroups> -- keep the rest zero; finish with srwn_reduce_partials, sqrt(.5) on the
+ * residual pair, exactly as after srwn_wgrad_layers).  df is not written at all; g_out receives the group's bottom
+ * gradient (layer 0's input gradient) and, with write_all_g != 0, layer g's at g_out + g*layer_stride (the conditioned
+ * decoders sum them per frame, model.py:180).  x: layer g's complete input at x + g*layer_stride.  Halo
+ * (sum(dilations)/gcd) <= 31.  fp32 runs the launch once per sum (the chain repeats identically). */
+int32_t srwn_group_wgrad_slabs(void);
+int srwn_residual_group_bwd_wgrad(const void* g_top, void* g_out, int32_t write_all_g, const void* x, const void* z,
+                                  const void* dcs, int64_t layer_stride, const void* const* wconvT,
+                                  const void* const* wresT, const int32_t* dilations, int32_t nlayers, float* part_f,
+                                  float* part_r, float* part_bf, float* part_br, int32_t nslabs, int32_t B, int32_t T,
+                                  int32_t R, int32_t K, int32_t seg_rows, int32_t dtype, void* stream);
 /* the same cut chosen for a problem size (B clips of T steps, R channels, dtype): minimises the estimated run time of
  * the group kernels (tile rounds per layer + a fixed cost per launch) over all cuts into runs of <= max_layers layers. */
 int32_t srwn_group_plan_auto(const int32_t* dilations, int32_t nlayers, int32_t B, int32_t T, int32_t R, int32_t dtype,

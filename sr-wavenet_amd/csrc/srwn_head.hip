@@ -70,7 +70,7 @@ template <int V> struct IC { static constexpr int value = V; };
 template <bool STAMP> struct HcStamper {
   unsigned long long* p; int n;
   __device__ __forceinline__ void operator()(int tag) {
-    if (STAMP && p) { p[n] = ((unsigned long long)tag << 48) | (__builtin_amdgcn_s_memtime() & 0xffffffffffffull); ++n; }
+    if (STAMP && p && n < 512) { p[n] = ((unsigned long long)tag << 48) | (__builtin_amdgcn_s_memtime() & 0xffffffffffffull); ++n; }
   }
 };
 

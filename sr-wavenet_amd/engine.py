@@ -111,6 +111,10 @@ class WaveNetEngine:
         fuse = _os.environ.get("SRWN_FUSE", "1")
         self.fuse_fwd = fuse not in ("0", "bwd")
         self.fuse_bwd = fuse not in ("0", "fwd")
+        # SRWN_FUSE_WG=1: layer weight gradients inside a one-wave-per-SIMD backward group kernel (csrc/srwn_groupw.hip):
+        # df and G never reach HBM (-1.9 GB per step), but the kernel is slower than the chain kernel + the separate
+        # weight-gradient pass it replaces (182 vs 83 + 77 us per group) -> off by default
+        self.fuse_wg = _os.environ.get("SRWN_FUSE_WG", "0") != "0"
         # weight-gradient passes on a side stream beside the data-gradient chain: worth 11 % with one launch per layer
         # (short latency-bound chain kernels), but with the group kernels every kernel of the backward phase is
         # bandwidth-bound and running two at once is slower than one after the other (2.15 vs 2.13 ms; the skip data
@@ -390,8 +394,12 @@ class WaveNetEngine:
         self.gs = z(L + 1, B, T, R)   # gs[L] is never written by the teacher: its last dense output is unused
         self.nslabs = K.wgrad_slabs(N)
         self.use_wl = (R in (32, 64) and self.Kw == 2)
+        self.use_dcs = (R, self.S) in ((64, 256), (32, 128))
         import os as _os
-        if self.use_wl and self.fuse_bwd and "SRWN_WG_SLAB_ROWS" not in _os.environ and self.groups:
+        if self.fused_wg:
+            # one partial per workgroup of the fused backward kernel (slabs it does not reach stay zero)
+            self.nslabs = K.group_wgrad_slabs()
+        elif self.use_wl and self.fuse_bwd and "SRWN_WG_SLAB_ROWS" not in _os.environ and self.groups:
             # the layer weight-gradient pass is launched per layer group with one workgroup per (layer, slab): cut the
             # rows so that the widest group's launch is one workgroup per CU (5-layer groups at 3072 rows per slab left
             # 46 of 256 CUs idle: 578 -> 503 us per step), slabs of at least 256 rows
@@ -417,7 +425,6 @@ class WaveNetEngine:
         B, T, N, L, R, S, Cp = self.B, self.T, self.N, self.L, self.R, self.S, self.Cp
         z = lambda *s, dt=self.dt: torch.zeros(s, dtype=dt, device=self.dev)
         self.targets = torch.zeros(N, dtype=torch.int32, device=self.dev)
-        self.use_dcs = (R, S) in ((64, 256), (32, 128))
         if self.use_dcs:
             self.dcs = z(L, B, T, R)  # Ws_l . dtotal of every layer (one output-streaming GEMM)
         self.r0 = z(N, S); self.r1 = z(N, S); self.da1 = z(N, S); self.dtotal = z(N, S)
@@ -618,6 +625,9 @@ class WaveNetEngine:
             for l0, l1 in reversed(self.groups):
                 if l0 > l_hi or l0 < l_lo:
                     continue
+                if self.fused_wg:
+                    self._group_bwd_wg(l0, l1)
+                    continue
                 self._group_bwd(l0, l1)
                 if not self.timing:
                     if overlap:
@@ -631,7 +641,7 @@ class WaveNetEngine:
                 if overlap:
                     main.wait_stream(side)
                 return
-            if self.timing:
+            if self.timing and not self.fused_wg:
                 for g in groups:
                     self._wgrad_layers_group(*g)
             with torch.cuda.stream(side):
@@ -684,6 +694,25 @@ class WaveNetEngine:
         """The data-gradient chain runs as one launch per layer group (needs the precomputed skip gradients `dcs`, or a
         stack without a skip path)."""
         return self.fuse_bwd and self.use_wl and (getattr(self, "use_dcs", False) or self.cfg.head_mode == "flow")
+
+    @property
+    def fused_wg(self) -> bool:
+        """The layer weight gradients are summed inside the backward group kernel (no df / G round trip)."""
+        return self.fuse_wg and self.fused_bwd
+
+    def _group_bwd_wg(self, l0: int, l1: int):
+        """Chain + weight-gradient partials of layers [l0, l1) in one launch (srwn_residual_group_bwd_wgrad)."""
+        flow = self.cfg.head_mode == "flow"
+        R, ns = self.R, self.nslabs
+        g_top = self.gs[l1] if (flow or l1 < self.L) else None
+        with _Span(self, "group_bwd_wg"):
+            K.residual_group_bwd_wgrad(g_top, self.gs[l0:l1], self.xs[l0:l1], self.zs[l0:l1],
+                                       None if flow else self.dcs[l0:l1],
+                                       [self.wptr(self.o_convT[l]) for l in range(l0, l1)],
+                                       [self.wptr(self.o_resT[l]) for l in range(l0, l1)], self.dil[l0:l1],
+                                       self.pl_f[l0 * ns * 2 * R * R:], self.pl_r[l0 * ns * R * R:],
+                                       self.pl_bf[l0 * ns * R:], self.pl_br[l0 * ns * R:], ns, self.Kw,
+                                       seg_rows=self.seg_rows, write_all_g=bool(self.E))
 
     def _group_bwd(self, l0: int, l1: int):
         flow = self.cfg.head_mode == "flow"
