@@ -139,6 +139,35 @@ int srwn_residual_group_bwd_wgrad(const void* g_top, void* g_out, int32_t write_
                                   const void* const* wresT, const int32_t* dilations, int32_t nlayers, float* part_f,
                                   float* part_r, float* part_bf, float* part_br, int32_t nslabs, int32_t B, int32_t T,
                                   int32_t R, int32_t K, int32_t seg_rows, int32_t dtype, void* stream);
+/* ---- layer weight gradients summed inside the backward group kernel, 8 waves, output-split ("wt" mode).
+ * The two kernels of a group are given the SAME segment cut (srwn_group_wt_geometry).  srwn_residual_group_fwd_wt is
+ * srwn_residual_group_fwd that also writes, per layer g of the group and per 32-step tile of every segment, the
+ * TRANSPOSED layer input x_g and gate output c_g = z_g sigmoid(z_g) ("weight-gradient tiles", [channel][32 steps],
+ * layer g at xT / cT + g*wt_layer_stride elements; steps a segment does not own are zero in xT).
+ * srwn_residual_group_bwd_wt is the chain of srwn_residual_group_bwd which, per layer, additionally contracts over time
+ *   part_r [g][slab][i][o]     = sum c_g[t,i] * G_{g+1}[t,o]      part_br[g][slab][o] = sum G_{g+1}[t,o]
+ *   part_f [g][slab][k*R+i][o] = sum x_g[t-(1-k)*d_g,i] * df_g[t,o]   part_bf[g][slab][o] = sum df_g[t,o]
+ * (the sums of srwn_wgrad_layers, in its layout; tf.gradients of ops.py:27,39) with the A operands loaded as MFMA
+ * fragments from those tiles and df_g / G_{g+1} read from the kernel's own LDS image, the R x R outputs split into
+ * 16 x 16 blocks over the eight waves.  df is not stored; G of the inner layers only with write_all_g (the conditioned
+ * decoders sum it per frame, model.py:180); g_out always receives the group's bottom gradient.  One partial slab per
+ * workgroup (`nslabs` from srwn_group_wt_geometry; slabs beyond it must stay zero); finish with srwn_reduce_partials,
+ * sqrt(.5) on the residual pair.  Halo (sum(dilations)/gcd) <= 31. */
+int srwn_group_wt_geometry(const int32_t* dilations, int32_t nlayers, int32_t B, int32_t T, int32_t R, int32_t dtype,
+                           int32_t seg_rows_in, int32_t* seg_rows, int32_t* tiles_per_seg, int64_t* elems_per_layer,
+                           int32_t* nslabs);
+int srwn_residual_group_fwd_wt(const void* x0, void* x_out, void* z_out, int64_t layer_stride, void* xT, void* cT,
+                               int64_t wt_layer_stride, const void* const* wconv, const void* const* wres,
+                               const float* const* bias_f, const float* const* bias_r, const void* const* cond_next,
+                               int32_t cond_frames, int32_t pool_stride, int32_t cond_row_stride,
+                               const int32_t* dilations, int32_t nlayers, int32_t B, int32_t T, int32_t R, int32_t K,
+                               int32_t seg_rows, int32_t dtype, void* stream);
+int srwn_residual_group_bwd_wt(const void* g_top, void* g_out, int32_t write_all_g, const void* z, const void* dcs,
+                               int64_t layer_stride, const void* xT, const void* cT, int64_t wt_layer_stride,
+                               const void* const* wconvT, const void* const* wresT, const int32_t* dilations,
+                               int32_t nlayers, float* part_f, float* part_r, float* part_bf, float* part_br,
+                               int32_t nslabs, int32_t B, int32_t T, int32_t R, int32_t K, int32_t seg_rows,
+                               int32_t dtype, void* stream);
 /* the same cut chosen for a problem size (B clips of T steps, R channels, dtype): minimises the estimated run time of
  * the group kernels (tile rounds per layer + a fixed cost per launch) over all cuts into runs of <= max_layers layers. */
 int32_t srwn_group_plan_auto(const int32_t* dilations, int32_t nlayers, int32_t B, int32_t T, int32_t R, int32_t dtype,

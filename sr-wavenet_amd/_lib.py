@@ -36,6 +36,11 @@ SIGNATURES = {
     "srwn_group_wgrad_slabs": (_i32, []),
     "srwn_residual_group_bwd_wgrad": (C.c_int, [_p, _p, _i32, _p, _p, _p, _i64, _p, _p, _p, _i32, _p, _p, _p, _p, _i32,
                                                 _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    "srwn_group_wt_geometry": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p]),
+    "srwn_residual_group_fwd_wt": (C.c_int, [_p, _p, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p,
+                                             _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    "srwn_residual_group_bwd_wt": (C.c_int, [_p, _p, _i32, _p, _p, _i64, _p, _p, _i64, _p, _p, _p, _i32, _p, _p, _p, _p,
+                                             _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "srwn_debug_stamp_buffer": (C.c_int, [_p]),
     "srwn_group_plan_auto": (_i32, [_p, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "srwn_log_softmax": (C.c_int, [_p, _p, _p, _i64, _i32, _p]),

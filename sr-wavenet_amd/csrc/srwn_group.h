@@ -46,6 +46,128 @@ __device__ __forceinline__ void dma_image(const void* gsrc, unsigned lds_dst, in
 
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// ----------------------------------------------------------------------------------------------
+// "Weight-gradient tiles": 32 consecutive positions of a segment x R channels, stored TRANSPOSED ([channel][32 steps])
+// so that a lane's eight consecutive elements are eight time steps of one channel -- directly the A fragment of a
+// v_mfma_f32_16x16x32_bf16 that contracts over time (lane l: row l & 15, k = 8 (l >> 4) + j).  The forward group kernel
+// writes them (the layer input x and the gate output c = z sigmoid z, from the LDS image with transposing reads), the
+// backward group kernel loads them as fragments and contracts them with df / G from its own LDS image:
+//   dWf[k] = x^T . df(shifted),  dWr = c^T . G       (tf.gradients of ops.py:27,39)
+// Element (c, kg, j) of a tile, at c*32 + kg*8 + j, is time step kordW(kg, j) of the tile: the order in which a
+// transposing LDS read (ds_read_b64_tr_b16: four rows per read) is free of bank conflicts at the image's row stride of
+// 36 dwords (rows 4 apart), and -- the only requirement -- the same for both operands of a product.
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ constexpr int kordW(int kg, int j) { return 16 * (kg >> 1) + 2 * (kg & 1) + (j >> 2) + 4 * (j & 3); }
+
+// 32 rows (time) x 16 columns (channels col0..col0+15) of a row-major LDS tile as a 16x16x32 fragment: lane l holds
+// column col0 + (l & 15), rows row0 + kordW(l >> 4, j)
+template <typename T> struct LdT16;
+template <> struct LdT16<bf16_t> {
+  static __device__ __forceinline__ Frag<bf16_t> load(const bf16_t* tile, int stride, int row0, int col0, int lane) {
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    const int kg = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const bf16_t* base = tile + (size_t)(row0 + 16 * (kg >> 1) + 2 * (kg & 1) + 4 * q) * stride + col0 + 4 * p;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + stride));
+    Frag<bf16_t> f;
+    f.v = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    return f;
+  }
+};
+template <> struct LdT16<float> {
+  static __device__ __forceinline__ Frag<float> load(const float* tile, int stride, int row0, int col0, int lane) {
+    const int kg = lane >> 4;
+    const float* base = tile + (size_t)row0 * stride + col0 + (lane & 15);
+    Frag<float> f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f.set(j, base[(size_t)kordW(kg, j) * stride]);
+    return f;
+  }
+};
+
+// The same fragment with the lane-dependent part of the address taken out of the loop over tiles: base() once per loop,
+// then one add of a wave-uniform row offset per tile and immediate offsets for the column block (the transposing read
+// itself is the only other instruction: the contraction loops are issue-bound, not LDS- or MFMA-bound).
+template <typename T> struct LdT16p;
+template <> struct LdT16p<bf16_t> {
+  static __device__ __forceinline__ const bf16_t* base(const bf16_t* tile, int stride, int lane) {
+    const int kg = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    return tile + (size_t)(16 * (kg >> 1) + 2 * (kg & 1) + 4 * q) * stride + 4 * p;
+  }
+  template <int STRIDE> static __device__ __forceinline__ Frag<bf16_t> load(const bf16_t* b, int col0) {
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(b + col0));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(b + col0 + STRIDE));
+    Frag<bf16_t> f;
+    f.v = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    return f;
+  }
+};
+template <> struct LdT16p<float> {
+  static __device__ __forceinline__ const float* base(const float* tile, int stride, int lane) {
+    const int kg = lane >> 4;
+    return tile + (size_t)(16 * (kg >> 1) + 2 * (kg & 1)) * stride + (lane & 15);
+  }
+  template <int STRIDE> static __device__ __forceinline__ Frag<float> load(const float* b, int col0) {
+    Frag<float> f;   // kordW(kg, j) - kordW(kg, 0) = (j >> 2) + 4 (j & 3)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f.set(j, b[col0 + ((j >> 2) + 4 * (j & 3)) * STRIDE]);
+    return f;
+  }
+};
+
+// one 16x16 output tile, 32-deep contraction (lane l: D row 4 (l >> 4) + r in register r, column l & 15)
+__device__ __forceinline__ void mma16(f32x4& acc, const Frag<bf16_t>& a, const Frag<bf16_t>& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma16(f32x4& acc, const Frag<float>& a, const Frag<float>& b) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.get(j), b.get(j), acc, 0, 0, 0);
+}
+
+// acc + sum_j f[j] * m[j]  (column sums over time for the bias gradients; m = 0/1 row mask in fragment form)
+__device__ __forceinline__ float frag_dot(float acc, const Frag<bf16_t>& f, const Frag<bf16_t>& m) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f.v, f.v, 0, 1), __builtin_shufflevector(m.v, m.v, 0, 1), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f.v, f.v, 2, 3), __builtin_shufflevector(m.v, m.v, 2, 3), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f.v, f.v, 4, 5), __builtin_shufflevector(m.v, m.v, 4, 5), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f.v, f.v, 6, 7), __builtin_shufflevector(m.v, m.v, 6, 7), acc, false);
+  return acc;
+}
+__device__ __forceinline__ float frag_dot(float acc, const Frag<float>& f, const Frag<float>& m) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc = fmaf(f.get(j), m.get(j), acc);
+  return acc;
+}
+
+// the fragment of channels c0..c0+15 of a weight-gradient tile in HBM, and its store
+template <typename T> __device__ __forceinline__ Frag<T> wt_load(const T* tile, int c0, int lane) {
+  return load_nat(tile + (size_t)(c0 + (lane & 15)) * 32 + (lane >> 4) * 8);
+}
+__device__ __forceinline__ void wt_store(bf16_t* tile, int c0, int lane, const Frag<bf16_t>& f) {
+  *reinterpret_cast<bf16x8*>(tile + (size_t)(c0 + (lane & 15)) * 32 + (lane >> 4) * 8) = f.v;
+}
+__device__ __forceinline__ void wt_store(float* tile, int c0, int lane, const Frag<float>& f) {
+  float* p = tile + (size_t)(c0 + (lane & 15)) * 32 + (lane >> 4) * 8;
+  *reinterpret_cast<f32x4*>(p) = f.lo;
+  *reinterpret_cast<f32x4*>(p + 4) = f.hi;
+}
+// rows [0, 32) of an LDS tile (R channels, row stride `stride`) -> a weight-gradient tile; time steps >= hi zeroed
+// (they belong to the neighbouring segment, or lie beyond the clip)
+template <typename T, int R>
+__device__ __forceinline__ void wt_store_tile(T* gtile, const T* rows, int stride, int hi, int lane) {
+#pragma unroll
+  for (int cb = 0; cb < R / 16; ++cb) {
+    Frag<T> f = LdT16<T>::load(rows, stride, 0, 16 * cb, lane);
+    if (hi < 32) {
+      const int kg = lane >> 4;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) if (kordW(kg, j) >= hi) f.set(j, 0.0f);
+    }
+    wt_store(gtile, 16 * cb, lane, f);
+  }
+}
+
 inline int num_cus() {
   static int cus = 0;
   if (cus == 0) {

@@ -46,6 +46,9 @@ struct GroupFwdArgs {
   int nsub;                       // segments per sub-sequence
   int nseg;                       // B * st * nsub
   unsigned long long* stamps;     // diagnostic builds only (srwn_debug_stamp_buffer): s_memtime stamps of workgroup 0
+  // weight-gradient tiles (srwn_group.h), WT instantiations only: the transposed layer input x_g and gate output c_g of
+  // the positions each segment owns, layer g at xT / cT + g*wt_stride, tile (seg, k) at ((seg*KT)+k)*R*32
+  void* xT; void* cT; int64_t wt_stride; int KT;
 };
 
 // In-kernel time stamps (MI355X guide, "In-kernel stamps"): lane 0 of waves 0 and 1 of workgroup 0 append the shader
@@ -61,7 +64,7 @@ template <> struct Stamper<true> {
   }
 };
 
-template <typename T, int RT, bool COND, int MAXT, int NWB, int NWV = 8, bool WDMA = true, bool STAMP = false>
+template <typename T, int RT, bool COND, int MAXT, int NWB, int NWV = 8, bool WDMA = true, bool STAMP = false, bool WT = false>
 __global__ __launch_bounds__(64 * NWV) void group_fwd_kernel(GroupFwdArgs a) {
   constexpr int R = 32 * RT, K = 2, KS = R / 16;
   constexpr int NCONV = RT * K * KS, NRES = RT * KS, NW = NCONV + NRES;   // weight fragments per layer
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(64 * NWV) void group_fwd_kernel(GroupFwdArgs a) {
   // vmcnt counts in issue order, so leaving that many operations outstanding retires the DMA without waiting for
   // the stores to be acknowledged.
   auto wstore = [&](int buf, int younger) {
-    constexpr int STP = 2 * NI;
+    constexpr int STP = 2 * NI + (WT ? R / 16 : 0);   // row stores of z and x (+ the c tile's pieces) per stored tile
     static_assert(MAXT <= 3 && 3 * STP < 64, "vmcnt immediates");
     if (!WDMA) {
       f32x4* dst = reinterpret_cast<f32x4*>(smem + (size_t)buf * WBYTES);
@@ -198,6 +201,20 @@ __global__ __launch_bounds__(64 * NWV) void group_fwd_kernel(GroupFwdArgs a) {
           src = src < 0 ? 0 : src;
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) tap0[m][ks] = load_nat(img + (size_t)src * LS + 16 * ks + 8 * half);
+          if (WT) {
+            // the layer's input of the tile's owned positions, transposed, for the backward pass's dWf (the image holds
+            // x_g of every row here; the halo is a whole number of tiles in this mode, so tile q is the segment's
+            // weight-gradient tile q - H/32)
+            const int k = q - a.H / 32;
+            int hi = Wseg - 32 * k;
+            hi = hi > 32 ? 32 : hi;
+            if (k >= 0 && hi > 0) {
+              int lw = lane;       // (opaque copy: the tile store's addresses are not worth a register across the layer)
+              asm volatile("" : "+v"(lw));
+              wt_store_tile<T, R>(reinterpret_cast<T*>(a.xT) + (size_t)g * a.wt_stride + ((size_t)seg * a.KT + k) * (R * 32),
+                                  img + (size_t)(32 * q) * LS, LS, hi, lw);
+            }
+          }
         }
       }
       if (NWB == 1 && g > 0) wstore(0, 0);
@@ -290,6 +307,23 @@ __global__ __launch_bounds__(64 * NWV) void group_fwd_kernel(GroupFwdArgs a) {
             }
           }
         }
+        if (WT && st_ok) {
+          // c = z sigmoid(z) of the tile, transposed, for the backward pass's dWr: through the tile's own rows like z
+          wave_lds_order();
+#pragma unroll
+          for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+              const Frag<T>& cfr = cf[2 * mt + (gq >> 1)];
+              const int e0 = 4 * (gq & 1);
+              store4(trow + (size_t)col * LS + 32 * mt + 8 * gq + 4 * half, cfr.get(e0), cfr.get(e0 + 1), cfr.get(e0 + 2), cfr.get(e0 + 3));
+            }
+          wave_lds_order();
+          int lw = lane;
+          asm volatile("" : "+v"(lw));
+          wt_store_tile<T, R>(reinterpret_cast<T*>(a.cT) + (size_t)g * a.wt_stride + ((size_t)seg * a.KT + (q - a.H / 32)) * (R * 32),
+                              trow, LS, 32, lw);
+        }
         stamp(14);
         // ---- 1x1 residual from registers, scaled residual add
         f32x16 accR[RT];
@@ -373,9 +407,22 @@ struct GroupBwdArgs {
   int sub[kMaxGroup];
   int nl, st, Tlen, B;
   int W, H, NT, nsub, nseg;
+  // WT instantiations (layer weight gradients summed in this launch): the forward kernel's weight-gradient tiles (layer g at
+  // xT / cT + g*wt_stride, tile (seg, k) at ((seg*KT)+k)*R*32) and the partial sums (layer g, slab s at ((g*nslabs)+s)*n
+  // floats, in the layout srwn_wgrad_layers writes); df is not stored, G only with write_all_g
+  const void* xT; const void* cT; int64_t wt_stride; int KT;
+  float* part_f; float* part_r; float* part_bf; float* part_br;
+  int nslabs, write_all_g;
+  int dbg;                        // timing experiments (SRWN_WT_DEBUG): 1 = skip the dWr contraction, 2 = skip the dWf one
 };
 
-template <typename T, int RT, bool DCS, int MAXT, int NWB, int NWV = 8>
+constexpr int kWtPadRows = 64;
+// Two ways of hiding the weight-gradient fragment loads behind the chain, both built and measured, both off: they need
+// registers the R = 64 kernels do not have (256 of 256 in use: every extra live value is a scratch access in a hot loop).
+constexpr bool kWtStagger = false;   // half of the waves contract dWf before their taps, half after
+constexpr bool kWtEarlyC = false;    // the next layer's first c^T fragments requested a phase early   // finite (zero) rows behind the image: the shifted tap of the last weight-gradient tile reads past it
+
+template <typename T, int RT, bool DCS, int MAXT, int NWB, int NWV = 8, bool WT = false>
 __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
   constexpr int R = 32 * RT, K = 2, KS = R / 16;
   constexpr int NCONV = RT * K * KS, NRES = RT * KS, NW = NCONV + NRES;
@@ -383,6 +430,7 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
   constexpr int LPR = R / VEC, RPI = 64 / LPR, NI = 32 / RPI;
   constexpr int WBYTES = NW * 64 * (int)sizeof(Frag<T>);
   constexpr int WPIECES = WBYTES / 16, CPIECES = NCONV * 64 * (int)sizeof(Frag<T>) / 16;
+  constexpr int KTMAX = NWV * MAXT;          // (WT) most weight-gradient tiles a segment can have
   typedef typename Raw4g<T>::type raw4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   Frag<T>* wbuf = reinterpret_cast<Frag<T>*>(smem);                       // [NWB][convT | resT]
@@ -399,7 +447,9 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
   };
   const int ntw = (a.NT - wave + NWV - 1) / NWV;  // tiles this wave owns: q = wave + NWV*m, m < ntw
 
+  int sit = -1;                                   // segments this workgroup has finished (WT: later ones add to its partial slab)
   for (int seg = blockIdx.x; seg < a.nseg; seg += gridDim.x) {
+    ++sit;
     const int per_clip = a.st * a.nsub;
     const int b = seg / per_clip;
     const int rem = seg - b * per_clip;
@@ -475,7 +525,15 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
     // ---- G of the group's top output (registers, accumulator layout), the top layer's weights
     // (kept in the storage type: what one launch per layer would read back from HBM; in fp32 mode that is exact)
     raw4 G[MAXT][RT][4];
+    Frag<T> acn[8];                 // (WT) c^T fragments of the next layer's dWr contraction, requested a phase early
     const int gtop = a.nl - 1;
+    if (WT) {
+      // every row the time contractions may touch must be finite: rows a layer has not (re)written only ever meet the zeroed
+      // (not owned) rows of the other operand, but 0 x NaN from stale LDS would poison a sum
+      f32x4* p = reinterpret_cast<f32x4*>(img);
+      for (int i = tid; i < (a.NT * 32 + kWtPadRows) * LS * (int)sizeof(T) / 16; i += 64 * NWV) p[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      wg_barrier();
+    }
     wload(gtop, 0);
 #pragma unroll
     for (int m = 0; m < MAXT; ++m) {
@@ -527,6 +585,125 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
       ntA = (a.H == 0 || ntA > a.NT) ? a.NT : ntA;
       ntB = (a.H == 0 || ntB > a.NT) ? a.NT : ntB;
 
+      // (WT) the wave's share of dWr_g: NBW 16 x 16 output blocks (16 rows of c channels x 16 G channels each)
+      constexpr int NIB = R / 16, NBLK = NIB * NIB;
+      constexpr int NBW = NBLK >= NWV ? NBLK / NWV : 1;
+      const bool active2 = NBLK >= NWV || wave < NBLK;
+      const int blk2 = wave * NBW, ib2 = blk2 / NIB, ob2 = blk2 - ib2 * NIB;
+      const size_t pslab = (size_t)g * a.nslabs + blockIdx.x;      // (WT) this workgroup's partial slab of layer g
+      const int ktn = (Wseg + 31) / 32;                            // (WT) weight-gradient tiles of the segment
+      if (WT) {
+        // ---- dWr_g = c_g^T . G_{g+1}, dbr_g = colsum(G_{g+1}) over the rows the segment owns.  The image is free between
+        // two layers: every wave parks G_{g+1} of its tiles there (rows beyond the owned ones zeroed), then the R x R sum is
+        // split by OUTPUT over the waves -- 16 x 16 blocks, c^T fragments straight from the forward kernel's tiles in HBM,
+        // G^T by transposing reads -- so a wave carries 4 accumulator registers per block instead of the whole sum.
+        const bool active = active2;
+        const int ib = ib2, ob0 = ob2;
+        f32x4 acc[NBW];
+        float bs[NBW];
+#pragma unroll
+        for (int bb = 0; bb < NBW; ++bb) { acc[bb] = f32x4{0.f, 0.f, 0.f, 0.f}; bs[bb] = 0.0f; }
+        int lw = lane;      // (opaque copy: keeps this block's lane-dependent addresses from being hoisted over the chain,
+        asm volatile("" : "+v"(lw));   //  where every register counts)
+        if (haveg) {
+#pragma unroll
+          for (int m = 0; m < MAXT; ++m) {
+            const int q = wave + NWV * m;
+            int hi = Wseg - 32 * q;
+            hi = hi > 32 ? 32 : hi;
+            if (q < a.NT && hi > 0) {
+              T* trow = img + (size_t)(32 * q) * LS;
+              const bool own = col < hi;
+              wave_lds_order();
+#pragma unroll
+              for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
+                  *reinterpret_cast<raw4*>(trow + (size_t)col * LS + 32 * mt + 8 * gq + 4 * half) = own ? G[m][mt][gq] : Raw4g<T>::zero();
+              wave_lds_order();
+              if (a.write_all_g && n > 0) {      // (the conditioned decoders sum G per frame: model.py:180)
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                  int rr = i * RPI + rsub;
+                  rr = rr < hi ? rr : hi - 1;
+                  const f32x4 v = *reinterpret_cast<const f32x4*>(trow + (size_t)rr * LS + piece * VEC);
+                  *reinterpret_cast<f32x4*>(gprev + grow(jbase + 32 * q + rr) * R + piece * VEC) = v;
+                }
+              }
+            }
+          }
+          wg_barrier();
+          if (active && !(a.dbg & 1)) {
+            const T* ct = reinterpret_cast<const T*>(a.cT) + (size_t)g * a.wt_stride + (size_t)seg * a.KT * (R * 32);
+            Frag<T> ones;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ones.set(j, 1.0f);
+            // eight tiles' fragments requested at a time, the next eight before the first are used: one or two HBM round
+            // trips per loop instead of one per tile (a chain of dependent round trips made this loop cost as much as the
+            // whole chain).  No branches inside: tiles beyond the segment's contribute a zero fragment.
+            const T* gbase = LdT16p<T>::base(img, LS, lw) + 16 * ob0;
+            Frag<T> av[8], bv[8];
+            if (kWtEarlyC && n > 0) {           // requested during the layer above
+#pragma unroll
+              for (int j = 0; j < 8; ++j) av[j] = acn[j];
+            } else {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) av[j] = wt_load(ct + (size_t)(j < ktn ? j : (ktn > 0 ? ktn - 1 : 0)) * (R * 32), 16 * ib, lw);
+            }
+#pragma unroll 1
+            for (int k0 = 0; k0 < ktn; k0 += 8) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                const int kn = k0 + 8 + j;
+                bv[j] = wt_load(ct + (size_t)(kn < ktn ? kn : ktn - 1) * (R * 32), 16 * ib, lw);
+              }
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                const int k = k0 + j;
+                if (k < ktn) {     // (wave-uniform)
+                  const T* pk = gbase + (size_t)(32 * k) * LS;
+#pragma unroll
+                  for (int bb = 0; bb < NBW; ++bb) {
+                    const Frag<T> bf = LdT16p<T>::template load<LS>(pk, 16 * bb);
+                    mma16(acc[bb], av[j], bf);
+                    if (ib == 0) bs[bb] = frag_dot(bs[bb], bf, ones);
+                  }
+                }
+                __builtin_amdgcn_sched_barrier(0);   // (left alone, the scheduler hoists all the transposing reads of the chunk: spills)
+              }
+#pragma unroll
+              for (int j = 0; j < 8; ++j) av[j] = bv[j];
+            }
+          }
+          wg_barrier();      // the image goes back to the chain
+        }
+        if (active) {
+          // one 16 x 16 block per accumulator: lane l holds rows 4 (l >> 4) + rr of column l & 15
+          float* pl = a.part_r + pslab * (R * R) + (size_t)(16 * ib + 4 * (lw >> 4)) * R + 16 * ob0 + (lw & 15);
+          float* pb = a.part_br + pslab * R + 16 * ob0 + (lw & 15);
+          if (sit > 0) {       // a later segment of this workgroup: its sums join the earlier ones (fixed order)
+#pragma unroll
+            for (int bb = 0; bb < NBW; ++bb) {
+#pragma unroll
+              for (int rr = 0; rr < 4; ++rr) acc[bb][rr] += pl[rr * R + 16 * bb];
+            }
+          }
+#pragma unroll
+          for (int bb = 0; bb < NBW; ++bb) {
+            if (!(a.dbg & 16)) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) pl[rr * R + 16 * bb] = acc[bb][rr];
+            }
+            if (ib == 0) {
+              float t = bs[bb];
+              t += __shfl_xor(t, 16, 64);
+              t += __shfl_xor(t, 32, 64);
+              if (lw < 16) pb[16 * bb] = (sit > 0 ? pb[16 * bb] : 0.0f) + t;
+            }
+          }
+        }
+      }
+
       // ---- phase A: df of every owned tile
 #pragma unroll
       for (int m = 0; m < MAXT; ++m) {
@@ -536,7 +713,7 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
         const bool ok = (jbase + 32 * q + col) < Jr;
         int hi = Wseg - 32 * q;
         hi = hi > 32 ? 32 : hi;
-        if (n > 0 && hi > 0) tile_store_raw(trow, gprev, q, hi, G[m]);   // G_{g+1}: complete since the last barrier
+        if (!WT && n > 0 && hi > 0) tile_store_raw(trow, gprev, q, hi, G[m]);   // G_{g+1}: complete since the last barrier
         raw4 zz[RT][4], dc0[RT][4];
         rows_put(trow, zr);
         acc_get(trow, zz);
@@ -572,11 +749,28 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
               dv[mt][4 * gq + e] = accC[mt][4 * gq + e] * dgate_df<T>(Raw4g<T>::get(zz[mt][gq], e));
-        tile_store(trow, dfg, q, hi, dv);
+        tile_store(trow, dfg, q, WT ? 0 : hi, dv);     // (WT: into the image only; its readers are all on the chip)
         __builtin_amdgcn_sched_barrier(0);   // keep the tile bodies apart: interleaving them only lengthens live ranges
       }
       wg_barrier();
 
+      // (WT) the wave's share of dWf_g: output blocks (tap, 16 rows of x channels, NBF x 16 df channels)
+      constexpr int NIB5 = R / 16, NBLK5 = NIB5 * NIB5;
+      constexpr int NBF = 2 * NBLK5 >= NWV ? 2 * NBLK5 / NWV : 1;
+      const bool active5 = WT && (2 * NBLK5 >= NWV || wave < 2 * NBLK5);
+      const int blk5 = wave * NBF, tap5 = blk5 / NBLK5, rem5 = blk5 - tap5 * NBLK5, ib5 = rem5 / NIB5, ob5 = rem5 - ib5 * NIB5;
+      int lw5 = lane;      // (opaque copy: keeps this block's lane-dependent addresses from being carried through the chain)
+      asm volatile("" : "+v"(lw5));
+      const T* xt5 = reinterpret_cast<const T*>(a.xT) + (size_t)g * a.wt_stride + (size_t)seg * a.KT * (R * 32);
+      if (kWtEarlyC && WT && g > 0 && active2) {
+        // the first eight c^T fragments of the layer BELOW (its dWr contraction opens that layer, between two barriers
+        // where nothing else can hide their latency) are requested now and arrive while the wave runs this layer's taps
+        const T* ctn = reinterpret_cast<const T*>(a.cT) + (size_t)(g - 1) * a.wt_stride + (size_t)seg * a.KT * (R * 32);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acn[j] = wt_load(ctn + (size_t)(j < ktn ? j : (ktn > 0 ? ktn - 1 : 0)) * (R * 32), 16 * ib2, lw5);
+      }
+
+      auto phaseB = [&]() {
       // ---- phase B: G_g = G_{g+1} sqrt(.5) + taps of df_g
 #pragma unroll
       for (int m = 0; m < MAXT; ++m) {
@@ -615,6 +809,94 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
             G[m][mt][gq] = Raw4g<T>::pack(accG[mt][4 * gq], accG[mt][4 * gq + 1], accG[mt][4 * gq + 2], accG[mt][4 * gq + 3]);
         __builtin_amdgcn_sched_barrier(0);
       }
+      };   // phaseB
+      auto dwf = [&]() {
+        // ---- dWf_g[k] = sum over the owned rows s of x_g[s] (x) df_g[s + (K-1-k) d], dbf_g = colsum(df_g): df_g is complete
+        // in the image since the barrier between the phases (its readers only read), x^T comes from the forward kernel's tiles
+        const bool active = active5;
+        const int tap = tap5, ib = ib5, ob0 = ob5;
+        if (active) {
+          const int lw = lw5;
+          const int shift = tap == 0 ? d : 0;             // tap 0 multiplies x[t - d]: row s of x meets row s + d of df
+          const bool bias = tap == 1 && ib == 0;
+          f32x4 acc[NBF];
+          float bs[NBF];
+#pragma unroll
+          for (int bb = 0; bb < NBF; ++bb) { acc[bb] = f32x4{0.f, 0.f, 0.f, 0.f}; bs[bb] = 0.0f; }
+          const T* xt = xt5;
+          const int ibl = (a.dbg & 8) ? 0 : ib;     // (timing experiment: every wave loads the same quarter of each tile)
+          const int ktl = (a.dbg & 2) ? 0 : ktn;
+          const int kfull = Wseg >> 5;                    // tiles the segment owns whole
+          Frag<T> ones5;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ones5.set(e, 1.0f);
+          const T* dbase = LdT16p<T>::base(img, LS, lw) + (size_t)shift * LS + 16 * ob0;
+          Frag<T> av[8], bv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) av[j] = wt_load(xt + (size_t)(j < ktn ? j : (ktn > 0 ? ktn - 1 : 0)) * (R * 32), 16 * ibl, lw);
+#pragma unroll 1
+          for (int k0 = 0; k0 < ktl; k0 += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const int kn = k0 + 8 + j;
+              bv[j] = wt_load(xt + (size_t)(kn < ktn ? kn : ktn - 1) * (R * 32), 16 * ibl, lw);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const int k = k0 + j;
+              if (k < ktn) {       // (wave-uniform)
+                const T* pk = dbase + (size_t)(32 * k) * LS;
+#pragma unroll
+                for (int bb = 0; bb < NBF; ++bb) {
+                  const Frag<T> bf = LdT16p<T>::template load<LS>(pk, 16 * bb);
+                  mma16(acc[bb], av[j], bf);
+                  if (bias && k < kfull) bs[bb] = frag_dot(bs[bb], bf, ones5);   // whole tiles; the ragged one below
+                }
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) av[j] = bv[j];
+          }
+          if (bias && (Wseg & 31) && Wseg > 0 && !(a.dbg & 2)) {   // dbf: the rows of the last, ragged tile the segment owns
+            const int hik = Wseg - 32 * kfull;
+            Frag<T> mk;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mk.set(e, kordW(lw >> 4, e) < hik ? 1.0f : 0.0f);
+#pragma unroll
+            for (int bb = 0; bb < NBF; ++bb)
+              bs[bb] = frag_dot(bs[bb], LdT16<T>::load(img, LS, 32 * kfull + shift, 16 * (ob0 + bb), lw), mk);
+          }
+          float* pl = a.part_f + pslab * (2 * R * R) + (size_t)tap * R * R + (size_t)(16 * ib + 4 * (lw >> 4)) * R + 16 * ob0 + (lw & 15);
+          float* pb = a.part_bf + pslab * R + 16 * ob0 + (lw & 15);
+          if (sit > 0) {
+#pragma unroll
+            for (int bb = 0; bb < NBF; ++bb) {
+#pragma unroll
+              for (int rr = 0; rr < 4; ++rr) acc[bb][rr] += pl[rr * R + 16 * bb];
+            }
+          }
+#pragma unroll
+          for (int bb = 0; bb < NBF; ++bb) {
+            if (!(a.dbg & 16)) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) pl[rr * R + 16 * bb] = acc[bb][rr];
+            }
+            if (bias) {
+              float t = bs[bb];
+              t += __shfl_xor(t, 16, 64);
+              t += __shfl_xor(t, 32, 64);
+              if (lw < 16) pb[16 * bb] = (sit > 0 ? pb[16 * bb] : 0.0f) + t;
+            }
+          }
+        }
+      };   // dwf
+      // Both only READ the image.  The contraction is a burst of HBM traffic (every x^T tile of the segment), the taps are
+      // issue-bound: half of the waves run one first, half the other, so each covers the other's idle resource.
+      // (Measured: the second copy of the two bodies and the longer live ranges cost 30-60 spilled registers in the R = 64
+      // kernels, which are at 256 already -- 0.74 -> 0.98 ms per step; off.)
+      if (kWtStagger && WT && wave < NWV / 2) { dwf(); phaseB(); }
+      else { phaseB(); if (WT) dwf(); }
       if (NWB == 2 && g > 0) dma_wait();
       wg_barrier();
     }
@@ -633,16 +915,36 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
 }
 
 unsigned long long* g_stamps = nullptr;
-template <typename T, int RT, int MAXT, int NWB, int NWV = 8, bool WDMA = true, bool STAMP = false>
+// tiles the forward / backward group kernels can hold per segment image (LDS and waves x tiles per wave)
+template <typename T, int RT, int MAXT, int NWB, int NWV> int fwd_nt_max() {
+  constexpr int R = 32 * RT, KS = R / 16, NW = RT * 2 * KS + RT * KS;
+  const size_t fixed = (size_t)NWB * NW * 64 * sizeof(Frag<T>) + (size_t)NWB * 2 * R * 4;
+  const size_t row_bytes = (size_t)RowStage<T>::stride(R) * sizeof(T);
+  const int nt = (int)((kLdsBudget - fixed) / (32 * row_bytes));
+  return nt > NWV * MAXT ? NWV * MAXT : nt;
+}
+template <typename T, int RT, int MAXT, int NWB, int NWV> int bwd_nt_max(bool wt) {
+  constexpr int R = 32 * RT, KS = R / 16, NW = RT * 2 * KS + RT * KS;
+  const size_t row_bytes = (size_t)RowStage<T>::stride(R) * sizeof(T);
+  const size_t fixed = (size_t)NWB * NW * 64 * sizeof(Frag<T>) + (wt ? (size_t)kWtPadRows * row_bytes : 0);
+  const int nt = (int)((kLdsBudget - fixed) / (32 * row_bytes));
+  return nt > NWV * MAXT ? NWV * MAXT : nt;
+}
+
+template <typename T, int RT, int MAXT, int NWB, int NWV = 8, bool WDMA = true, bool STAMP = false, bool WT = false>
 int launch_group_fwd(GroupFwdArgs& a, bool cond, int seg_rows, hipStream_t st) {
   constexpr int R = 32 * RT, KS = R / 16, NW = RT * 2 * KS + RT * KS;
   const size_t fixed = (size_t)NWB * NW * 64 * sizeof(Frag<T>) + (size_t)NWB * 2 * R * 4;
   const size_t row_bytes = (size_t)RowStage<T>::stride(R) * sizeof(T);
-  int nt_max = (int)((kLdsBudget - fixed) / (32 * row_bytes));
-  if (nt_max > NWV * MAXT) nt_max = NWV * MAXT;
+  const int nt_max = fwd_nt_max<T, RT, MAXT, NWB, NWV>();
+  if (WT) a.H = (a.H + 31) / 32 * 32;      // whole halo tiles: the compute tiles line up with the weight-gradient tiles
   if (nt_max * 32 - a.H < 32) return set_error(SRWN_E_UNSUPPORTED, "residual_group_fwd: halo %d too large", a.H);
   const int J = (a.Tlen + a.st - 1) / a.st;
   choose_segments(J, &a.H, a.B, a.st, nt_max, seg_rows, &a.W, &a.NT, &a.nsub);
+  if (WT) {
+    if (a.W != seg_rows) return set_error(SRWN_E_SHAPE, "residual_group_fwd_wt: seg_rows %d does not fit (use srwn_group_wt_geometry)", seg_rows);
+    a.KT = (a.W + 31) / 32;
+  }
   const long long nseg = (long long)a.B * a.st * a.nsub;
   if (nseg > 0x7fffffffLL) return set_error(SRWN_E_SHAPE, "residual_group_fwd: too many segments");
   a.nseg = (int)nseg;
@@ -651,7 +953,7 @@ int launch_group_fwd(GroupFwdArgs& a, bool cond, int seg_rows, hipStream_t st) {
   dim3 grid((unsigned)blocks), block(64 * NWV);
 #define SRWN_GF(C)                                                                                              \
   {                                                                                                             \
-    auto kfn = group_fwd_kernel<T, RT, C, MAXT, NWB, NWV, WDMA, STAMP>;                                                           \
+    auto kfn = group_fwd_kernel<T, RT, C, MAXT, NWB, NWV, WDMA, STAMP, WT>;                                     \
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);  \
     if (e != hipSuccess) return set_error((int)e, "residual_group_fwd: LDS %zu: %s", sh, hipGetErrorString(e)); \
     hipLaunchKernelGGL(kfn, grid, block, sh, st, a);                                                            \
@@ -661,13 +963,12 @@ int launch_group_fwd(GroupFwdArgs& a, bool cond, int seg_rows, hipStream_t st) {
 #undef SRWN_GF
 }
 
-template <typename T, int RT, int MAXT, int NWB, int NWV = 8>
+template <typename T, int RT, int MAXT, int NWB, int NWV = 8, bool WT = false>
 int launch_group_bwd(GroupBwdArgs& a, int seg_rows, hipStream_t st) {
   constexpr int R = 32 * RT, KS = R / 16, NW = RT * 2 * KS + RT * KS;
-  const size_t fixed = (size_t)NWB * NW * 64 * sizeof(Frag<T>);
   const size_t row_bytes = (size_t)RowStage<T>::stride(R) * sizeof(T);
-  int nt_max = (int)((kLdsBudget - fixed) / (32 * row_bytes));
-  if (nt_max > NWV * MAXT) nt_max = NWV * MAXT;
+  const size_t fixed = (size_t)NWB * NW * 64 * sizeof(Frag<T>) + (WT ? (size_t)kWtPadRows * row_bytes : 0);
+  const int nt_max = bwd_nt_max<T, RT, MAXT, NWB, NWV>(WT);
   if (nt_max * 32 - a.H < 32) return set_error(SRWN_E_UNSUPPORTED, "residual_group_bwd: halo %d too large", a.H);
   const int J = (a.Tlen + a.st - 1) / a.st;
   choose_segments(J, &a.H, a.B, a.st, nt_max, seg_rows, &a.W, &a.NT, &a.nsub);
@@ -676,6 +977,11 @@ int launch_group_bwd(GroupBwdArgs& a, int seg_rows, hipStream_t st) {
   a.nseg = (int)nseg;
   const size_t sh = fixed + (size_t)a.NT * 32 * row_bytes;
   long long blocks = nseg < num_cus() ? nseg : num_cus();
+  if (WT) {
+    if (a.W != seg_rows) return set_error(SRWN_E_SHAPE, "residual_group_bwd_wt: seg_rows %d does not fit (use srwn_group_wt_geometry)", seg_rows);
+    a.KT = (a.W + 31) / 32;
+    if (blocks > a.nslabs) return set_error(SRWN_E_SHAPE, "residual_group_bwd_wt: %lld workgroups but %d partial slabs", blocks, a.nslabs);
+  }
   dim3 grid((unsigned)blocks), block(64 * NWV);
   // segments of at most two tiles per wave (the halo-free residue-class groups: 16 tiles) run the two-tile body: 16 fewer
   // live registers for G, no third (empty) tile iteration
@@ -683,7 +989,7 @@ int launch_group_bwd(GroupBwdArgs& a, int seg_rows, hipStream_t st) {
   const bool two = MAXT > 2 && a.NT <= 2 * NWV;
 #define SRWN_GB(D)                                                                                              \
   {                                                                                                             \
-    auto kfn = two ? group_bwd_kernel<T, RT, D, MT2, NWB, NWV> : group_bwd_kernel<T, RT, D, MAXT, NWB, NWV>;                                                       \
+    auto kfn = two ? group_bwd_kernel<T, RT, D, MT2, NWB, NWV, WT> : group_bwd_kernel<T, RT, D, MAXT, NWB, NWV, WT>; \
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);  \
     if (e != hipSuccess) return set_error((int)e, "residual_group_bwd: LDS %zu: %s", sh, hipGetErrorString(e)); \
     hipLaunchKernelGGL(kfn, grid, block, sh, st, a);                                                            \
@@ -695,13 +1001,24 @@ int launch_group_bwd(GroupBwdArgs& a, int seg_rows, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int srwn_residual_group_bwd(const void* g_top, void* g_out, void* df_out, const void* z, const void* dcs,
-                                       int64_t layer_stride, const void* const* wconvT, const void* const* wresT,
-                                       const int32_t* dilations, int32_t nlayers, int32_t B, int32_t T, int32_t R,
-                                       int32_t K, int32_t seg_rows, int32_t dtype, void* stream) {
+namespace {
+struct WtBwd {   // the extra operands of srwn_residual_group_bwd_wt
+  const void* xT; const void* cT; int64_t wt_stride;
+  float* part_f; float* part_r; float* part_bf; float* part_br; int nslabs; int write_all_g;
+};
+}
+
+static int group_bwd_impl(const void* g_top, void* g_out, void* df_out, const void* z, const void* dcs,
+                          int64_t layer_stride, const void* const* wconvT, const void* const* wresT,
+                          const int32_t* dilations, int32_t nlayers, int32_t B, int32_t T, int32_t R,
+                          int32_t K, int32_t seg_rows, int32_t dtype, void* stream, const WtBwd* wt) {
   if (B == 0 || T == 0 || nlayers == 0) return 0;
-  if (!g_out || !df_out || !z || !wconvT || !wresT || !dilations)
+  if (!g_out || (!df_out && !wt) || !z || !wconvT || !wresT || !dilations)
     return set_error(SRWN_E_NULL, "residual_group_bwd: null pointer");
+  if (wt && (!wt->xT || !wt->cT || !wt->part_f || !wt->part_r || !wt->part_bf || !wt->part_br))
+    return set_error(SRWN_E_NULL, "residual_group_bwd_wt: null pointer");
+  if (wt && (seg_rows < 1 || wt->nslabs < 1 || wt->wt_stride < 0))
+    return set_error(SRWN_E_SHAPE, "residual_group_bwd_wt: seg_rows=%d nslabs=%d (take them from srwn_group_wt_geometry)", seg_rows, wt->nslabs);
   if (K != 2) return set_error(SRWN_E_UNSUPPORTED, "residual_group_bwd: filter_width %d (only 2 is built)", K);
   if (R != 32 && R != 64) return set_error(SRWN_E_UNSUPPORTED, "residual_group_bwd: dilation_channels %d (built: 32, 64)", R);
   if (nlayers < 0 || nlayers > kMaxGroup || B < 0 || T < 0 || seg_rows < 0)
@@ -710,6 +1027,13 @@ extern "C" int srwn_residual_group_bwd(const void* g_top, void* g_out, void* df_
   if (!g_top && !dcs) return set_error(SRWN_E_SHAPE, "residual_group_bwd: no top gradient and no skip path: every gradient would be zero");
   GroupBwdArgs a;
   a.g_top = g_top; a.g_out = g_out; a.df_out = df_out; a.z = z; a.dcs = dcs; a.layer_stride = layer_stride;
+  a.xT = a.cT = nullptr; a.wt_stride = 0; a.KT = 0; a.part_f = a.part_r = a.part_bf = a.part_br = nullptr; a.nslabs = 0; a.write_all_g = 0;
+  static const int wt_dbg = [] { const char* e = getenv("SRWN_WT_DEBUG"); return e ? atoi(e) : 0; }();
+  a.dbg = wt_dbg;
+  if (wt) {
+    a.xT = wt->xT; a.cT = wt->cT; a.wt_stride = wt->wt_stride; a.part_f = wt->part_f; a.part_r = wt->part_r;
+    a.part_bf = wt->part_bf; a.part_br = wt->part_br; a.nslabs = wt->nslabs; a.write_all_g = wt->write_all_g ? 1 : 0;
+  }
   for (int g = 0; g < kMaxGroup; ++g) {
     const bool in = g < nlayers;
     a.wconvT[g] = in ? wconvT[g] : nullptr; a.wresT[g] = in ? wresT[g] : nullptr;
@@ -721,6 +1045,17 @@ extern "C" int srwn_residual_group_bwd(const void* g_top, void* g_out, void* df_
     return set_error(SRWN_E_SHAPE, "residual_group_bwd: dilations must be >= 1");
   if (a.H > 63) return set_error(SRWN_E_UNSUPPORTED, "residual_group_bwd: halo %d > 63 (sum of dilations / their gcd)", a.H);
   hipStream_t st = (hipStream_t)stream;
+  if (wt) {
+    if (a.H > 31) return set_error(SRWN_E_UNSUPPORTED, "residual_group_bwd_wt: halo %d > 31 (sum of dilations / their gcd)", a.H);
+    if (dtype == SRWN_BF16) {
+      if (R == 32) return launch_group_bwd<bf16_t, 1, 3, 2, 8, true>(a, seg_rows, st);
+      return launch_group_bwd<bf16_t, 2, 3, 2, 8, true>(a, seg_rows, st);
+    } else if (dtype == SRWN_F32) {
+      if (R == 32) return launch_group_bwd<float, 1, 1, 1, 8, true>(a, seg_rows, st);
+      return launch_group_bwd<float, 2, 1, 1, 8, true>(a, seg_rows, st);
+    }
+    return set_error(SRWN_E_DTYPE, "residual_group_bwd_wt: dtype %d", dtype);
+  }
   if (dtype == SRWN_BF16) {
     if (R == 32) return launch_group_bwd<bf16_t, 1, 3, 2>(a, seg_rows, st);
     // (twelve waves of two tiles, as the forward kernel runs, need 65 spilled registers here: 0.56 -> 0.73 ms per step)
@@ -732,14 +1067,36 @@ extern "C" int srwn_residual_group_bwd(const void* g_top, void* g_out, void* df_
   return set_error(SRWN_E_DTYPE, "residual_group_bwd: dtype %d", dtype);
 }
 
-extern "C" int srwn_residual_group_fwd(const void* x0, void* x_out, void* z_out, int64_t layer_stride,
-                                       const void* const* wconv, const void* const* wres,
-                                       const float* const* bias_f, const float* const* bias_r,
-                                       const void* const* cond_next, int32_t cond_frames, int32_t pool_stride,
-                                       int32_t cond_row_stride, const int32_t* dilations, int32_t nlayers, int32_t B,
-                                       int32_t T, int32_t R, int32_t K, int32_t seg_rows, int32_t dtype,
-                                       void* stream) {
+extern "C" int srwn_residual_group_bwd(const void* g_top, void* g_out, void* df_out, const void* z, const void* dcs,
+                                       int64_t layer_stride, const void* const* wconvT, const void* const* wresT,
+                                       const int32_t* dilations, int32_t nlayers, int32_t B, int32_t T, int32_t R,
+                                       int32_t K, int32_t seg_rows, int32_t dtype, void* stream) {
+  return group_bwd_impl(g_top, g_out, df_out, z, dcs, layer_stride, wconvT, wresT, dilations, nlayers, B, T, R, K, seg_rows,
+                        dtype, stream, nullptr);
+}
+
+extern "C" int srwn_residual_group_bwd_wt(const void* g_top, void* g_out, int32_t write_all_g, const void* z,
+                                          const void* dcs, int64_t layer_stride, const void* xT, const void* cT,
+                                          int64_t wt_layer_stride, const void* const* wconvT, const void* const* wresT,
+                                          const int32_t* dilations, int32_t nlayers, float* part_f, float* part_r,
+                                          float* part_bf, float* part_br, int32_t nslabs, int32_t B, int32_t T,
+                                          int32_t R, int32_t K, int32_t seg_rows, int32_t dtype, void* stream) {
+  const WtBwd wt{xT, cT, wt_layer_stride, part_f, part_r, part_bf, part_br, nslabs, write_all_g};
+  return group_bwd_impl(g_top, g_out, nullptr, z, dcs, layer_stride, wconvT, wresT, dilations, nlayers, B, T, R, K, seg_rows,
+                        dtype, stream, &wt);
+}
+
+static int group_fwd_impl(const void* x0, void* x_out, void* z_out, int64_t layer_stride,
+                          const void* const* wconv, const void* const* wres,
+                          const float* const* bias_f, const float* const* bias_r,
+                          const void* const* cond_next, int32_t cond_frames, int32_t pool_stride,
+                          int32_t cond_row_stride, const int32_t* dilations, int32_t nlayers, int32_t B,
+                          int32_t T, int32_t R, int32_t K, int32_t seg_rows, int32_t dtype,
+                          void* stream, void* xT, void* cT, int64_t wt_stride) {
   if (B == 0 || T == 0 || nlayers == 0) return 0;
+  const bool wt = xT != nullptr || cT != nullptr;
+  if (wt && (!xT || !cT || seg_rows < 1 || wt_stride < 0))
+    return set_error(SRWN_E_SHAPE, "residual_group_fwd_wt: xT, cT and seg_rows (srwn_group_wt_geometry) are all required");
   if (!x0 || !x_out || !z_out || !wconv || !wres || !bias_f || !bias_r || !dilations)
     return set_error(SRWN_E_NULL, "residual_group_fwd: null pointer");
   if (K != 2) return set_error(SRWN_E_UNSUPPORTED, "residual_group_fwd: filter_width %d (only 2 is built)", K);
@@ -749,6 +1106,7 @@ extern "C" int srwn_residual_group_fwd(const void* x0, void* x_out, void* z_out,
   if (layer_stride < (int64_t)B * T * R) return set_error(SRWN_E_SHAPE, "residual_group_fwd: layer_stride %lld", (long long)layer_stride);
   GroupFwdArgs a;
   a.x0 = x0; a.x_out = x_out; a.z_out = z_out; a.layer_stride = layer_stride;
+  a.xT = xT; a.cT = cT; a.wt_stride = wt_stride; a.KT = 0;
   bool any_cond = false;
   for (int g = 0; g < kMaxGroup; ++g) {
     const bool in = g < nlayers;
@@ -773,6 +1131,19 @@ extern "C" int srwn_residual_group_fwd(const void* x0, void* x_out, void* z_out,
   // waves of three tiles leave ~30 % idle (forward groups 412 -> 377 us per step); sixteen (128 registers) spill.
   static const int gf_waves = [] { const char* e = getenv("SRWN_GF_WAVES"); const int v = e ? atoi(e) : 12; return (v == 8 || v == 16) ? v : 12; }();
   const bool waves16 = gf_waves == 16, waves12 = gf_waves == 12;
+  if (wt) {      // the weight-gradient tiles of x and c written as well (one instantiation per dtype / width)
+    if (a.H > 31) return set_error(SRWN_E_UNSUPPORTED, "residual_group_fwd_wt: halo %d > 31 (sum of dilations / their gcd)", a.H);
+    if (dtype == SRWN_BF16) {
+      if (R == 32) return launch_group_fwd<bf16_t, 1, 3, 2, 8, true, false, true>(a, any_cond, seg_rows, st);
+      static const int wtw = [] { const char* e = getenv("SRWN_GF_WT_WAVES"); return e ? atoi(e) : 8; }();   // (twelve waves of 168 registers spill 30-47 of them with the tile stores: 0.43 vs 0.38 ms per step)
+      if (wtw == 8) return launch_group_fwd<bf16_t, 2, 3, 2, 8, true, false, true>(a, any_cond, seg_rows, st);
+      return launch_group_fwd<bf16_t, 2, 2, 2, 12, true, false, true>(a, any_cond, seg_rows, st);
+    } else if (dtype == SRWN_F32) {
+      if (R == 32) return launch_group_fwd<float, 1, 1, 1, 8, true, false, true>(a, any_cond, seg_rows, st);
+      return launch_group_fwd<float, 2, 1, 1, 8, true, false, true>(a, any_cond, seg_rows, st);
+    }
+    return set_error(SRWN_E_DTYPE, "residual_group_fwd_wt: dtype %d", dtype);
+  }
   if (dtype == SRWN_BF16) {
     if (R == 32) return launch_group_fwd<bf16_t, 1, 3, 2>(a, any_cond, seg_rows, st);
     if (g_stamps) { a.stamps = g_stamps; return launch_group_fwd<bf16_t, 2, 3, 2, 8, true, true>(a, any_cond, seg_rows, st); }
@@ -786,6 +1157,66 @@ extern "C" int srwn_residual_group_fwd(const void* x0, void* x_out, void* z_out,
     return launch_group_fwd<float, 2, 1, 1>(a, any_cond, seg_rows, st);
   }
   return set_error(SRWN_E_DTYPE, "residual_group_fwd: dtype %d", dtype);
+}
+
+extern "C" int srwn_residual_group_fwd(const void* x0, void* x_out, void* z_out, int64_t layer_stride,
+                                       const void* const* wconv, const void* const* wres,
+                                       const float* const* bias_f, const float* const* bias_r,
+                                       const void* const* cond_next, int32_t cond_frames, int32_t pool_stride,
+                                       int32_t cond_row_stride, const int32_t* dilations, int32_t nlayers, int32_t B,
+                                       int32_t T, int32_t R, int32_t K, int32_t seg_rows, int32_t dtype,
+                                       void* stream) {
+  return group_fwd_impl(x0, x_out, z_out, layer_stride, wconv, wres, bias_f, bias_r, cond_next, cond_frames, pool_stride,
+                        cond_row_stride, dilations, nlayers, B, T, R, K, seg_rows, dtype, stream, nullptr, nullptr, 0);
+}
+
+extern "C" int srwn_residual_group_fwd_wt(const void* x0, void* x_out, void* z_out, int64_t layer_stride, void* xT,
+                                          void* cT, int64_t wt_layer_stride, const void* const* wconv,
+                                          const void* const* wres, const float* const* bias_f,
+                                          const float* const* bias_r, const void* const* cond_next,
+                                          int32_t cond_frames, int32_t pool_stride, int32_t cond_row_stride,
+                                          const int32_t* dilations, int32_t nlayers, int32_t B, int32_t T, int32_t R,
+                                          int32_t K, int32_t seg_rows, int32_t dtype, void* stream) {
+  if (!xT || !cT) return (B == 0 || T == 0 || nlayers == 0) ? 0 : set_error(SRWN_E_NULL, "residual_group_fwd_wt: null pointer");
+  return group_fwd_impl(x0, x_out, z_out, layer_stride, wconv, wres, bias_f, bias_r, cond_next, cond_frames, pool_stride,
+                        cond_row_stride, dilations, nlayers, B, T, R, K, seg_rows, dtype, stream, xT, cT, wt_layer_stride);
+}
+
+// The segment cut both _wt kernels of a group must be given (seg_rows_in = 0: the library's choice), the weight-gradient
+// tiles per segment, the elements of one layer's xT (= cT) buffer and the partial slabs per layer the backward launch writes.
+extern "C" int srwn_group_wt_geometry(const int32_t* dilations, int32_t nlayers, int32_t B, int32_t T, int32_t R,
+                                      int32_t dtype, int32_t seg_rows_in, int32_t* seg_rows, int32_t* tiles_per_seg,
+                                      int64_t* elems_per_layer, int32_t* nslabs) {
+  if (!dilations || nlayers < 1 || nlayers > kMaxGroup || B < 1 || T < 1 || seg_rows_in < 0)
+    return set_error(SRWN_E_SHAPE, "group_wt_geometry: nlayers=%d B=%d T=%d", nlayers, B, T);
+  if (R != 32 && R != 64) return set_error(SRWN_E_UNSUPPORTED, "group_wt_geometry: dilation_channels %d (built: 32, 64)", R);
+  int st = 0, H = 0, sub[kMaxGroup];
+  if (group_geometry(dilations, nlayers, &st, sub, &H) != 0) return set_error(SRWN_E_SHAPE, "group_wt_geometry: dilations must be >= 1");
+  if (H > 31) return set_error(SRWN_E_UNSUPPORTED, "group_wt_geometry: halo %d > 31", H);
+  int ntf, ntb;
+  if (dtype == SRWN_BF16) {
+    ntf = R == 32 ? fwd_nt_max<bf16_t, 1, 3, 2, 8>() : fwd_nt_max<bf16_t, 2, 2, 2, 12>();   // (= the 8 x 3 variant's)
+    ntb = R == 32 ? bwd_nt_max<bf16_t, 1, 3, 2, 8>(true) : bwd_nt_max<bf16_t, 2, 3, 2, 8>(true);
+  } else if (dtype == SRWN_F32) {
+    ntf = R == 32 ? fwd_nt_max<float, 1, 1, 1, 8>() : fwd_nt_max<float, 2, 1, 1, 8>();
+    ntb = R == 32 ? bwd_nt_max<float, 1, 1, 1, 8>(true) : bwd_nt_max<float, 2, 1, 1, 8>(true);
+  } else {
+    return set_error(SRWN_E_DTYPE, "group_wt_geometry: dtype %d", dtype);
+  }
+  if (H > 0) ntf -= 1;                      // the forward kernel rounds its halo up to a whole tile
+  const int nt = ntf < ntb ? ntf : ntb;
+  if (nt * 32 - H < 32) return set_error(SRWN_E_UNSUPPORTED, "group_wt_geometry: halo %d too large", H);
+  const int J = (T + st - 1) / st;
+  int W, NT, nsub, Hc = H;
+  choose_segments(J, &Hc, B, st, nt, seg_rows_in, &W, &NT, &nsub);
+  const long long nseg = (long long)B * st * nsub;
+  if (nseg > 0x7fffffffLL) return set_error(SRWN_E_SHAPE, "group_wt_geometry: too many segments");
+  const int KT = (W + 31) / 32;
+  if (seg_rows) *seg_rows = W;
+  if (tiles_per_seg) *tiles_per_seg = KT;
+  if (elems_per_layer) *elems_per_layer = (int64_t)nseg * KT * R * 32;
+  if (nslabs) *nslabs = (int32_t)(nseg < num_cus() ? nseg : num_cus());
+  return 0;
 }
 
 // how the layers of a stack are grouped for the fused kernels: greedy runs whose halo stays <= max_halo and whose

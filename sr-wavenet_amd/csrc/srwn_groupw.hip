@@ -98,21 +98,6 @@ template <> struct LdT<float> {
 };
 __device__ __forceinline__ constexpr int kordT(int h, int j) { return 2 * h + (j >> 2) + 4 * (j & 3); }
 
-// acc + sum_j f[j] * m[j]  (column sums over time for the bias gradients; m = 0/1 row mask in fragment form)
-__device__ __forceinline__ float frag_dot(float acc, const Frag<bf16_t>& f, const Frag<bf16_t>& m) {
-  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f.v, f.v, 0, 1), __builtin_shufflevector(m.v, m.v, 0, 1), acc, false);
-  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f.v, f.v, 2, 3), __builtin_shufflevector(m.v, m.v, 2, 3), acc, false);
-  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f.v, f.v, 4, 5), __builtin_shufflevector(m.v, m.v, 4, 5), acc, false);
-  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f.v, f.v, 6, 7), __builtin_shufflevector(m.v, m.v, 6, 7), acc, false);
-  return acc;
-}
-__device__ __forceinline__ float frag_dot(float acc, const Frag<float>& f, const Frag<float>& m) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j) acc = fmaf(f.get(j), m.get(j), acc);
-  return acc;
-}
-
 // WGM: which sums this instantiation keeps (1 = dWr + dbr, 2 = dWf[0], 4 = dWf[1] + dbf).  bf16 keeps all three;
 // fp32 fragments are twice the registers, so the exact-fp32 mode runs the launch once per sum (the chain is repeated).
 template <typename T, int RT, bool DCS, int MAXT, int NWB, int NWV, int WGM, bool STAMP = false>

@@ -115,6 +115,10 @@ class WaveNetEngine:
         # df and G never reach HBM (-1.9 GB per step), but the kernel is slower than the chain kernel + the separate
         # weight-gradient pass it replaces (182 vs 83 + 77 us per group) -> off by default
         self.fuse_wg = _os.environ.get("SRWN_FUSE_WG", "0") != "0"
+        # SRWN_FUSE_WT=1 (default): layer weight gradients inside the 8-wave backward group kernel, split by output over
+        # the waves; the forward group kernel writes the transposed operands ("weight-gradient tiles") they need
+        # (csrc/srwn_group.hip, _wt entry points).  0: chain kernel + separate weight-gradient pass (the parity twin)
+        self.fuse_wt = _os.environ.get("SRWN_FUSE_WT", "1") != "0"
         # weight-gradient passes on a side stream beside the data-gradient chain: worth 11 % with one launch per layer
         # (short latency-bound chain kernels), but with the group kernels every kernel of the backward phase is
         # bandwidth-bound and running two at once is slower than one after the other (2.15 vs 2.13 ms; the skip data
@@ -396,7 +400,16 @@ class WaveNetEngine:
         self.use_wl = (R in (32, 64) and self.Kw == 2)
         self.use_dcs = (R, self.S) in ((64, 256), (32, 128))
         import os as _os
-        if self.fused_wg:
+        if self.fused_wt:
+            # weight-gradient tiles of every layer (written by the forward group kernels, read by the backward ones) and one
+            # partial slab per workgroup of the backward kernels (slabs a group does not reach stay zero)
+            geo = [K.group_wt_geometry(self.dil[l0:l1], B, T, R, self.dt, self.seg_rows) for l0, l1 in self.groups]
+            self.wt_seg_rows = [g[0] for g in geo]
+            wt_elems = max(g[2] for g in geo)
+            self.xTs = z(L, wt_elems)
+            self.cTs = z(L, wt_elems)
+            self.nslabs = max(g[3] for g in geo)
+        elif self.fused_wg:
             # one partial per workgroup of the fused backward kernel (slabs it does not reach stay zero)
             self.nslabs = K.group_wgrad_slabs()
         elif self.use_wl and self.fuse_bwd and "SRWN_WG_SLAB_ROWS" not in _os.environ and self.groups:
@@ -556,7 +569,7 @@ class WaveNetEngine:
         """The residual layers (model.py:42-47 / 176-189 / 428-453): xs[0] -> xs[1..L], zs[0..L-1]."""
         if self.fuse_fwd:
             for l0, l1 in self.groups:      # runs of layers whose outputs travel between layers in LDS
-                if l1 - l0 >= 2:
+                if l1 - l0 >= 2 or self.fused_wt:
                     self._group_fwd(l0, l1, cond_all)
                 else:
                     self._layer_fwd(l0, cond_all)
@@ -571,12 +584,16 @@ class WaveNetEngine:
         if cond_all is not None:
             cond3 = cond_all.view(self.B, self.frames, self.L * self.R)
             offs = [(l + 1) * self.R if l + 1 < self.L else None for l in range(l0, l1)]
+        wt = {}
+        if self.fused_wt:
+            wt = dict(xT=self.xTs[l0:l1], cT=self.cTs[l0:l1])
         K.residual_group_fwd(self.xs[l0], self.xs[l0 + 1:l1 + 1], self.zs[l0:l1],
                              [self.wptr(self.o_conv[l]) for l in range(l0, l1)],
                              [self.wptr(self.o_res[l]) for l in range(l0, l1)],
                              [v("BF")[l] for l in range(l0, l1)], [v("BR")[l] for l in range(l0, l1)],
                              self.dil[l0:l1], self.Kw, cond=cond3, cond_channel_offsets=offs,
-                             pool_stride=self.cfg.pool_stride, seg_rows=self.seg_rows)
+                             pool_stride=self.cfg.pool_stride,
+                             seg_rows=self.wt_seg_rows[self.groups.index((l0, l1))] if self.fused_wt else self.seg_rows, **wt)
 
     def _layer_fwd(self, l: int, cond_all: Optional[torch.Tensor]):
         v = self.view
@@ -625,6 +642,9 @@ class WaveNetEngine:
             for l0, l1 in reversed(self.groups):
                 if l0 > l_hi or l0 < l_lo:
                     continue
+                if self.fused_wt:
+                    self._group_bwd_wt(l0, l1)
+                    continue
                 if self.fused_wg:
                     self._group_bwd_wg(l0, l1)
                     continue
@@ -641,7 +661,7 @@ class WaveNetEngine:
                 if overlap:
                     main.wait_stream(side)
                 return
-            if self.timing and not self.fused_wg:
+            if self.timing and not (self.fused_wg or self.fused_wt):
                 for g in groups:
                     self._wgrad_layers_group(*g)
             with torch.cuda.stream(side):
@@ -697,8 +717,28 @@ class WaveNetEngine:
 
     @property
     def fused_wg(self) -> bool:
-        """The layer weight gradients are summed inside the backward group kernel (no df / G round trip)."""
-        return self.fuse_wg and self.fused_bwd
+        """The layer weight gradients are summed inside the one-wave-per-SIMD backward group kernel (srwn_groupw.hip)."""
+        return self.fuse_wg and self.fused_bwd and not self.fused_wt
+
+    @property
+    def fused_wt(self) -> bool:
+        """The layer weight gradients are summed inside the backward group kernel from the forward kernel's weight-gradient
+        tiles (no df / G round trip through HBM, no separate weight-gradient pass)."""
+        return self.fuse_wt and self.fuse_fwd and self.fused_bwd
+
+    def _group_bwd_wt(self, l0: int, l1: int):
+        """Chain + weight-gradient partials of layers [l0, l1) in one launch (srwn_residual_group_bwd_wt)."""
+        flow = self.cfg.head_mode == "flow"
+        R, ns = self.R, self.nslabs
+        g_top = self.gs[l1] if (flow or l1 < self.L) else None
+        with _Span(self, "group_bwd_wt"):
+            K.residual_group_bwd_wt(g_top, self.gs[l0:l1], self.zs[l0:l1], None if flow else self.dcs[l0:l1],
+                                    self.xTs[l0:l1], self.cTs[l0:l1],
+                                    [self.wptr(self.o_convT[l]) for l in range(l0, l1)],
+                                    [self.wptr(self.o_resT[l]) for l in range(l0, l1)], self.dil[l0:l1],
+                                    self.pl_f[l0 * ns * 2 * R * R:], self.pl_r[l0 * ns * R * R:],
+                                    self.pl_bf[l0 * ns * R:], self.pl_br[l0 * ns * R:], ns,
+                                    self.wt_seg_rows[self.groups.index((l0, l1))], self.Kw, write_all_g=bool(self.E))
 
     def _group_bwd_wg(self, l0: int, l1: int):
         """Chain + weight-gradient partials of layers [l0, l1) in one launch (srwn_residual_group_bwd_wgrad)."""

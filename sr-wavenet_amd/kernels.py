@@ -198,9 +198,12 @@ def _ptr_array(ptrs):
 
 def residual_group_fwd(x0: torch.Tensor, x_out: torch.Tensor, z_out: torch.Tensor, wconv_ptrs, wres_ptrs,
                        biases_f, biases_r, dilations, K: int = 2, cond: Optional[torch.Tensor] = None,
-                       cond_channel_offsets=None, pool_stride: int = 1, seg_rows: int = 0):
+                       cond_channel_offsets=None, pool_stride: int = 1, seg_rows: int = 0,
+                       xT: Optional[torch.Tensor] = None, cT: Optional[torch.Tensor] = None):
     """x_out / z_out: [n,B,T,R] stacks (views of the engine's xs[l0+1:], zs[l0:]); cond: [B, frames, C] whose channels
-    [cond_channel_offsets[g], +R) hold the bias of the layer above layer g (None entries: no add)."""
+    [cond_channel_offsets[g], +R) hold the bias of the layer above layer g (None entries: no add).
+    xT / cT ([>=n, elems] each, `group_wt_geometry`): also write the layers' weight-gradient tiles (seg_rows from the same
+    geometry call)."""
     import ctypes as C
     B, T, R = x0.shape
     n = len(dilations)
@@ -226,9 +229,69 @@ def residual_group_fwd(x0: torch.Tensor, x_out: torch.Tensor, z_out: torch.Tenso
                 raise ValueError("cond channel offset %r outside %d channels" % (o, cstride))
         pcs = _ptr_array([None if o is None else cond.data_ptr() + o * cond.element_size() for o in offs])
     dl = (C.c_int32 * n)(*[int(d) for d in dilations])
+    if xT is not None or cT is not None:
+        for name, t in (("xT", xT), ("cT", cT)):
+            _chk(t, name, x0.dtype)
+            if t.dim() != 2 or t.shape[0] < n:
+                raise ValueError("%s: shape %s, expected [>=%d, elems]" % (name, tuple(t.shape), n))
+        if xT.shape[1] != cT.shape[1]:
+            raise ValueError("xT / cT: layer strides differ")
+        call("srwn_residual_group_fwd_wt", px, x_out.data_ptr(), z_out.data_ptr(), B * T * R, xT.data_ptr(), cT.data_ptr(),
+             int(xT.shape[1]), _ptr_array(wconv_ptrs), _ptr_array(wres_ptrs), _ptr_array(pbf), _ptr_array(pbr), pcs,
+             frames, int(pool_stride), int(cstride), dl, n, B, T, R, int(K), int(seg_rows), dt, _stream())
+        return
     call("srwn_residual_group_fwd", px, x_out.data_ptr(), z_out.data_ptr(), B * T * R, _ptr_array(wconv_ptrs),
          _ptr_array(wres_ptrs), _ptr_array(pbf), _ptr_array(pbr), pcs, frames, int(pool_stride), int(cstride), dl, n,
          B, T, R, int(K), int(seg_rows), dt, _stream())
+
+
+def group_wt_geometry(dilations, B: int, T: int, R: int, dtype: torch.dtype, seg_rows: int = 0):
+    """(seg_rows, tiles per segment, elements of one layer's xT / cT buffer, partial slabs per layer) of a layer group in
+    the weight-gradient-tile mode: the cut both of its _wt kernels must be given."""
+    import ctypes as C
+    n = len(dilations)
+    dl = (C.c_int32 * n)(*[int(d) for d in dilations])
+    sr, kt, ns, el = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int64(0)
+    call("srwn_group_wt_geometry", dl, n, int(B), int(T), int(R), abi_dtype(dtype), int(seg_rows), C.byref(sr), C.byref(kt),
+         C.byref(el), C.byref(ns))
+    return sr.value, kt.value, el.value, ns.value
+
+
+def residual_group_bwd_wt(g_top: Optional[torch.Tensor], g_out: torch.Tensor, z: torch.Tensor, dcs: Optional[torch.Tensor],
+                          xT: torch.Tensor, cT: torch.Tensor, wconvT_ptrs, wresT_ptrs, dilations, part_f: torch.Tensor,
+                          part_r: torch.Tensor, part_bf: torch.Tensor, part_br: torch.Tensor, nslabs: int, seg_rows: int,
+                          K: int = 2, write_all_g: bool = False):
+    """Backward chain of a layer group + its layer weight-gradient partials in one launch (8 waves, output-split; the A
+    operands are the forward kernel's weight-gradient tiles xT / cT [>=n, elems]).  g_out / z / dcs: [n,B,T,R] stacks;
+    part_*: fp32 partial buffers starting at the group's first layer, [n][nslabs][2RR | RR | R | R]."""
+    import ctypes as C
+    n = len(dilations)
+    _, B, T, R = z.shape
+    if not (len(wconvT_ptrs) == len(wresT_ptrs) == n):
+        raise ValueError("residual_group_bwd_wt: per-layer argument lists differ in length")
+    dt = abi_dtype(z.dtype)
+    for name, t in (("z", z),) + ((("dcs", dcs),) if dcs is not None else ()):
+        _chk(t, name, z.dtype)
+        if t.dim() != 4 or t.shape[0] < n or tuple(t.shape[1:]) != (B, T, R):
+            raise ValueError("%s: shape %s, expected [>=%d,%d,%d,%d]" % (name, tuple(t.shape), n, B, T, R))
+    _chk(g_out, "g_out", z.dtype)
+    if g_out.dim() != 4 or g_out.shape[0] < (n if write_all_g else 1) or tuple(g_out.shape[1:]) != (B, T, R):
+        raise ValueError("g_out: shape %s" % (tuple(g_out.shape),))
+    for name, t in (("xT", xT), ("cT", cT)):
+        _chk(t, name, z.dtype)
+        if t.dim() != 2 or t.shape[0] < n:
+            raise ValueError("%s: shape %s, expected [>=%d, elems]" % (name, tuple(t.shape), n))
+    for name, t, per in (("part_f", part_f, 2 * R * R), ("part_r", part_r, R * R), ("part_bf", part_bf, R),
+                         ("part_br", part_br, R)):
+        _chk(t, name, torch.float32)
+        if t.numel() < n * nslabs * per:
+            raise ValueError("%s: %d floats, needs %d" % (name, t.numel(), n * nslabs * per))
+    pg = _opt(g_top, "g_top", z.dtype, (B, T, R))
+    dl = (C.c_int32 * n)(*[int(d) for d in dilations])
+    call("srwn_residual_group_bwd_wt", pg, g_out.data_ptr(), 1 if write_all_g else 0, z.data_ptr(),
+         None if dcs is None else dcs.data_ptr(), B * T * R, xT.data_ptr(), cT.data_ptr(), int(xT.shape[1]),
+         _ptr_array(wconvT_ptrs), _ptr_array(wresT_ptrs), dl, n, part_f.data_ptr(), part_r.data_ptr(),
+         part_bf.data_ptr(), part_br.data_ptr(), int(nslabs), B, T, R, int(K), int(seg_rows), dt, _stream())
 
 
 def residual_group_bwd(g_top: Optional[torch.Tensor], g_out: torch.Tensor, df_out: torch.Tensor, z: torch.Tensor,

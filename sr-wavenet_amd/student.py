@@ -206,7 +206,10 @@ class FlowStack(WaveNetEngine):
         group_lo = {g[0]: g for g in groups}
         with _Span(self, "flow_bwd_layers"):
             for l0, l1 in (reversed(self.groups) if self.fused_bwd else ()):   # one launch per layer group
-                if self.fused_wg:       # ... that also sums the group's weight gradients (csrc/srwn_groupw.hip)
+                if self.fused_wt:       # ... that also sums the group's weight gradients (srwn_residual_group_bwd_wt)
+                    self._group_bwd_wt(l0, l1)
+                    continue
+                if self.fused_wg:
                     self._group_bwd_wg(l0, l1)
                     continue
                 self._group_bwd(l0, l1)
