@@ -143,7 +143,9 @@ int srwn_residual_group_bwd_wgrad(const void* g_top, void* g_out, int32_t write_
  * The two kernels of a group are given the SAME segment cut (srwn_group_wt_geometry).  srwn_residual_group_fwd_wt is
  * srwn_residual_group_fwd that also writes, per layer g of the group and per 32-step tile of every segment, the
  * TRANSPOSED layer input x_g and gate output c_g = z_g sigmoid(z_g) ("weight-gradient tiles", [channel][32 steps],
- * layer g at xT / cT + g*wt_layer_stride elements; steps a segment does not own are zero in xT).
+ * layer g at xT / cT + g*wt_layer_stride elements; steps a segment does not own are zero in xT).  With
+ * store_inner_x = 0 only the group's top layer stores its output rows (x_out + (nlayers-1)*layer_stride): in this mode
+ * nothing reads the inner layers' (their transposed copies feed the weight gradients).
  * srwn_residual_group_bwd_wt is the chain of srwn_residual_group_bwd which, per layer, additionally contracts over time
  *   part_r [g][slab][i][o]     = sum c_g[t,i] * G_{g+1}[t,o]      part_br[g][slab][o] = sum G_{g+1}[t,o]
  *   part_f [g][slab][k*R+i][o] = sum x_g[t-(1-k)*d_g,i] * df_g[t,o]   part_bf[g][slab][o] = sum df_g[t,o]
@@ -157,7 +159,7 @@ int srwn_group_wt_geometry(const int32_t* dilations, int32_t nlayers, int32_t B,
                            int32_t seg_rows_in, int32_t* seg_rows, int32_t* tiles_per_seg, int64_t* elems_per_layer,
                            int32_t* nslabs);
 int srwn_residual_group_fwd_wt(const void* x0, void* x_out, void* z_out, int64_t layer_stride, void* xT, void* cT,
-                               int64_t wt_layer_stride, const void* const* wconv, const void* const* wres,
+                               int64_t wt_layer_stride, int32_t store_inner_x, const void* const* wconv, const void* const* wres,
                                const float* const* bias_f, const float* const* bias_r, const void* const* cond_next,
                                int32_t cond_frames, int32_t pool_stride, int32_t cond_row_stride,
                                const int32_t* dilations, int32_t nlayers, int32_t B, int32_t T, int32_t R, int32_t K,

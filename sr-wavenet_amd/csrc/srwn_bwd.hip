@@ -702,7 +702,7 @@ __global__ __launch_bounds__(256) void reduce_partials_multi_kernel(RpMulti m) {
   const int l = (int)(b / job.blocks_x);
   const int nslabs = job.nslabs;
   const int64_t n = job.n;
-  if (job.wide) {
+  if (job.wide == 1) {
     const int64_t i = (int64_t)bx * 16 + (threadIdx.x >> 4);
     const int sub = threadIdx.x & 15;
     double s = 0.0;
@@ -713,6 +713,28 @@ __global__ __launch_bounds__(256) void reduce_partials_multi_kernel(RpMulti m) {
 #pragma unroll
     for (int w = 8; w > 0; w >>= 1) s += __shfl_xor(s, w, 64);
     if (i < n && sub == 0) job.out[(int64_t)l * job.out_batch_stride + i] = (float)(s * (double)job.scale);
+  } else if (job.wide == 2) {
+    // many slabs of a large block (the fused backward kernels leave one slab per workgroup): four outputs per thread, 16-byte
+    // loads, eight slabs in flight; every output is still summed slab by slab in order (same bits as one output per thread)
+    const int64_t i = ((int64_t)bx * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    const float* p = job.partials + (int64_t)l * job.part_batch_mul * nslabs * n + i;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int q = 0;
+    for (; q + 8 <= nslabs; q += 8) {
+      srwn::f32x4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const srwn::f32x4*>(p + (int64_t)(q + j) * n);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s0 += (double)v[j][0]; s1 += (double)v[j][1]; s2 += (double)v[j][2]; s3 += (double)v[j][3]; }
+    }
+    for (; q < nslabs; ++q) {
+      const srwn::f32x4 v = *reinterpret_cast<const srwn::f32x4*>(p + (int64_t)q * n);
+      s0 += (double)v[0]; s1 += (double)v[1]; s2 += (double)v[2]; s3 += (double)v[3];
+    }
+    const double sc = (double)job.scale;
+    *reinterpret_cast<srwn::f32x4*>(job.out + (int64_t)l * job.out_batch_stride + i) =
+        srwn::f32x4{(float)(s0 * sc), (float)(s1 * sc), (float)(s2 * sc), (float)(s3 * sc)};
   } else {
     const int64_t i = (int64_t)bx * 256 + threadIdx.x;
     if (i >= n) return;
@@ -748,7 +770,11 @@ extern "C" int srwn_reduce_partials_multi(const SrwnReduceJob* jobs, int32_t njo
     j.partials = q.partials; j.out = q.out; j.n = q.n; j.out_batch_stride = q.out_batch_stride;
     j.nslabs = q.nslabs; j.nbatch = q.nbatch; j.part_batch_mul = q.partials_batched ? 1 : 0; j.scale = q.scale;
     j.wide = (q.n <= 4096 && q.nslabs >= 32) ? 1 : 0;           // the choice srwn_reduce_partials makes
-    j.blocks_x = (unsigned)(j.wide ? (q.n + 15) / 16 : (q.n + 255) / 256);
+    // >= 128 slabs of >= 1024 outputs (16-byte aligned blocks): the four-outputs-per-thread body
+    if (q.nslabs >= 128 && q.n >= 1024 && q.n % 4 == 0 && q.out_batch_stride % 4 == 0 &&
+        (reinterpret_cast<uintptr_t>(q.partials) | reinterpret_cast<uintptr_t>(q.out)) % 16 == 0)
+      j.wide = 2;
+    j.blocks_x = (unsigned)(j.wide == 2 ? (q.n / 4 + 255) / 256 : j.wide ? (q.n + 15) / 16 : (q.n + 255) / 256);
     j.block0 = (unsigned)blocks;
     blocks += (uint64_t)j.blocks_x * (uint64_t)q.nbatch;
     if (blocks > 0x7fffffffull) return set_error(SRWN_E_SHAPE, "reduce_partials_multi: grid too large");

@@ -49,6 +49,7 @@ struct GroupFwdArgs {
   // weight-gradient tiles (srwn_group.h), WT instantiations only: the transposed layer input x_g and gate output c_g of
   // the positions each segment owns, layer g at xT / cT + g*wt_stride, tile (seg, k) at ((seg*KT)+k)*R*32
   void* xT; void* cT; int64_t wt_stride; int KT;
+  int store_inner_x;              // WT: 0 = only the group's top layer stores its output rows (nothing reads the inner ones)
 };
 
 // In-kernel time stamps (MI355X guide, "In-kernel stamps"): lane 0 of waves 0 and 1 of workgroup 0 append the shader
@@ -111,8 +112,9 @@ __global__ __launch_bounds__(64 * NWV) void group_fwd_kernel(GroupFwdArgs a) {
   // retire the DMA, park the biases.  `younger` = tiles whose 2*NI row stores this wave has issued SINCE the DMA:
   // vmcnt counts in issue order, so leaving that many operations outstanding retires the DMA without waiting for
   // the stores to be acknowledged.
-  auto wstore = [&](int buf, int younger) {
+  auto wstore = [&](int buf, int younger, bool xrows) {
     constexpr int STP = 2 * NI + (WT ? R / 16 : 0);   // row stores of z and x (+ the c tile's pieces) per stored tile
+    constexpr int STZ = NI + (WT ? R / 16 : 0);       // ... of a layer that does not store its x rows (WT, inner layers)
     static_assert(MAXT <= 3 && 3 * STP < 64, "vmcnt immediates");
     if (!WDMA) {
       f32x4* dst = reinterpret_cast<f32x4*>(smem + (size_t)buf * WBYTES);
@@ -122,9 +124,15 @@ __global__ __launch_bounds__(64 * NWV) void group_fwd_kernel(GroupFwdArgs a) {
         if (p < WPIECES) dst[p] = wreg[v];
       }
     } else if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STP) : "memory");
-    else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * STP) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * STP) : "memory");
+    else if (xrows) {
+      if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STP) : "memory");
+      else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * STP) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * STP) : "memory");
+    } else {
+      if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STZ) : "memory");
+      else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * STZ) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * STZ) : "memory");
+    }
     if (tid < 2 * R / 4) *reinterpret_cast<f32x4*>(bbuf + buf * 2 * R + 4 * tid) = breg;
   };
 
@@ -172,7 +180,7 @@ __global__ __launch_bounds__(64 * NWV) void group_fwd_kernel(GroupFwdArgs a) {
         }
       }
     }
-    wstore(0, 0);
+    wstore(0, 0, true);
     stamp(2);
     wg_barrier();
     stamp(3);
@@ -217,11 +225,12 @@ __global__ __launch_bounds__(64 * NWV) void group_fwd_kernel(GroupFwdArgs a) {
           }
         }
       }
-      if (NWB == 1 && g > 0) wstore(0, 0);
+      if (NWB == 1 && g > 0) wstore(0, 0, true);
       stamp(10);
       wg_barrier();
       stamp(11);
       const bool more = g + 1 < a.nl;
+      const bool xrows = !WT || a.store_inner_x || !more;   // the layer's output rows go to HBM (WT: the group's top layer only)
       if (NWB == 2 && more) wload(g + 1, wb ^ 1);
 
       const Frag<T>* lds_conv = wbuf + (size_t)wb * NW * 64;
@@ -364,7 +373,7 @@ __global__ __launch_bounds__(64 * NWV) void group_fwd_kernel(GroupFwdArgs a) {
             for (int gq = 0; gq < 4; ++gq)
               store4(trow + (size_t)col * LS + 32 * mt + 8 * gq + 4 * half, hv[mt][4 * gq], hv[mt][4 * gq + 1],
                      hv[mt][4 * gq + 2], hv[mt][4 * gq + 3]);
-          if (st_ok) {
+          if (st_ok && xrows) {
             wave_lds_order();
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
@@ -377,7 +386,7 @@ __global__ __launch_bounds__(64 * NWV) void group_fwd_kernel(GroupFwdArgs a) {
         }
         stamp(16);
       }
-      if (NWB == 2 && more) wstore(wb ^ 1, nstored);
+      if (NWB == 2 && more) wstore(wb ^ 1, nstored, xrows);
       stamp(17);
       wg_barrier();
       stamp(18);
@@ -1092,7 +1101,7 @@ static int group_fwd_impl(const void* x0, void* x_out, void* z_out, int64_t laye
                           const void* const* cond_next, int32_t cond_frames, int32_t pool_stride,
                           int32_t cond_row_stride, const int32_t* dilations, int32_t nlayers, int32_t B,
                           int32_t T, int32_t R, int32_t K, int32_t seg_rows, int32_t dtype,
-                          void* stream, void* xT, void* cT, int64_t wt_stride) {
+                          void* stream, void* xT, void* cT, int64_t wt_stride, int32_t store_inner_x) {
   if (B == 0 || T == 0 || nlayers == 0) return 0;
   const bool wt = xT != nullptr || cT != nullptr;
   if (wt && (!xT || !cT || seg_rows < 1 || wt_stride < 0))
@@ -1106,7 +1115,7 @@ static int group_fwd_impl(const void* x0, void* x_out, void* z_out, int64_t laye
   if (layer_stride < (int64_t)B * T * R) return set_error(SRWN_E_SHAPE, "residual_group_fwd: layer_stride %lld", (long long)layer_stride);
   GroupFwdArgs a;
   a.x0 = x0; a.x_out = x_out; a.z_out = z_out; a.layer_stride = layer_stride;
-  a.xT = xT; a.cT = cT; a.wt_stride = wt_stride; a.KT = 0;
+  a.xT = xT; a.cT = cT; a.wt_stride = wt_stride; a.KT = 0; a.store_inner_x = store_inner_x ? 1 : 0;
   bool any_cond = false;
   for (int g = 0; g < kMaxGroup; ++g) {
     const bool in = g < nlayers;
@@ -1167,11 +1176,11 @@ extern "C" int srwn_residual_group_fwd(const void* x0, void* x_out, void* z_out,
                                        int32_t T, int32_t R, int32_t K, int32_t seg_rows, int32_t dtype,
                                        void* stream) {
   return group_fwd_impl(x0, x_out, z_out, layer_stride, wconv, wres, bias_f, bias_r, cond_next, cond_frames, pool_stride,
-                        cond_row_stride, dilations, nlayers, B, T, R, K, seg_rows, dtype, stream, nullptr, nullptr, 0);
+                        cond_row_stride, dilations, nlayers, B, T, R, K, seg_rows, dtype, stream, nullptr, nullptr, 0, 1);
 }
 
 extern "C" int srwn_residual_group_fwd_wt(const void* x0, void* x_out, void* z_out, int64_t layer_stride, void* xT,
-                                          void* cT, int64_t wt_layer_stride, const void* const* wconv,
+                                          void* cT, int64_t wt_layer_stride, int32_t store_inner_x, const void* const* wconv,
                                           const void* const* wres, const float* const* bias_f,
                                           const float* const* bias_r, const void* const* cond_next,
                                           int32_t cond_frames, int32_t pool_stride, int32_t cond_row_stride,
@@ -1179,7 +1188,8 @@ extern "C" int srwn_residual_group_fwd_wt(const void* x0, void* x_out, void* z_o
                                           int32_t K, int32_t seg_rows, int32_t dtype, void* stream) {
   if (!xT || !cT) return (B == 0 || T == 0 || nlayers == 0) ? 0 : set_error(SRWN_E_NULL, "residual_group_fwd_wt: null pointer");
   return group_fwd_impl(x0, x_out, z_out, layer_stride, wconv, wres, bias_f, bias_r, cond_next, cond_frames, pool_stride,
-                        cond_row_stride, dilations, nlayers, B, T, R, K, seg_rows, dtype, stream, xT, cT, wt_layer_stride);
+                        cond_row_stride, dilations, nlayers, B, T, R, K, seg_rows, dtype, stream, xT, cT, wt_layer_stride,
+                        store_inner_x);
 }
 
 // The segment cut both _wt kernels of a group must be given (seg_rows_in = 0: the library's choice), the weight-gradient

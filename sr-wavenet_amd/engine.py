@@ -119,6 +119,7 @@ class WaveNetEngine:
         # the waves; the forward group kernel writes the transposed operands ("weight-gradient tiles") they need
         # (csrc/srwn_group.hip, _wt entry points).  0: chain kernel + separate weight-gradient pass (the parity twin)
         self.fuse_wt = _os.environ.get("SRWN_FUSE_WT", "1") != "0"
+        self.wt_store_x = _os.environ.get("SRWN_WT_STORE_X", "0") != "0"
         # weight-gradient passes on a side stream beside the data-gradient chain: worth 11 % with one launch per layer
         # (short latency-bound chain kernels), but with the group kernels every kernel of the backward phase is
         # bandwidth-bound and running two at once is slower than one after the other (2.15 vs 2.13 ms; the skip data
@@ -586,7 +587,9 @@ class WaveNetEngine:
             offs = [(l + 1) * self.R if l + 1 < self.L else None for l in range(l0, l1)]
         wt = {}
         if self.fused_wt:
-            wt = dict(xT=self.xTs[l0:l1], cT=self.cTs[l0:l1])
+            # (xs of the layers inside a group is NOT written in this mode: only the weight gradients would read it, and they
+            # take the transposed tiles; SRWN_WT_STORE_X=1 keeps it for inspection)
+            wt = dict(xT=self.xTs[l0:l1], cT=self.cTs[l0:l1], store_inner_x=self.wt_store_x)
         K.residual_group_fwd(self.xs[l0], self.xs[l0 + 1:l1 + 1], self.zs[l0:l1],
                              [self.wptr(self.o_conv[l]) for l in range(l0, l1)],
                              [self.wptr(self.o_res[l]) for l in range(l0, l1)],

@@ -199,11 +199,11 @@ def _ptr_array(ptrs):
 def residual_group_fwd(x0: torch.Tensor, x_out: torch.Tensor, z_out: torch.Tensor, wconv_ptrs, wres_ptrs,
                        biases_f, biases_r, dilations, K: int = 2, cond: Optional[torch.Tensor] = None,
                        cond_channel_offsets=None, pool_stride: int = 1, seg_rows: int = 0,
-                       xT: Optional[torch.Tensor] = None, cT: Optional[torch.Tensor] = None):
+                       xT: Optional[torch.Tensor] = None, cT: Optional[torch.Tensor] = None, store_inner_x: bool = True):
     """x_out / z_out: [n,B,T,R] stacks (views of the engine's xs[l0+1:], zs[l0:]); cond: [B, frames, C] whose channels
     [cond_channel_offsets[g], +R) hold the bias of the layer above layer g (None entries: no add).
     xT / cT ([>=n, elems] each, `group_wt_geometry`): also write the layers' weight-gradient tiles (seg_rows from the same
-    geometry call)."""
+    geometry call); store_inner_x = False: only the group's top layer stores its output rows."""
     import ctypes as C
     B, T, R = x0.shape
     n = len(dilations)
@@ -237,7 +237,8 @@ def residual_group_fwd(x0: torch.Tensor, x_out: torch.Tensor, z_out: torch.Tenso
         if xT.shape[1] != cT.shape[1]:
             raise ValueError("xT / cT: layer strides differ")
         call("srwn_residual_group_fwd_wt", px, x_out.data_ptr(), z_out.data_ptr(), B * T * R, xT.data_ptr(), cT.data_ptr(),
-             int(xT.shape[1]), _ptr_array(wconv_ptrs), _ptr_array(wres_ptrs), _ptr_array(pbf), _ptr_array(pbr), pcs,
+             int(xT.shape[1]), 1 if store_inner_x else 0, _ptr_array(wconv_ptrs), _ptr_array(wres_ptrs), _ptr_array(pbf),
+             _ptr_array(pbr), pcs,
              frames, int(pool_stride), int(cstride), dl, n, B, T, R, int(K), int(seg_rows), dt, _stream())
         return
     call("srwn_residual_group_fwd", px, x_out.data_ptr(), z_out.data_ptr(), B * T * R, _ptr_array(wconv_ptrs),

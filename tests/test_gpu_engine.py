@@ -24,6 +24,14 @@ def _engine(sp, B, T, R, S, C, dt, shift=True, E=0, pool=1, lr=1e-3):
     return eng
 
 
+@pytest.fixture(autouse=True)
+def _keep_inner_layer_inputs(monkeypatch):
+    """The default path does not store the inputs of the layers inside a group (only their transposed tiles, which feed
+    the weight gradients); the bf16 tests below rebuild the oracle's backward from the engine's saved activations, so
+    they ask for the rows too.  (tests/test_gpu_group.py and tests/test_gpu_depth.py run the default setting.)"""
+    monkeypatch.setenv("SRWN_WT_STORE_X", "1")
+
+
 def _bwd_oracle_on_engine_forward(eng, sp, cond=None, pool=1):
     """bf16 mode: relu masks flip where an activation is within rounding of zero, which changes single
     gradient entries by O(1) and says nothing about the backward kernels.  So the backward is judged
