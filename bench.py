@@ -24,12 +24,37 @@ import numpy as np
 import torch
 
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
-# HBM bytes per launch of the dominant kernel, measured with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes):
-# (dtype, B, T, R, S, L) -> (bytes, profile the number was copied from).  Filled in from profiles/ each round.
-PROFILED_TRAFFIC = {
-    ("bf16", 8, 16000, 64, 256, 30): (365.0e6, "profiles/r02_f_hbm_traffic.md (group_bwd_kernel, mean of the six launches of a step: 213.8 MB read + 176.4 written for the 1..16 groups, 176.0 + 163.8 for the halo-free 32..512 groups)"),
-}
 PEAK_HBM_GBS = 8000.0        # HBM3E peak (same guide); ~4.9 TB/s is what a plain copy kernel reaches (tools/micro/membench.hip)
+
+
+def synthetic_audio(B, T, seed=0):
+    """x[b,t] = 0.5 sin(2 pi f_b t / 16000) + 0.05 N(0,1), f_b = 110 (b+1) Hz, clipped to [-1, 1], fp32."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(T, dtype=np.float64)[None, :]
+    f = 110.0 * (1 + np.arange(B, dtype=np.float64))[:, None]
+    x = 0.5 * np.sin(2.0 * np.pi * f * t / 16000.0) + 0.05 * rng.standard_normal((B, T))
+    return np.clip(x, -1.0, 1.0).astype(np.float32)
+
+
+def profiled_traffic(kernel_substr, config_key):
+    """HBM bytes per launch of a kernel from the newest tracked rocprofv3 PMC table under profiles/ whose first line
+    names this configuration (tools/hbm_traffic.py writes the table; FETCH_SIZE x 2 + WRITE_SIZE, separate passes):
+    launch-weighted mean over the table rows whose kernel name contains `kernel_substr`.  (None, None) if there is none."""
+    import glob
+    import re
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.md")), reverse=True):
+        txt = open(path).read()
+        if config_key not in txt.split("\n", 1)[0]:
+            continue
+        tot, calls = 0.0, 0
+        for m in re.finditer(r"^\| `([^`]*)` \| (\d+) \| ([0-9.]+) \| ([0-9.]+) \|", txt, flags=re.M):
+            if kernel_substr in m.group(1):
+                n = int(m.group(2))
+                tot += n * (float(m.group(3)) + float(m.group(4))) * 1e6
+                calls += n
+        if calls:
+            return tot / calls, os.path.relpath(path, ROOT)
+    return None, None
 
 
 def algorithmic_flops(N, L, R, S, C, Kw):
@@ -56,6 +81,56 @@ def cpu_baseline(dil, R, S, C, threads, seconds_budget=20.0):
                       "fp32 fwd+bwd+Adam, %d steps of batch %dx%d samples (same 30-layer stack)" % (r["steps"], B, T)}
 
 
+def student_leg(steps=10, warmup=3, B=8, T=16000):
+    """BASELINE configs[3] at its one-GPU shape: 4 IAF flows x 30 layers (R = 64) distilled against a frozen 30-layer
+    mixture-of-logistics-10 teacher, batch 8 x 16000, bf16; teacher forward + student forward/backward + clipped Adam
+    as hipGraphs (student.py:70-107, model.py:290-401).  Returns ms per step."""
+    EG = importlib.import_module("sr-wavenet_amd.engine")
+    ST = importlib.import_module("sr-wavenet_amd.student")
+    dil = [1, 2, 4, 8, 16, 32, 64, 128, 256, 512] * 3
+    pool, lat, M = 125, 16, 10
+    dt = torch.bfloat16
+    tcfg = EG.StackConfig(dilations=dil, dilation_channels=64, skip_channels=256, output_channels=4 * M, cond_channels=lat,
+                          pool_stride=pool, shift_input=True, dtype=dt, head_mode="mol")
+    teacher = EG.WaveNetEngine(tcfg, B, T, "cuda")
+    fcfg = EG.StackConfig(dilations=dil, dilation_channels=64, skip_channels=256, cond_channels=lat, pool_stride=pool, dtype=dt)
+    stu = ST.StudentEngine(teacher, fcfg, 4, alpha=1.0, beta=1.0, gamma=1e-3, learning_rate=1e-4)
+    rng = np.random.default_rng(0)
+    dev = lambda x: torch.tensor(x, dtype=torch.float32, device="cuda")
+    stu.set_inputs(dev(rng.logistic(0, 1, (B, T))), dev(synthetic_audio(B, T, 0)), dev(rng.standard_normal((B, T // pool, lat))))
+    for _ in range(max(warmup, 1)):
+        stu.train_step()
+    stu.capture_graphs()
+    for _ in range(2):
+        stu.train_step_graphed()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        stu.train_step_graphed()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def generation_leg(nsteps=256):
+    """BASELINE configs[4]: queue-cached autoregressive sampling from the 30-layer mu-law teacher (generator.py; the
+    reference runs teacher.py:140-171's whole-clip pass per sample), bf16: microseconds per 16 kHz sample with ONE
+    workgroup of 32 streams (the latency of a single stream) and with 2048 streams (the chip's aggregate rate)."""
+    EG = importlib.import_module("sr-wavenet_amd.engine")
+    dil = [1, 2, 4, 8, 16, 32, 64, 128, 256, 512] * 3
+    cfg = EG.StackConfig(dilations=dil, dilation_channels=64, skip_channels=256, output_channels=256, shift_input=True,
+                         dtype=torch.bfloat16)
+    eng = EG.WaveNetEngine(cfg, 1, 64, "cuda")
+    out = {}
+    for name, B in (("1wg", 32), ("2048", 2048)):
+        eng.generate(64, batch=B)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.generate(nsteps, mode="sample", seed=1, batch=B)
+        torch.cuda.synchronize()
+        out[name] = (time.perf_counter() - t0) / nsteps * 1e6
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -65,6 +140,7 @@ def main():
     ap.add_argument("--length", type=int, default=16000)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the student (config 4) and generation (config 5) legs")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("SRWN_GRAPH", "1")))
     args = ap.parse_args()
 
@@ -88,7 +164,6 @@ def main():
 
     EG = importlib.import_module("sr-wavenet_amd.engine")
     KN = importlib.import_module("sr-wavenet_amd.kernels")
-    from oracle import wavenet_np as O   # only for the synthetic input generator + cpu_baseline
 
     dil = [1, 2, 4, 8, 16, 32, 64, 128, 256, 512] * 3
     R, S, C, Kw = 64, 256, 256, 2
@@ -97,7 +172,7 @@ def main():
                          dtype=dt, learning_rate=1e-3)
     eng = EG.WaveNetEngine(cfg, args.batch, args.length, "cuda", seed=0)   # same init on every rank
     B, T, N, L = eng.B, eng.T, eng.N, eng.L
-    audio = torch.tensor(O.synthetic_audio(B, T, seed=rank), device="cuda")
+    audio = torch.tensor(synthetic_audio(B, T, seed=rank), device="cuda")
     codes = KN.mu_law_encode(audio, C)
     eng.set_inputs(audio, codes)
 
@@ -164,26 +239,32 @@ def main():
     kflops = {"skip_sum": 2.0 * N * L * R * S, "wgrad_skip": 2.0 * N * L * R * S}
     es = 2 if args.dtype == "bf16" else 4
     step_ms = 1e3 * dt_s / args.steps
-    # Dominant kernel by time = the data-gradient chain of the residual stack, HBM-bound.
-    #  fused path (default): group_bwd_kernel, one launch per layer group.  Algorithmic bytes per launch: per sample and
-    #    layer it reads z, dcs and writes df, G (4 x R x es bytes) plus the group's top gradient once (R x es);
+    # Dominant kernel by time = the backward chain of the residual stack, HBM-bound.
+    #  default path (fused_wt): group_bwd_kernel in its weight-gradient-tile instantiation, one launch per layer group.
+    #    Algorithmic bytes per launch: per sample and layer it reads z, dcs and the transposed x and c tiles (4 x R x es
+    #    bytes), reads the group's top gradient (where there is one) and writes its bottom gradient once (R x es each);
+    #    the fp32 partial sums it leaves (one 3 R R + 2 R block per workgroup and layer) are in the measured traffic.
+    #  SRWN_FUSE_WT=0: the same kernel without the weight gradients: reads z, dcs, writes df, G (4 x R x es) + top gradient;
     #  SRWN_FUSE=0: layer_bwd_kernel, one launch per layer: reads G_{l+2}, df_{l+1}, dcs_l, z_l, writes G_{l+1}, df_l.
     fused = eng.fused_bwd
+    cfg_key = "config: %s B=%d T=%d L=%d R=%d S=%d" % (args.dtype, B, T, L, R, S)
     if fused:
         ngr = len(eng.groups)
-        bwd_bytes_step = sum((4.0 * (l1 - l0) + (1.0 if l1 < L else 0.0)) * R * es * N for l0, l1 in eng.groups)
+        extra = 1.0 if eng.fused_wt else 0.0      # (the bottom gradient; without the weight gradients it is one of the 4)
+        bwd_bytes_step = sum((4.0 * (l1 - l0) + extra + (1.0 if l1 < L else 0.0)) * R * es * N for l0, l1 in eng.groups)
         nlaunch, kname = ngr, "group_bwd_kernel"
-        traffic, traffic_src = PROFILED_TRAFFIC.get((args.dtype, B, T, R, S, L), (None, None))
+        traffic, traffic_src = profiled_traffic("group_bwd_kernel", cfg_key + (" wt=1" if eng.fused_wt else " wt=0"))
     else:
         bwd_bytes_step = 6.0 * R * es * N * (L + 1)
         nlaunch, kname = L + 1, "layer_bwd_kernel"
-        traffic, traffic_src = (105.0e6, "profiles/r01_l_hbm_traffic.md") if (args.dtype, B, T, R, S, L) == ("bf16", 8, 16000, 64, 256, 30) else (None, None)
+        traffic, traffic_src = profiled_traffic("layer_bwd_kernel", cfg_key + " fuse=0")
     bwd_launch_ms = spans["bwd_layers"] / nlaunch
     ach_bw = bwd_bytes_step / nlaunch / (bwd_launch_ms * 1e-3) / 1e9
     roofline = {"kernel": kname, "bound": "hbm", "achieved": ach_bw, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": ach_bw / PEAK_HBM_GBS,
                 # HBM bytes per launch from the rocprofv3 PMC passes of the same command (FETCH_SIZE x 2 + WRITE_SIZE,
-                # MI355X_MICROARCH.md); copied from the profile named in traffic_source, not measured in this run
+                # MI355X_MICROARCH.md), read at run time from the tracked profile named in traffic_source (null when
+                # no tracked profile covers this configuration); not measured in this run
                 "traffic": traffic, "traffic_source": traffic_src,
                 "bytes_per_launch": bwd_bytes_step / nlaunch, "launch_us": 1e3 * bwd_launch_ms,
                 # the same launches timed inside the schedule the timed region replays (weight-gradient passes running
@@ -197,9 +278,9 @@ def main():
     achieved = kflops[dom] / (spans[dom] * 1e-3) / 1e12
     roofline_gemm = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_BF16_TFLOPS,
-                     "traffic": ({"skip_sum": 573.1e6, "wgrad_skip": 662.2e6}[dom]
-                                 if (args.dtype == "bf16" and (B, T, R, S, L) == (8, 16000, 64, 256, 30)) else None),
-                     "traffic_source": "profiles/r02_f_hbm_traffic.md"}
+                     }
+    roofline_gemm["traffic"], roofline_gemm["traffic_source"] = profiled_traffic(
+        {"skip_sum": "rowgemm_kernel", "wgrad_skip": "wgrad256_kernelIDF16bLi1"}[dom], cfg_key)
 
     if rank == 0:
         out = {
@@ -214,6 +295,27 @@ def main():
             "roofline": roofline,
             "roofline_gemm": roofline_gemm,
         }
+        if not args.no_extras and world == 1 and args.dtype == "bf16":
+            # after (and outside) the timed region: BASELINE configs[3] and [4] at their one-GPU shapes
+            del eng
+            torch.cuda.empty_cache()
+            extra = {}
+            try:
+                extra["student_ms_per_step"] = student_leg()
+                extra["student_samples_per_s"] = 8 * 16000 / extra["student_ms_per_step"] * 1e3
+                extra["student_config"] = "4 flows x 30 layers (R=64) + frozen 30-layer MoL-10 teacher forward, 8x16000, bf16, hipGraph"
+            except Exception as e:      # (the headline line must survive a failure of an extra leg)
+                extra["student_error"] = repr(e)
+            try:
+                g = generation_leg()
+                extra["gen_us_per_sample_1wg"] = g["1wg"]
+                extra["gen_rtf_per_stream"] = g["1wg"] * 16000 / 1e6          # > 1: slower than real time
+                extra["gen_us_per_sample_2048_streams"] = g["2048"]
+                extra["gen_aggregate_x_real_time_2048_streams"] = 2048 / (g["2048"] * 16000 / 1e6)
+                extra["gen_config"] = "30-layer mu-law teacher, bf16, 256 sampled steps; 1 workgroup = 32 streams"
+            except Exception as e:
+                extra["gen_error"] = repr(e)
+            out["extra"] = extra
         if not args.no_cpu_baseline and world == 1:
             # the CPU restatement on the box's host cores, and the same on ONE thread (half the time budget)
             out["cpu_baseline"] = cpu_baseline(dil, R, S, C, threads=min(os.cpu_count() or 1, 16), seconds_budget=16.0)

@@ -995,7 +995,8 @@ int launch_group_bwd(GroupBwdArgs& a, int seg_rows, hipStream_t st) {
   // segments of at most two tiles per wave (the halo-free residue-class groups: 16 tiles) run the two-tile body: 16 fewer
   // live registers for G, no third (empty) tile iteration
   constexpr int MT2 = MAXT > 2 ? 2 : MAXT;
-  const bool two = MAXT > 2 && a.NT <= 2 * NWV;
+  static const int two_env = [] { const char* e = getenv("SRWN_GB_TWO"); return e ? atoi(e) : 1; }();   // (timing experiments)
+  const bool two = two_env && MAXT > 2 && a.NT <= 2 * NWV;
 #define SRWN_GB(D)                                                                                              \
   {                                                                                                             \
     auto kfn = two ? group_bwd_kernel<T, RT, D, MT2, NWB, NWV, WT> : group_bwd_kernel<T, RT, D, MAXT, NWB, NWV, WT>; \

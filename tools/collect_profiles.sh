@@ -6,8 +6,8 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats -d $OUT/trace -- $B > $OUT/trace.log 2>&1
+B="python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras"
+rocprofv3 --kernel-trace --stats -d $OUT/trace -- $B --no-extras > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- $B --graph 0 --steps 3 --warmup 1 > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- $B --graph 0 --steps 3 --warmup 1 > $OUT/write.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $OUT/sqa -- $B --graph 0 --steps 3 --warmup 1 > $OUT/sqa.log 2>&1
