@@ -1,7 +1,9 @@
 """One rank of the data-parallel GPU test (tests/test_gpu_dp2.py): a fresh process that shards a fixed global batch,
 runs one eager and two graph-replayed training steps of the ENGINE's own data-parallel schedule (gradient all-reduce
 in one bucket or two, the first overlapped with the lower backward pass), and saves its parameters.
-usage: dp_worker.py <mode: softmax|mol|student> <out.pt>     (RANK / WORLD_SIZE / MASTER_* from the environment)"""
+usage: dp_worker.py <mode: softmax|mol|student|deep> <out.pt>     (RANK / WORLD_SIZE / MASTER_* from the environment)
+"deep" is the benchmark's own stack (30 layers 3 x [1..512], bf16) on clips longer than the receptive field, so that the
+two-bucket schedule cuts where the benchmark cuts (split_layer = 10, three hipGraphs)."""
 import importlib
 import os
 import sys
@@ -23,21 +25,25 @@ def main():
     from oracle import wavenet_np as O   # parameter / input generators only
     GB, T, R, S = 4, 700, 64, 256
     dil = [1, 2, 4, 8, 16, 32, 64, 128, 256, 512]
+    dtype = torch.float32
+    if mode == "deep":
+        T, dil, dtype = 3200, dil * 3, torch.bfloat16
     b = GB // world
     sl = slice(rank * b, (rank + 1) * b)
     audio = O.synthetic_audio(GB, T, seed=5)
     dev = lambda a, dt=torch.float32: torch.tensor(np.asarray(a), dtype=dt, device="cuda")
-    if mode in ("softmax", "mol"):
-        C = 256 if mode == "softmax" else 20
+    if mode in ("softmax", "mol", "deep"):
+        C = 20 if mode == "mol" else 256
         sp = O.init_stack_params(7, dil, 2, R, S, C, bias_scale=0.05)
         cfg = EG.StackConfig(dilations=dil, dilation_channels=R, skip_channels=S, output_channels=C, shift_input=True,
-                             dtype=torch.float32, learning_rate=1e-3,
-                             head_mode="per_timestep" if mode == "softmax" else "mol")
+                             dtype=dtype, learning_rate=1e-3,
+                             head_mode="mol" if mode == "mol" else "per_timestep")
         eng = EG.WaveNetEngine(cfg, b, T, "cuda")
         eng.load_oracle_params(sp)
         codes = O.mu_law_encode(audio, 256).astype(np.int32)
         eng.set_inputs(dev(audio[sl]), dev(codes[sl], torch.int32))
-        info = {"bucketed": bool(eng.bucketed), "world": eng.world, "fused": bool(eng.fused_bwd)}
+        info = {"bucketed": bool(eng.bucketed), "world": eng.world, "fused": bool(eng.fused_bwd),
+                "split_layer": int(eng.split_layer), "layers": eng.L}
         eng.train_step()
         torch.cuda.synchronize()
         grads1, params1 = eng.grads.cpu().clone(), eng.params.cpu().clone()

@@ -65,16 +65,29 @@ def _check(eng, logits, loss, grads, dt):
             g = got[n].cpu().numpy()
             assert np.abs(g - ref).max() < 1e-3 * max(np.abs(ref).max(), 1e-12), n
     else:                       # bf16 mode (the timed path): every stored activation is rounded to 8 significant bits
-        assert rel_err(lg, logits) < 6e-2
-        assert abs(float(eng.loss.item()) - loss) < 2e-2 * loss
+        errs = {"logits": rel_err(lg, logits), "loss": abs(float(eng.loss.item()) - loss) / loss}
         for n, ref in grads.items():
             g = got[n].float().cpu().numpy().ravel().astype(np.float64)
             r = ref.ravel()
             if not r.any():
                 assert not g.any(), n
                 continue
-            cos = float(g @ r / (np.linalg.norm(g) * np.linalg.norm(r) + 1e-300))
-            assert cos > 0.99 and abs(np.linalg.norm(g) / np.linalg.norm(r) - 1) < 0.1, (n, cos)
+            errs[n] = float(np.linalg.norm(g - r) / np.linalg.norm(r))      # per-tensor relative L2 error
+        import os
+        if os.environ.get("SRWN_PRINT_BF16_ERRS"):
+            print("bf16 errors: logits %.4f loss %.5f" % (errs["logits"], errs["loss"]),
+                  {k: round(v, 4) for k, v in sorted(errs.items(), key=lambda kv: -kv[1])[:6]})
+        return errs
+    return None
+
+
+def _assert_bf16(errs, logits_tol, loss_tol, grad_tol):
+    """Bounds at about twice the errors measured on MI355X (SRWN_PRINT_BF16_ERRS=1 prints them; round 3: logits 5e-3
+    max-relative, loss 1e-5, worst per-tensor relative L2 gradient error 1.7e-2 at config 2's depth, 1.4e-2 at config 1)."""
+    assert errs["logits"] < logits_tol, errs["logits"]
+    assert errs["loss"] < loss_tol, errs["loss"]
+    worst = max((v, k) for k, v in errs.items() if k not in ("logits", "loss"))
+    assert worst[0] < grad_tol, worst
 
 
 @pytest.mark.parametrize("fuse", ["1", "0"])
@@ -92,7 +105,9 @@ def test_config2_depth_and_dilations_vs_oracle(monkeypatch, dt, fuse):
     eng = _engine(sp, DIL30, B, T, R, S, C, dt)
     assert eng.fused_bwd == (fuse == "1")
     eng.set_inputs(dev(audio), dev(codes, torch.int32))
-    _check(eng, logits, loss, grads, dt)
+    errs = _check(eng, logits, loss, grads, dt)
+    if errs is not None:
+        _assert_bf16(errs, 1.2e-2, 5e-4, 3.5e-2)
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
@@ -107,7 +122,9 @@ def test_config1_own_size_vs_oracle(dt):
     logits, loss, grads = _oracle_cached("config1", sp, audio, codes)
     eng = _engine(sp, dil, B, T, R, S, C, dt)
     eng.set_inputs(dev(audio), dev(codes, torch.int32))
-    _check(eng, logits, loss, grads, dt)
+    errs = _check(eng, logits, loss, grads, dt)
+    if errs is not None:
+        _assert_bf16(errs, 1.2e-2, 5e-4, 3.5e-2)
 
 
 def test_config4_shape_student_vs_oracle():

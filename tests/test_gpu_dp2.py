@@ -42,15 +42,21 @@ def _run(mode, world, tmp_path, tag, buckets, port):
     return [torch.load(o, weights_only=True) for o in outs]
 
 
-@pytest.mark.parametrize("mode,buckets", [("softmax", "0"), ("softmax", "1"), ("mol", "1"), ("student", "0")])
+@pytest.mark.parametrize("mode,buckets", [("softmax", "0"), ("softmax", "1"), ("mol", "1"), ("student", "0"), ("deep", "1")])
 def test_two_ranks_equal_one_process_on_the_global_batch(tmp_path, mode, buckets):
-    port = 29600 + (os.getpid() % 200) + {"softmax": 0, "mol": 1, "student": 2}[mode] * 3 + int(buckets)
+    """"deep": BASELINE config 3's stack and dtype (30 layers, bf16) with two ranks through the schedule the scaling bench
+    replays: backward cut at layer 10, first bucket all-reduced beside the lower part, three hipGraphs.  The shards are
+    whole clips, every kernel works clip by clip, so even in bf16 two ranks and one process form the same per-clip
+    gradients: only the order of the fp32 sums differs."""
+    port = 29600 + (os.getpid() % 200) + {"softmax": 0, "mol": 1, "student": 2, "deep": 3}[mode] * 3 + int(buckets)
     ref = _run(mode, 1, tmp_path, "ref", "0", port)[0]
     r0, r1 = _run(mode, 2, tmp_path, "dp" + buckets, buckets, port + 400)
     assert r0["info"]["world"] == 2 and r1["info"]["world"] == 2
     if mode != "student":
         assert r0["info"]["bucketed"] == (buckets == "1"), r0["info"]
         assert r0["info"]["fused"]
+    if mode == "deep":
+        assert r0["info"]["layers"] == 30 and r0["info"]["split_layer"] == 10, r0["info"]
     assert torch.equal(r0["params"], r1["params"]), "ranks diverged"
     # the all-reduced gradient buffer of the FIRST step (identical parameters everywhere): SUM over ranks of the shard
     # gradients.  Mean losses: sum / world is the global-batch gradient; the mixture-of-logistics SUM loss: the sum
@@ -59,7 +65,7 @@ def test_two_ranks_equal_one_process_on_the_global_batch(tmp_path, mode, buckets
     assert torch.equal(r0["grads1"], r1["grads1"])
     scale = 1.0 if mode == "mol" else 0.5
     gerr = float((g * scale - gref).abs().max() / gref.abs().max())
-    assert gerr < 1e-5, gerr
+    assert gerr < (1e-4 if mode == "deep" else 1e-5), gerr
     # parameters after the first Adam step and after the two graph-replayed ones, where the gradient is not numerically
     # zero (Adam turns the sign of a ~1e-9 gradient entry into a 1e-3 step, and later steps amplify that)
     live = gref.abs() > 1e-4 * gref.abs().max()
