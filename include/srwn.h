@@ -102,7 +102,7 @@ int srwn_residual_layer_fwd(const void* x, const void* cond, const void* wconv, 
  * layer g (dilation dilations[g]) reads x_{g} and stores z_g at z_out + g*layer_stride and x_{g+1} at
  * x_out + g*layer_stride (elements; the engine's [L,B,T,R] stacks).  wconv/wres/bias_f/bias_r/cond_next are HOST
  * arrays of nlayers device pointers (cond_next[g] = the conditioning bias of the layer above layer g, or NULL).
- * Requirement: sum(dilations)/gcd(dilations) <= 63 and nlayers <= 8 (srwn_group_plan cuts a stack accordingly):
+ * Requirement: sum(dilations)/gcd(dilations) <= 31 and nlayers <= 8 (srwn_group_plan cuts a stack accordingly):
  * the kernel works on the residue classes t = j*gcd + r, where the group's dilations are small, and recomputes a
  * halo of that many steps per segment.  seg_rows = 0 lets the library choose the segment length. */
 int srwn_residual_group_fwd(const void* x0, void* x_out, void* z_out, int64_t layer_stride,

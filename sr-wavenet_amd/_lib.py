@@ -130,6 +130,7 @@ def load():
         raise RuntimeError(
             "libsrwn.so not found at %s: build it with `python sr-wavenet_amd/build.py` "
             "(there is no CPU fallback for the product path)" % LIB_PATH)
+    _check_manifest()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
@@ -137,6 +138,21 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def _check_manifest():
+    """build.py records the sha256 of every source next to the library; a library older than the sources it ships with
+    (an edit without a rebuild) is refused instead of silently running yesterday's kernels."""
+    man = os.path.join(HERE, "libsrwn.manifest.json")
+    if not os.path.exists(man) or not os.path.isdir(os.path.join(HERE, "csrc")):
+        return
+    import hashlib
+    import json
+    root = os.path.dirname(HERE)
+    for rel, digest in json.load(open(man)).get("sources", {}).items():
+        path = os.path.join(root, rel)
+        if os.path.exists(path) and hashlib.sha256(open(path, "rb").read()).hexdigest() != digest:
+            raise RuntimeError("libsrwn.so was built from a different %s: rebuild with `python sr-wavenet_amd/build.py`" % rel)
 
 
 def call(name, *args):

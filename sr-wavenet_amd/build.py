@@ -13,6 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsrwn.so")
+MANIFEST = os.path.join(HERE, "libsrwn.manifest.json")   # sha256 of every source the library was built from
 IO_LIB = os.path.join(HERE, "libsrwn_io.so")     # host-only data path (TFRecord reader), plain g++
 IO_SOURCES = ["srwn_tfrecord.cpp"]
 CXX = os.environ.get("CXX", "g++")
@@ -25,6 +26,19 @@ def _deps():
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hdrs.append(os.path.join(HERE, "..", "include", "srwn.h"))
     return hdrs
+
+
+def source_hashes():
+    """sha256 of every file the library is compiled from (sources, headers, the C-ABI header)."""
+    import hashlib
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h", ".cpp"))]
+    files.append(os.path.join(HERE, "..", "include", "srwn.h"))
+    files.append(os.path.join(HERE, "..", "include", "srwn_io.h"))
+    out = {}
+    for f in files:
+        if os.path.exists(f):
+            out[os.path.relpath(f, os.path.join(HERE, ".."))] = hashlib.sha256(open(f, "rb").read()).hexdigest()
+    return out
 
 
 def _stale(target, srcs):
@@ -58,6 +72,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s" % r.stderr[-8000:])
     build_io(force)
+    import json
+    with open(MANIFEST, "w") as f:      # which sources this library came from: _lib.load() refuses a stale one
+        json.dump({"flags": FLAGS, "sources": source_hashes()}, f, indent=1, sort_keys=True)
     return LIB
 
 

@@ -310,14 +310,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && SK != 0) ? 2 : 1) void laye
   }
 }
 
-static int bwd_blocks_per_cu(int dflt) {
-  static const int v = [] {
-    const char* e = getenv("SRWN_BWD_BPC");
-    int x = e ? atoi(e) : 0;
-    return x < 0 ? 0 : (x > 8 ? 8 : x);
-  }();
-  return v ? v : dflt;
-}
+static int bwd_blocks_per_cu(int dflt) { return dflt; }
 
 template <typename T, int RT>
 static int launch_layer_bwd(LayerBwdArgs a, int B, int up, bool gin, bool down, int sk, hipStream_t st) {

@@ -303,10 +303,10 @@ template <typename T, int RT, int K>
 static int launch_layer_fwd(const void* x, const void* cond, const void* wconv, const void* wres,
                             const float* bias_f, const float* bias_r, void* h_out, void* z_out, int B, int Tlen,
                             int dilation, int cond_frames, int pool, int cond_stride, hipStream_t st) {
-  static const int nbuf_env = [] { const char* e = getenv("SRWN_FWD_NBUF"); return e ? atoi(e) : 0; }();
-  if (sizeof(T) == 2 && nbuf_env == 0) return launch_layer_fwd_n<T, RT, K, 0>(x, cond, wconv, wres, bias_f, bias_r, h_out, z_out, B, Tlen, dilation, cond_frames, pool, cond_stride, st);
-  if (sizeof(T) == 2 && nbuf_env == 1) return launch_layer_fwd_n<T, RT, K, 1>(x, cond, wconv, wres, bias_f, bias_r, h_out, z_out, B, Tlen, dilation, cond_frames, pool, cond_stride, st);
-  return launch_layer_fwd_n<T, RT, K, (sizeof(T) == 2) ? 2 : 1>(x, cond, wconv, wres, bias_f, bias_r, h_out, z_out, B, Tlen, dilation, cond_frames, pool, cond_stride, st);
+  // bf16: operand windows prefetched into registers one tile ahead (NBUF = 0; the LDS-DMA variants measured no faster);
+  // fp32: one LDS buffer
+  if (sizeof(T) == 2) return launch_layer_fwd_n<T, RT, K, 0>(x, cond, wconv, wres, bias_f, bias_r, h_out, z_out, B, Tlen, dilation, cond_frames, pool, cond_stride, st);
+  return launch_layer_fwd_n<T, RT, K, 1>(x, cond, wconv, wres, bias_f, bias_r, h_out, z_out, B, Tlen, dilation, cond_frames, pool, cond_stride, st);
 }
 
 

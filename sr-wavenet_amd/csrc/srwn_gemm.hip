@@ -536,8 +536,7 @@ int rowgemm_dispatch(const void* x, int64_t x_row_stride, int64_t x_chunk_stride
   }
   RgArgs a{x, x_row_stride, x_chunk_stride, chunk_len, Cin / 16, wpack, bias, y, y_row_stride, cout_valid, rows,
            aux, aux_row_stride, targets, loss_partials, logits_out, grad_scale, 0, 0, nullptr, 0, 0, 1, 0.0f};
-  static const int nt_bf16 = [] { const char* e = getenv("SRWN_RG_NT"); return (e && atoi(e) == 2) ? 2 : 1; }();
-  if (dtype == SRWN_BF16) *rc = (nt_bf16 == 2) ? launch_rg<bf16_t, 8, 4, 2>(a, pro, epi, st) : launch_rg<bf16_t, 8, 4, 1>(a, pro, epi, st);
+  if (dtype == SRWN_BF16) *rc = launch_rg<bf16_t, 8, 4, 1>(a, pro, epi, st);   // (two row tiles per wave measured slower: DESIGN.md 5)
   else if (dtype == SRWN_F32) *rc = launch_rg<float, 8, 2, 1>(a, pro, epi, st);
   else return 0;
   return 1;

@@ -8,7 +8,7 @@
 //   {1,2,4,8,16}      -> st = 1,  sub = 1,2,4,8,16   (32 segments of 500 steps per 16000-step clip)
 //   {32,...,512}      -> st = 32, sub = 1,2,4,8,16   (32 residue classes of 500 steps per clip)
 // are the same program: a workgroup owns one SEGMENT = (clip b, residue r, positions [j0, j0+W)) plus a halo of
-// H = sum(sub_g) <= 63 positions on the causal side, which it recomputes instead of exchanging with a neighbour.
+// H = sum(sub_g) <= 31 positions on the causal side, which it recomputes instead of exchanging with a neighbour.
 // The only difference is the HBM row stride (a row = R channels of one time step = one or two whole cache lines).
 //
 // Forward (group_fwd_kernel): 8 waves; the segment's rows live in one LDS image [rows][R] (padded rows); per layer
@@ -995,8 +995,7 @@ int launch_group_bwd(GroupBwdArgs& a, int seg_rows, hipStream_t st) {
   // segments of at most two tiles per wave (the halo-free residue-class groups: 16 tiles) run the two-tile body: 16 fewer
   // live registers for G, no third (empty) tile iteration
   constexpr int MT2 = MAXT > 2 ? 2 : MAXT;
-  static const int two_env = [] { const char* e = getenv("SRWN_GB_TWO"); return e ? atoi(e) : 1; }();   // (timing experiments)
-  const bool two = two_env && MAXT > 2 && a.NT <= 2 * NWV;
+  const bool two = MAXT > 2 && a.NT <= 2 * NWV;
 #define SRWN_GB(D)                                                                                              \
   {                                                                                                             \
     auto kfn = two ? group_bwd_kernel<T, RT, D, MT2, NWB, NWV, WT> : group_bwd_kernel<T, RT, D, MAXT, NWB, NWV, WT>; \
@@ -1053,7 +1052,7 @@ static int group_bwd_impl(const void* g_top, void* g_out, void* df_out, const vo
   a.nl = nlayers; a.Tlen = T; a.B = B;
   if (group_geometry(dilations, nlayers, &a.st, a.sub, &a.H) != 0)
     return set_error(SRWN_E_SHAPE, "residual_group_bwd: dilations must be >= 1");
-  if (a.H > 63) return set_error(SRWN_E_UNSUPPORTED, "residual_group_bwd: halo %d > 63 (sum of dilations / their gcd)", a.H);
+  if (a.H > 31) return set_error(SRWN_E_UNSUPPORTED, "residual_group_bwd: halo %d > 31 (sum of dilations / their gcd)", a.H);
   hipStream_t st = (hipStream_t)stream;
   if (wt) {
     if (a.H > 31) return set_error(SRWN_E_UNSUPPORTED, "residual_group_bwd_wt: halo %d > 31 (sum of dilations / their gcd)", a.H);
@@ -1134,20 +1133,21 @@ static int group_fwd_impl(const void* x0, void* x_out, void* z_out, int64_t laye
   a.nl = nlayers; a.Tlen = T; a.B = B; a.stamps = nullptr;
   if (group_geometry(dilations, nlayers, &a.st, a.sub, &a.H) != 0)
     return set_error(SRWN_E_SHAPE, "residual_group_fwd: dilations must be >= 1");
-  if (a.H > 63) return set_error(SRWN_E_UNSUPPORTED, "residual_group_fwd: halo %d > 63 (sum of dilations / their gcd)", a.H);
+  if (a.H > 31) return set_error(SRWN_E_UNSUPPORTED, "residual_group_fwd: halo %d > 31 (sum of dilations / their gcd)", a.H);
   hipStream_t st = (hipStream_t)stream;
   // waves per workgroup (bf16, R = 64).  The kernel is bound by the instructions one wave can issue (one per ~5 cycles;
   // tools/micro/valubench.hip): twelve waves of <= 168 registers and two tiles each fill the VALU pipe that eight
   // waves of three tiles leave ~30 % idle (forward groups 412 -> 377 us per step); sixteen (128 registers) spill.
-  static const int gf_waves = [] { const char* e = getenv("SRWN_GF_WAVES"); const int v = e ? atoi(e) : 12; return (v == 8 || v == 16) ? v : 12; }();
-  const bool waves16 = gf_waves == 16, waves12 = gf_waves == 12;
+  // (SRWN_GF_WAVES=8 keeps the eight-wave body reachable: tests/test_gpu_group.py runs it against the twelve-wave one)
+  static const int gf_waves = [] { const char* e = getenv("SRWN_GF_WAVES"); return (e && atoi(e) == 8) ? 8 : 12; }();
+  const bool waves12 = gf_waves == 12;
   if (wt) {      // the weight-gradient tiles of x and c written as well (one instantiation per dtype / width)
     if (a.H > 31) return set_error(SRWN_E_UNSUPPORTED, "residual_group_fwd_wt: halo %d > 31 (sum of dilations / their gcd)", a.H);
     if (dtype == SRWN_BF16) {
       if (R == 32) return launch_group_fwd<bf16_t, 1, 3, 2, 8, true, false, true>(a, any_cond, seg_rows, st);
-      static const int wtw = [] { const char* e = getenv("SRWN_GF_WT_WAVES"); return e ? atoi(e) : 8; }();   // (twelve waves of 168 registers spill 30-47 of them with the tile stores: 0.43 vs 0.38 ms per step)
-      if (wtw == 8) return launch_group_fwd<bf16_t, 2, 3, 2, 8, true, false, true>(a, any_cond, seg_rows, st);
-      return launch_group_fwd<bf16_t, 2, 2, 2, 12, true, false, true>(a, any_cond, seg_rows, st);
+      // (eight waves of three tiles: twelve waves of 168 registers, the plain kernel's choice, spill 30-47 registers once the
+      // tile stores are in the body: 0.43 vs 0.38 ms per step)
+      return launch_group_fwd<bf16_t, 2, 3, 2, 8, true, false, true>(a, any_cond, seg_rows, st);
     } else if (dtype == SRWN_F32) {
       if (R == 32) return launch_group_fwd<float, 1, 1, 1, 8, true, false, true>(a, any_cond, seg_rows, st);
       return launch_group_fwd<float, 2, 1, 1, 8, true, false, true>(a, any_cond, seg_rows, st);
@@ -1157,10 +1157,7 @@ static int group_fwd_impl(const void* x0, void* x_out, void* z_out, int64_t laye
   if (dtype == SRWN_BF16) {
     if (R == 32) return launch_group_fwd<bf16_t, 1, 3, 2>(a, any_cond, seg_rows, st);
     if (g_stamps) { a.stamps = g_stamps; return launch_group_fwd<bf16_t, 2, 3, 2, 8, true, true>(a, any_cond, seg_rows, st); }
-    if (waves16) return launch_group_fwd<bf16_t, 2, 2, 2, 16>(a, any_cond, seg_rows, st);
     if (waves12) return launch_group_fwd<bf16_t, 2, 2, 2, 12>(a, any_cond, seg_rows, st);
-    static const int wdma = [] { const char* e = getenv("SRWN_GF_WDMA"); return e ? atoi(e) : 1; }();
-    if (!wdma) return launch_group_fwd<bf16_t, 2, 3, 2, 8, false>(a, any_cond, seg_rows, st);
     return launch_group_fwd<bf16_t, 2, 3, 2>(a, any_cond, seg_rows, st);
   } else if (dtype == SRWN_F32) {
     if (R == 32) return launch_group_fwd<float, 1, 1, 1>(a, any_cond, seg_rows, st);
@@ -1206,7 +1203,7 @@ extern "C" int srwn_group_wt_geometry(const int32_t* dilations, int32_t nlayers,
   if (H > 31) return set_error(SRWN_E_UNSUPPORTED, "group_wt_geometry: halo %d > 31", H);
   int ntf, ntb;
   if (dtype == SRWN_BF16) {
-    ntf = R == 32 ? fwd_nt_max<bf16_t, 1, 3, 2, 8>() : fwd_nt_max<bf16_t, 2, 2, 2, 12>();   // (= the 8 x 3 variant's)
+    ntf = R == 32 ? fwd_nt_max<bf16_t, 1, 3, 2, 8>() : fwd_nt_max<bf16_t, 2, 3, 2, 8>();
     ntb = R == 32 ? bwd_nt_max<bf16_t, 1, 3, 2, 8>(true) : bwd_nt_max<bf16_t, 2, 3, 2, 8>(true);
   } else if (dtype == SRWN_F32) {
     ntf = R == 32 ? fwd_nt_max<float, 1, 1, 1, 8>() : fwd_nt_max<float, 2, 1, 1, 8>();
@@ -1293,7 +1290,7 @@ extern "C" int32_t srwn_group_plan_auto(const int32_t* dilations, int32_t nlayer
     for (int len = 1; len <= max_layers && l + len <= nlayers; ++len) {
       int st = 0, H = 0, sub[kMaxGroup];
       if (group_geometry(dilations + l, len, &st, sub, &H) != 0) break;
-      if (H > 63 || nt_max * 32 - H < 32) break;
+      if (H > 31 || nt_max * 32 - H < 32) break;
       int W, NT, nsub;
       const int J = (T + st - 1) / st;
       choose_segments(J, &H, B, st, nt_max, 0, &W, &NT, &nsub);

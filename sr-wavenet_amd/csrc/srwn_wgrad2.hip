@@ -710,8 +710,7 @@ extern "C" int srwn_wgrad_layers(const void* x, const void* z, const void* df, c
   hipStream_t st = (hipStream_t)stream;
   // row groups per workgroup: 2 in bf16 (90 KB of LDS; still fits beside a layer_bwd workgroup of the main stream),
   // 1 in fp32 (one group's two tiles are already 90 KB)
-  static const int ng_env = [] { const char* e = getenv("SRWN_WGL_GROUPS"); return e ? atoi(e) : 2; }();
-  const int ng = (dtype == SRWN_F32) ? 1 : (ng_env >= 3 ? 3 : (ng_env <= 1 ? 1 : 2));
+  const int ng = (dtype == SRWN_F32) ? 1 : 2;
   dim3 grid((unsigned)nslabs, (unsigned)nlayers), block(256 * ng);
 #define SRWN_WLN(TT, C, NGV)                                                                                   \
   {                                                                                                            \
@@ -724,7 +723,6 @@ extern "C" int srwn_wgrad_layers(const void* x, const void* z, const void* df, c
   }
 #define SRWN_WL(TT, C)                                                                                         \
   {                                                                                                            \
-    if (ng == 3) SRWN_WLN(TT, C, 3)                                                                            \
     if (ng == 2) SRWN_WLN(TT, C, 2)                                                                            \
     SRWN_WLN(TT, C, 1)                                                                                         \
   }

@@ -124,7 +124,11 @@ class WaveNetEngine:
         # (short latency-bound chain kernels), but with the group kernels every kernel of the backward phase is
         # bandwidth-bound and running two at once is slower than one after the other (2.15 vs 2.13 ms; the skip data
         # gradient beside the skip weight gradient: 446 us together, 347 us in turn) -> off by default there.
-        self.overlap = _os.environ.get("SRWN_OVERLAP", "0" if self.fuse_bwd else "1") != "0"
+        # (decided on whether the grouped backward actually RUNS for this stack -- a 64/128 stack, say, keeps the per-layer
+        # chain even with SRWN_FUSE=1 and wants the overlap)
+        will_group = (self.fuse_bwd and cfg.dilation_channels in (32, 64) and cfg.filter_width == 2 and
+                      ((cfg.dilation_channels, cfg.skip_channels) in ((64, 256), (32, 128)) or cfg.head_mode == "flow"))
+        self.overlap = _os.environ.get("SRWN_OVERLAP", "0" if will_group else "1") != "0"
         self.seg_rows = int(_os.environ.get("SRWN_SEG_ROWS", "0"))
         # head 1x1 + softmax-CE + head data gradients as one launch (SRWN_HEAD_CHAIN=0: the four separate ones)
         self.head_chain = (_os.environ.get("SRWN_HEAD_CHAIN", "1") != "0" and cfg.head_mode == "per_timestep"

@@ -661,28 +661,3 @@ class ParallelWaveNet(object):
     def reconstruct(self, sess, inputs, conditions=None):
         """The teacher's own reconstruction (``teacher_out``, model.py:651-656)."""
         return self._ae_teacher(inputs).reconstruct(inputs, conditions)
-
-
-def smoke_check():
-    """One tiny fwd+bwd+Adam of the teacher on cuda:0, checked against the CPU oracle (graft smoke)."""
-    from oracle import wavenet_np as O   # checker only
-    dil = [1, 2, 4, 8]
-    B, T, R, S, C = 2, 256, 64, 64, 256
-    sp = O.init_stack_params(3, dil, 2, R, S, C, bias_scale=0.05)
-    audio = O.synthetic_audio(B, T, seed=1)
-    codes = O.mu_law_encode(audio, C)
-    logits, cache = O.stack_forward(sp, audio.astype(np.float64), shift_input=True)
-    ref_loss = O.softmax_ce_per_timestep(logits, codes)
-    m = WaveNetTeacher(T, 0, dil, dilation_channels=R, skip_channels=S, quantization_channels=C,
-                       dtype=torch.float32, learning_rate=1e-3)
-    eng = m._engine(B, T)
-    eng.load_oracle_params(sp)
-    got = m.get_logits(audio)
-    err = float(np.abs(got - logits).max() / np.abs(logits).max())
-    assert err < 1e-3, "forward parity %g" % err
-    l0 = float(m.loss(audio))
-    assert abs(l0 - ref_loss) < 1e-3 * ref_loss, (l0, ref_loss)
-    for _ in range(3):
-        l1 = float(m.train(audio))
-    assert l1 < l0 + 1e-3, (l0, l1)
-    print("smoke: forward rel err %.2e, loss %.4f (oracle %.4f) -> %.4f after 3 steps" % (err, l0, ref_loss, l1))

@@ -79,6 +79,36 @@ def test_group_forward_equals_per_layer(monkeypatch, dt, dil, B, T, R, S, seg):
     assert torch.equal(ref.loss, fus.loss)
 
 
+def test_group_forward_eight_wave_body(monkeypatch):
+    """The plain forward group kernel has two bodies for bf16 / 64 channels: twelve waves of two tiles (default) and eight
+    of three (SRWN_GF_WAVES=8; also what the weight-gradient-tile mode runs).  Same arithmetic, same bits; the choice is
+    read once per process, so the eight-wave run is a fresh child process."""
+    import subprocess, sys, os, textwrap
+    from tests._pkg import ROOT
+    code = textwrap.dedent("""
+        import importlib, sys, torch, numpy as np
+        sys.path.insert(0, %r)
+        EG = importlib.import_module("sr-wavenet_amd.engine")
+        cfg = EG.StackConfig(dilations=[1, 2, 4, 8, 16, 32, 64, 128, 256, 512], dilation_channels=64, skip_channels=256,
+                             output_channels=64, shift_input=True, dtype=torch.bfloat16)
+        eng = EG.WaveNetEngine(cfg, 2, 2100, "cuda", seed=3)
+        rng = np.random.default_rng(3)
+        eng.set_inputs(torch.tensor(np.clip(0.3 * rng.normal(size=(2, 2100)), -1, 1), dtype=torch.float32, device="cuda"),
+                       torch.tensor(rng.integers(0, 64, size=(2, 2100)), dtype=torch.int32, device="cuda"))
+        eng.forward(); torch.cuda.synchronize()
+        torch.save({"zs": eng.zs.cpu(), "xtop": eng.xs[[5, 10]].cpu(), "loss": eng.loss.cpu()}, sys.argv[1])
+    """ % ROOT)
+    outs = []
+    for waves in ("12", "8"):
+        out = os.path.join(str(os.environ.get("TMPDIR", "/tmp")), "srwn_gf_waves_%s_%d.pt" % (waves, os.getpid()))
+        env = dict(os.environ, SRWN_GF_WAVES=waves, SRWN_FUSE_WT="0", SRWN_FUSE="1")
+        subprocess.run([sys.executable, "-c", code, out], env=env, check=True, cwd=ROOT, timeout=300)
+        outs.append(torch.load(out, weights_only=True))
+        os.remove(out)
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("E,pool", [(16, 8), (40, 50)])
 def test_group_forward_conditioned(monkeypatch, dt, E, pool):
