@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """HBM bytes per launch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; counter_collection.csv each) as the
 markdown table kept under profiles/.  FETCH_SIZE is doubled (MI355X_MICROARCH.md: gfx950 reports half the bytes of
-wide coalesced reads); both counters are in KiB, the table is in MB (1e6 bytes).  Usage: hbm_traffic.py <fetch.csv> <write.csv> <steps> <out.md>"""
+wide coalesced reads); both counters are in KiB, the table is in MB (1e6 bytes).  The optional header becomes the table's
+first line: bench.py looks there for "config: <dtype> B=.. T=.. L=.. R=.. S=.. wt=.." to decide whether a tracked table
+covers the configuration it is running.  Usage: hbm_traffic.py <fetch.csv> <write.csv> <steps> <out.md> [header]"""
 import collections
 import csv
 import sys
@@ -17,7 +19,7 @@ def load(path, name):
     return val, dur
 
 
-def main(fetch, write, steps, out):
+def main(fetch, write, steps, out, header=None):
     fv, fd = load(fetch, "FETCH_SIZE")
     wv, _ = load(write, "WRITE_SIZE")
     rows = []
@@ -31,6 +33,8 @@ def main(fetch, write, steps, out):
     tot_r = sum(r[2] * r[3] for r in rows) / steps / 1e3
     tot_w = sum(r[2] * r[4] for r in rows) / steps / 1e3
     with open(out, "w") as f:
+        if header:
+            f.write(header.strip() + "\n\n")
         f.write("| kernel | calls | read MB/launch | write MB/launch | us/launch (profiled) | GB/s |\n|---|---|---|---|---|---|\n")
         for _, k, n, rd, wr, us in rows:
             f.write("| `%s` | %d | %.1f | %.1f | %.1f | %.0f |\n" % (k[:90], n, rd, wr, us, (rd + wr) / us * 1e3))
@@ -38,4 +42,4 @@ def main(fetch, write, steps, out):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4])
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else None)
