@@ -120,6 +120,7 @@ class WaveNetEngine:
         # (csrc/srwn_group.hip, _wt entry points).  0: chain kernel + separate weight-gradient pass (the parity twin)
         self.fuse_wt = _os.environ.get("SRWN_FUSE_WT", "1") != "0"
         self.wt_store_x = _os.environ.get("SRWN_WT_STORE_X", "0") != "0"
+        self.frozen = False   # forward-only use (set by StudentEngine for its teacher): no weight-gradient tiles written
         # weight-gradient passes on a side stream beside the data-gradient chain: worth 11 % with one launch per layer
         # (short latency-bound chain kernels), but with the group kernels every kernel of the backward phase is
         # bandwidth-bound and running two at once is slower than one after the other (2.15 vs 2.13 ms; the skip data
@@ -731,7 +732,10 @@ class WaveNetEngine:
     def fused_wt(self) -> bool:
         """The layer weight gradients are summed inside the backward group kernel from the forward kernel's weight-gradient
         tiles (no df / G round trip through HBM, no separate weight-gradient pass)."""
-        return self.fuse_wt and self.fuse_fwd and self.fused_bwd
+        # (not for the flows of the student: they carry no skip path and write every layer's input gradient for the
+        # conditioning 1x1 anyway -- measured: their backward gains nothing and their forward pays for the tiles,
+        # 7.09 vs 6.77 ms per distillation step -- and not for a stack that is never trained: StudentEngine's teacher)
+        return self.fuse_wt and self.fuse_fwd and self.fused_bwd and self.cfg.head_mode != "flow" and not self.frozen
 
     def _group_bwd_wt(self, l0: int, l1: int):
         """Chain + weight-gradient partials of layers [l0, l1) in one launch (srwn_residual_group_bwd_wt)."""

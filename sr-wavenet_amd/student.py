@@ -314,12 +314,14 @@ class StudentEngine:
         B, T, N = self.B, self.T, self.N
         tch = self.teacher
         main = torch.cuda.current_stream()
+        was_frozen, tch.frozen = tch.frozen, True   # forward only (stop_gradient, model.py:334): no weight-gradient tiles
         if self.tstream is not None:   # the frozen teacher depends on (truth, encoding) only: run it beside the flows
             self.tstream.wait_stream(main)
             with torch.cuda.stream(self.tstream):
                 tch.forward(with_loss=False)                           # logits32 [N, 4M] on RightShift(truth)
         else:
             tch.forward(with_loss=False)
+        tch.frozen = was_frozen
         self.forward_flows()
         K.stft_power(self.truth, None, self.fpow, self.pow_truth)      # model.py:360,367
         K.stft_power(self.out.view(B, T), self.spec, self.fpow, self.pow_out)
