@@ -1,0 +1,379 @@
+// Queue-cached incremental generation, latency-optimised body for the benchmark's teacher (bf16, 64 residual / 256 skip
+// channels, mu-law softmax head, unconditioned): the same arithmetic and the same rings as generate_kernel
+// (srwn_gen.hip; the reference only has the whole-clip-per-sample loop of teacher.py:140-171 / generator.py:150-170),
+// organised for the length of the DEPENDENT chain of one step instead of for throughput.
+//
+// generate_kernel runs the conv -> tanh -> gate -> 1x1 chain of a layer redundantly in each of its four waves (no
+// exchange inside a layer) on 32x32x16 tiles: 32 MFMAs and the transcendental work of all 64 channels per wave and
+// layer, every MFMA behind an LDS read of its weight fragment: 3.7 us per layer, real-time factor 1.8 for one stream.
+// Here a layer's 64 channels are SPLIT over the four waves (16 each) on v_mfma_f32_16x16x32_bf16 tiles -- the 32
+// utterances of a workgroup are two 16-column blocks -- so a wave runs 8 + 4 MFMAs of 16 cycles and the tanh / gate of 8
+// values per lane on the chain; the gate output and the layer output cross the waves through two 4.5-KB LDS tiles (two
+// barriers per layer); every weight fragment a wave needs (its 16 rows of the conv and residual kernels, its 64 rows of
+// the skip kernel: 14 KB per layer) is requested from L2 one layer ahead straight into registers (one wave per SIMD: 512
+// registers), so no MFMA waits for LDS or memory; the skip products run in the matrix pipe behind the residual ones
+// while the VALU finishes the layer.  Pinned by the same tests as the throughput kernel (tests/test_gpu_generate.py).
+#include <cstdlib>
+#include "srwn_common.h"
+#include "srwn_group.h"
+#include "srwn_host.h"
+#include "../../include/srwn.h"
+
+using namespace srwn;
+using namespace srwn::grp;
+
+namespace {
+
+constexpr int kG16MaxLayers = 64;
+
+struct Gen16Args {
+  const void* wl;       // per layer: [4 waves][conv ks 0..3 | res ks 0..1 | skip (rb 0..3) x (ks 0..1)] 16x32 A fragments
+  const void* wh1;      // head 1x1 S -> S: [4 waves][rb 0..3][ks 0..7]
+  const void* wh2;      // head 1x1 S -> C (rows >= C zero): same shape
+  const float* bias_f; const float* bias_r;   // [L][R]
+  const float* bs_sum; const float* b1; const float* b2;   // [S], [S], [256]
+  const float* init_w; const float* init_b;   // [2][R], [R]
+  void* ring;
+  float* audio_out; int32_t* codes_out; float* logits_out; const float* forced;
+  int B, Tout, nsteps, L, C, Cp, mode, Q;       // Cp: entries of b2 / rows of the last 1x1 (ceil(C/32)*32)
+  long long ring_group_elems;
+  unsigned long long seed;
+  int dil[kG16MaxLayers];
+  long long ring_off[kG16MaxLayers];
+};
+
+__device__ __forceinline__ float g16_mu_law_decode(int code, int Q) {   // ops.py:96-104, as srwn_mu_law_decode
+  const float mu = (float)(Q - 1);
+  const float signal = __fadd_rn(__fmul_rn(2.0f, __fdiv_rn((float)code, mu)), -1.0f);
+  const float p = (float)pow((double)Q, (double)fabsf(signal));
+  const float magnitude = __fmul_rn((float)(1.0 / (double)(Q - 1)), __fadd_rn(p, -1.0f));
+  const float sgn = (signal > 0.0f) ? 1.0f : ((signal < 0.0f) ? -1.0f : 0.0f);
+  return __fmul_rn(sgn, magnitude);
+}
+
+__device__ __forceinline__ float g16_uniform(unsigned long long seed, unsigned u, unsigned t) {   // as gen_uniform (srwn_gen.hip)
+  unsigned long long x = seed + 0x9E3779B97F4A7C15ull * ((unsigned long long)u * 0x100000001ull + t + 1);
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+  return (float)((x >> 40) + 0.5) * (1.0f / 16777216.0f);
+}
+
+typedef bf16_t T;
+constexpr int R = 64, S = 256, LSX = 72, LSH = 264, LGS = 256;
+constexpr int FR = 512;                       // elements of one fragment image (64 lanes x 8)
+constexpr int LAYER_FR = 4 * 14;              // fragment images per layer
+
+// one layer's operands of a wave that do not depend on the step's activations: its weight fragments and the delayed tap
+struct Pre {
+  Frag<T> wc[4], wr[2], ws[4][2];
+  Frag<T> x0[2][2];                           // [k-step of the delayed tap][column block]
+};
+
+__global__ __launch_bounds__(256) void generate16_kernel(Gen16Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* xb = reinterpret_cast<T*>(smem);                         // [32][LSX] the layer input x_l[t]
+  T* cb = xb + 32 * LSX;                                      // [32][LSX] the gate output c_l[t]
+  T* hx = cb + 32 * LSX;                                      // [32][LSH] head activations (r0 / r1)
+  float* lgl = reinterpret_cast<float*>(hx + 32 * LSH);       // [32][LGS] logits
+  float* prev = lgl + 32 * LGS;                               // [2][32] last two samples
+  float* c_bf = prev + 64;                                    // [L][R]
+  float* c_br = c_bf + a.L * R;                               // [L][R]
+  float* c_bs = c_br + a.L * R;                               // [S]
+  float* c_b1 = c_bs + S;                                     // [S]
+  float* c_b2 = c_b1 + S;                                     // [256]
+  float* c_iw = c_b2 + 256;                                   // [2][R]
+  float* c_ib = c_iw + 2 * R;                                 // [R]
+
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int col = lane & 15, rq = lane >> 4;                  // D tile: column (utterance in its block), rows 4 rq + r
+  const int u0 = blockIdx.x * 32;
+  T* ring = reinterpret_cast<T*>(a.ring) + (size_t)blockIdx.x * a.ring_group_elems;
+  const T* wl = reinterpret_cast<const T*>(a.wl);
+
+  for (int i = threadIdx.x; i < a.L * R; i += 256) { c_bf[i] = a.bias_f[i]; c_br[i] = a.bias_r[i]; }
+  for (int i = threadIdx.x; i < S; i += 256) { c_bs[i] = a.bs_sum[i]; c_b1[i] = a.b1[i]; }
+  for (int i = threadIdx.x; i < 256; i += 256) c_b2[i] = i < a.Cp ? a.b2[i] : 0.0f;
+  if (threadIdx.x < 2 * R) c_iw[threadIdx.x] = a.init_w[threadIdx.x];
+  if (threadIdx.x < R) c_ib[threadIdx.x] = a.init_b[threadIdx.x];
+  if (threadIdx.x < 64) prev[threadIdx.x] = 0.0f;
+  __syncthreads();
+
+  auto preload = [&](int l_, int t, Pre& p) {
+    const int l = l_ < a.L ? l_ : a.L - 1;
+    const T* w = wl + ((size_t)l * LAYER_FR + wave * 14) * FR + lane * 8;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) p.wc[f] = load_nat(w + f * FR);
+#pragma unroll
+    for (int f = 0; f < 2; ++f) p.wr[f] = load_nat(w + (4 + f) * FR);
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) p.ws[rb][ks] = load_nat(w + (6 + 2 * rb + ks) * FR);
+    const int d = a.dil[l], depth = d + 1;
+    const int td = t - d;
+    const int slot = (td >= 0 ? td : 0) % depth;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int c2 = 0; c2 < 2; ++c2)
+        p.x0[ks][c2] = load_nat(ring + a.ring_off[l] + ((size_t)slot * 32 + 16 * c2 + col) * R + 32 * ks + 8 * rq);
+  };
+
+  Pre pa, pb;
+  for (int t = 0; t < a.nsteps; ++t) {
+    // (layer 0's operands were requested by the last layer of the step before -- its ring slot is at least one step old --
+    // unless the layers do not alternate back onto the same set)
+    if (t == 0 || (a.L & 1)) preload(0, t, pa);
+    // ---- input conv with RightShift (model.py:172-173): h0[t] = w[0] audio[t-2] + w[1] audio[t-1] + b; this wave's 16 channels
+    float xs[2][4];                              // the wave's slice of the current layer input (as stored: rounded)
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2) {
+      const int ug = u0 + 16 * c2 + col;
+      float a1 = 0.0f, a2 = 0.0f;
+      if (ug < a.B) {
+        if (a.forced) {
+          if (t >= 1) a1 = a.forced[(size_t)ug * a.Tout + t - 1];
+          if (t >= 2) a2 = a.forced[(size_t)ug * a.Tout + t - 2];
+        } else {
+          a1 = prev[16 * c2 + col];
+          a2 = prev[32 + 16 * c2 + col];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = 16 * wave + 4 * rq + r;
+        xs[c2][r] = (float)(T)fmaf(c_iw[n], a2, fmaf(c_iw[R + n], a1, c_ib[n]));
+      }
+      store4(xb + (size_t)(16 * c2 + col) * LSX + 16 * wave + 4 * rq, xs[c2][0], xs[c2][1], xs[c2][2], xs[c2][3]);
+    }
+    f32x4 accS[4][2];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+      for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) accS[rb][c2][r] = c_bs[64 * wave + 16 * rb + 4 * rq + r];
+    wg_barrier();
+
+    auto layer = [&](int l, const Pre& p, Pre& pnext) {
+      const int d = a.dil[l], depth = d + 1;
+      // x_l[t] of the workgroup -> the layer's ring (read d steps from now): each wave copies eight utterances' rows
+      {
+        const int ul = 8 * wave + (lane >> 3);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (size_t)ul * LSX + (lane & 7) * 8);
+        *reinterpret_cast<f32x4*>(ring + a.ring_off[l] + ((size_t)(t % depth) * 32 + ul) * R + (lane & 7) * 8) = v;
+      }
+      // the next layer's weights and delayed tap, one layer ahead (after the top layer: layer 0 of the next step)
+      if (l + 1 < a.L) preload(l + 1, t, pnext);
+      else if (!(a.L & 1)) preload(0, t + 1, pnext);
+      const bool tap0 = (t - d) >= 0;
+      f32x4 accF[2];
+#pragma unroll
+      for (int c2 = 0; c2 < 2; ++c2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) accF[c2][r] = c_bf[l * R + 16 * wave + 4 * rq + r];
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+          const Frag<T> x1 = load_nat(xb + (size_t)(16 * c2 + col) * LSX + 32 * ks + 8 * rq);
+          mma16(accF[c2], p.wc[2 + ks], x1);
+          mma16(accF[c2], p.wc[ks], tap0 ? p.x0[ks][c2] : zero_frag<T>());
+        }
+      // tanh, gate (ops.py:28-36); z as the training graph stores it
+#pragma unroll
+      for (int c2 = 0; c2 < 2; ++c2) {
+        float cv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float z = Math<T>::tanh_(accF[c2][r]);
+          z = (float)(T)z;
+          cv[r] = gate_of_z<T>(z);
+        }
+        store4(cb + (size_t)(16 * c2 + col) * LSX + 16 * wave + 4 * rq, cv[0], cv[1], cv[2], cv[3]);
+      }
+      wg_barrier();
+      Frag<T> cf[2][2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) cf[ks][c2] = load_nat(cb + (size_t)(16 * c2 + col) * LSX + 32 * ks + 8 * rq);
+      f32x4 accR[2];
+#pragma unroll
+      for (int c2 = 0; c2 < 2; ++c2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) accR[c2][r] = c_br[l * R + 16 * wave + 4 * rq + r];
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) mma16(accR[c2], p.wr[ks], cf[ks][c2]);
+      // this wave's quarter of the skip 1x1 (ops.py:44), accumulated over layers (model.py:50): in the matrix pipe behind
+      // the residual products while the VALU finishes the layer
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int c2 = 0; c2 < 2; ++c2) mma16(accS[rb][c2], p.ws[rb][ks], cf[ks][c2]);
+#pragma unroll
+      for (int c2 = 0; c2 < 2; ++c2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xs[c2][r] = (float)(T)((xs[c2][r] + accR[c2][r]) * kSqrtHalf);
+        store4(xb + (size_t)(16 * c2 + col) * LSX + 16 * wave + 4 * rq, xs[c2][0], xs[c2][1], xs[c2][2], xs[c2][3]);
+      }
+      wg_barrier();
+    };
+    for (int l = 0; l < a.L; l += 2) {
+      layer(l, pa, pb);
+      if (l + 1 >= a.L) break;
+      layer(l + 1, pb, pa);
+    }
+
+    // ---- head: relu(sum skip) -> 1x1 + relu -> 1x1 (model.py:51-56); each wave owns 64 of the 256 rows of both products,
+    // the activations cross the waves through LDS
+    auto head_product = [&](const T* wimg, const float* bias, f32x4 (&acc)[4][2]) {
+      Frag<T> w[4][8];                          // all of the wave's fragments requested before the first is used
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) w[rb][ks] = load_nat(wimg + ((size_t)(wave * 4 + rb) * 8 + ks) * FR + lane * 8);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[rb][c2][r] = bias[64 * wave + 16 * rb + 4 * rq + r];
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+          const Frag<T> bf = load_nat(hx + (size_t)(16 * c2 + col) * LSH + 32 * ks + 8 * rq);
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb) mma16(acc[rb][c2], w[rb][ks], bf);
+        }
+    };
+    auto relu_to_hx = [&](const f32x4 (&acc)[4][2]) {
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2)
+          store4(hx + (size_t)(16 * c2 + col) * LSH + 64 * wave + 16 * rb + 4 * rq, fmaxf(acc[rb][c2][0], 0.f),
+                 fmaxf(acc[rb][c2][1], 0.f), fmaxf(acc[rb][c2][2], 0.f), fmaxf(acc[rb][c2][3], 0.f));
+    };
+    relu_to_hx(accS);
+    wg_barrier();
+    f32x4 acc1[4][2];
+    head_product(reinterpret_cast<const T*>(a.wh1), c_b1, acc1);
+    wg_barrier();                                 // everyone has read r0
+    relu_to_hx(acc1);
+    wg_barrier();
+    f32x4 acc2[4][2];
+    head_product(reinterpret_cast<const T*>(a.wh2), c_b2, acc2);
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+      for (int c2 = 0; c2 < 2; ++c2)
+        *reinterpret_cast<f32x4*>(lgl + (size_t)(16 * c2 + col) * LGS + 64 * wave + 16 * rb + 4 * rq) = acc2[rb][c2];
+    wg_barrier();
+
+    // ---- softmax over the C classes, pick a code, mu-law decode: wave w serves utterances 8w..8w+7 with lanes = classes
+    // (as generate_kernel: 4 classes per lane, shuffle reductions)
+    for (int i = 0; i < 8; ++i) {
+      const int ul = 8 * wave + i;
+      const int u = u0 + ul;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(lgl + ul * LGS + 4 * lane);
+      float m = -INFINITY; int am = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (4 * lane + e < a.C && v[e] > m) { m = v[e]; am = 4 * lane + e; }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const float mo = __shfl_xor(m, off); const int ao = __shfl_xor(am, off);
+        if (mo > m || (mo == m && ao < am)) { m = mo; am = ao; }
+      }
+      int code = am;
+      if (a.mode == 1) {   // categorical sample from softmax(logits): inclusive prefix sums over the lanes
+        float ev[4], loc = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ev[e] = (4 * lane + e < a.C) ? __expf(v[e] - m) : 0.0f; loc += ev[e]; }
+        float inc = loc;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const float o = __shfl_up(inc, off);
+          if (lane >= off) inc += o;
+        }
+        const float total = __shfl(inc, 63);
+        const float target = g16_uniform(a.seed, (unsigned)u, (unsigned)t) * total;
+        const unsigned long long hit = __ballot(inc > target);
+        const int src = hit ? (__ffsll((long long)hit) - 1) : 63;
+        float run = inc - loc;
+        int pick = 4 * lane + 3;
+#pragma unroll
+        for (int e = 3; e >= 0; --e) { if (run + ev[0] + (e > 0 ? ev[1] : 0.f) + (e > 1 ? ev[2] : 0.f) + (e > 2 ? ev[3] : 0.f) > target) pick = 4 * lane + e; }
+        if (pick >= a.C) pick = a.C - 1;
+        code = __shfl(pick, src);
+      }
+      if (lane == 0) {
+        const float smp = g16_mu_law_decode(code, a.Q);
+        if (u < a.B) {
+          a.audio_out[(size_t)u * a.Tout + t] = smp;
+          a.codes_out[(size_t)u * a.Tout + t] = code;
+        }
+        prev[32 + ul] = prev[ul];
+        prev[ul] = smp;
+      }
+      if (a.logits_out && u < a.B && 4 * lane < a.C) {
+        float* lo = a.logits_out + ((size_t)u * a.Tout + t) * a.C + 4 * lane;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (4 * lane + e < a.C) lo[e] = v[e];
+      }
+    }
+    wg_barrier();
+  }
+}
+
+}  // namespace
+
+// elements of the three weight images srwn_generate16 takes (in the activation type), for nlayers layers
+extern "C" int64_t srwn_generate16_image_elems(int32_t nlayers, int32_t which) {
+  if (which == 0) return (int64_t)nlayers * LAYER_FR * FR;
+  return (int64_t)4 * 4 * 8 * FR;
+}
+
+extern "C" int srwn_generate16(const void* wl, const void* wh1, const void* wh2, const float* bias_f,
+                               const float* bias_r, const float* bs_sum, const float* b1, const float* b2,
+                               const float* init_w, const float* init_b, void* ring, float* audio_out,
+                               int32_t* codes_out, float* logits_out, const float* forced, const int32_t* dilations,
+                               int32_t nlayers, int32_t B, int32_t Tout, int32_t nsteps, int32_t C, int32_t mode,
+                               uint64_t seed, void* stream) {
+  if (B == 0 || nsteps == 0) return 0;
+  if (!wl || !wh1 || !wh2 || !bias_f || !bias_r || !bs_sum || !b1 || !b2 || !init_w || !init_b || !ring || !audio_out ||
+      !codes_out || !dilations)
+    return set_error(SRWN_E_NULL, "generate16: null pointer");
+  if (C < 2 || C > 256) return set_error(SRWN_E_UNSUPPORTED, "generate16: C=%d (2..256)", C);
+  if (B < 0 || nsteps < 0 || nsteps > Tout || nlayers < 1 || nlayers > kG16MaxLayers || (mode != 0 && mode != 1))
+    return set_error(SRWN_E_SHAPE, "generate16: B=%d nsteps=%d Tout=%d layers=%d mode=%d", B, nsteps, Tout, nlayers, mode);
+  Gen16Args a;
+  a.wl = wl; a.wh1 = wh1; a.wh2 = wh2; a.bias_f = bias_f; a.bias_r = bias_r; a.bs_sum = bs_sum; a.b1 = b1; a.b2 = b2;
+  a.init_w = init_w; a.init_b = init_b; a.ring = ring; a.audio_out = audio_out; a.codes_out = codes_out;
+  a.logits_out = logits_out; a.forced = forced;
+  a.B = B; a.Tout = Tout; a.nsteps = nsteps; a.L = nlayers; a.C = C; a.Cp = (C + 31) / 32 * 32; a.mode = mode; a.Q = C; a.seed = seed;
+  long long off = 0;
+  for (int l = 0; l < kG16MaxLayers; ++l) {
+    a.dil[l] = (l < nlayers) ? dilations[l] : 1;
+    a.ring_off[l] = off;
+    if (l < nlayers) {
+      if (dilations[l] < 1) return set_error(SRWN_E_SHAPE, "generate16: dilation %d", dilations[l]);
+      off += (long long)(dilations[l] + 1) * 32 * R;
+    }
+  }
+  a.ring_group_elems = off;
+  const unsigned groups = (unsigned)((B + 31) / 32);
+  const size_t sh = (size_t)(2 * 32 * LSX + 32 * LSH) * sizeof(T) + (size_t)(32 * LGS + 64 + 2 * nlayers * R + 2 * S + 256 + 3 * R) * 4;
+  hipError_t e = hipFuncSetAttribute((const void*)generate16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+  if (e != hipSuccess) return set_error((int)e, "generate16: LDS %zu: %s", sh, hipGetErrorString(e));
+  hipLaunchKernelGGL(generate16_kernel, dim3(groups), dim3(256), sh, (hipStream_t)stream, a);
+  return check_launch("generate16");
+}

@@ -358,6 +358,14 @@ class WaveNetEngine:
             for l in range(L):
                 P.fill_linear(pk, self.o_skip_gen, sec["WS"].offset + l * R * S, R, S, S // 32, L * R // 16,
                               ks_offset=l * R // 16, ks_count=R // 16, perm=True)
+        # the latency-optimised generator's fragment images (csrc/srwn_gen16.hip): the benchmark's teacher only
+        self.o_g16 = None
+        if (self.o_gen is not None and R == 64 and S == 256 and self.dt == torch.bfloat16 and not self.E
+                and self.cfg.head_mode == "per_timestep"):
+            self.o_g16 = pk.reserve_raw(np.concatenate([P.gen16_layer_index(sec["WF"].offset, sec["WR"].offset,
+                                                                            sec["WS"].offset, l, R, S) for l in range(L)]))
+            self.o_g16_h1 = pk.reserve_raw(P.gen16_head_index(sec["head_w1"].offset, S, S, S))
+            self.o_g16_h2 = pk.reserve_raw(P.gen16_head_index(sec["head_w2"].offset, S, Cp, Cp))
         # transposed skip kernels of all layers back to back (srwn_skip_dgrad_all streams them in order)
         per = (R // 32) * (S // 16) * 512
         self.o_skipT_all = pk.reserve(L * (R // 32), S // 16)
@@ -1028,7 +1036,12 @@ class WaveNetEngine:
             if self.E or cond is not None:
                 raise NotImplementedError("generate: the conditioned softmax teacher is not built (the conditioned "
                                           "decoder of the reference has the mixture-of-logistics head)")
-            _lib.call("srwn_generate", *common, self.C, self.Kw, md, int(seed), K.abi_dtype(self.dt), st)
+            import os as _os
+            if self.o_g16 is not None and _os.environ.get("SRWN_GEN16", "1") != "0":
+                _lib.call("srwn_generate16", self.wptr(self.o_g16), self.wptr(self.o_g16_h1), self.wptr(self.o_g16_h2),
+                          *common[4:21], self.C, md, int(seed), st)
+            else:
+                _lib.call("srwn_generate", *common, self.C, self.Kw, md, int(seed), K.abi_dtype(self.dt), st)
         return audio, codes, logits
 
     def capture_graphs(self):

@@ -72,6 +72,7 @@ class Packer:
         self.device = device
         self.total = 0
         self._jobs: List[Tuple] = []
+        self._raw: List[Tuple] = []
         self.idx: Optional[torch.Tensor] = None
 
     def reserve(self, mt_count: int, ks_total: int) -> int:
@@ -87,11 +88,21 @@ class Packer:
         self._jobs.append((image_off, src_offset, rows_valid, k_valid, row_stride, k_stride, mt_count, ks_total,
                            ks_offset, ks_count, min(perm_from_ks, 1 << 30)))
 
+    def reserve_raw(self, index) -> int:
+        """An image given by its gather index itself (int32 array, -1 = zero): for fragment layouts other than the 32-row
+        A images `fill` describes (the 16x32 fragments of csrc/srwn_gen16.hip).  Returns its element offset."""
+        off = self.total
+        self.total += int(index.size)
+        self._raw.append((off, index))
+        return off
+
     def finalize(self):
         self.idx = torch.full((max(self.total, 1),), -1, dtype=torch.int32, device=self.device)
         base = self.idx.data_ptr()
         for (off, so, rv, kv, rs, ks_, mt, kst, kso, ksc, pf) in self._jobs:
             call("srwn_pack_a_index", base + 4 * off, so, rv, kv, rs, ks_, mt, kst, kso, ksc, pf, _stream())
+        for off, index in self._raw:
+            self.idx[off:off + index.size].copy_(torch.as_tensor(index.reshape(-1), dtype=torch.int32))
         return self
 
     def gather(self, params_flat: torch.Tensor, out: torch.Tensor):

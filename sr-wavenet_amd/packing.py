@@ -75,3 +75,46 @@ def pack_conv_gen(pk, src_offset: int, K: int, R: int) -> int:
     pk.fill(off, src_offset=src_offset, rows_valid=R, k_valid=K * R, row_stride=1, k_stride=R, mt_count=mt,
             ks_total=ks_total, perm_from_ks=(K - 1) * R // 16)
     return off
+
+
+# ----------------------------------------------------------------------------------------------
+# 16-row x 32-k A fragments of v_mfma_f32_16x16x32_bf16 (csrc/srwn_gen16.hip): lane l holds row (l & 15), k = 8 (l >> 4) + j
+# ----------------------------------------------------------------------------------------------
+def frag16_index(src_offset: int, row0: int, k0: int, row_stride: int, k_stride: int, rows_valid: int, k_valid: int):
+    """Gather index [64 lanes, 8] of one fragment: element (l, j) = W[row0 + (l & 15)][k0 + 8 (l >> 4) + j] at
+    src_offset + row * row_stride + k * k_stride of the flat parameter buffer; -1 (zero) outside rows_valid x k_valid."""
+    import numpy as np
+    lane = np.arange(64)[:, None]
+    j = np.arange(8)[None, :]
+    row = row0 + (lane & 15)
+    k = k0 + 8 * (lane >> 4) + j
+    idx = src_offset + row * row_stride + k * k_stride
+    return np.where((row < rows_valid) & (k < k_valid), idx, -1).astype(np.int32)
+
+
+def gen16_layer_index(sec_wf: int, sec_wr: int, sec_ws: int, l: int, R: int, S: int):
+    """[4 waves][conv ks 0..3 | res ks 0..1 | skip (rb 0..3) x (ks 0..1)] fragment images of layer l: wave w owns output
+    channels 16w.. of the conv (contraction over [tap 0 | tap 1] x R) and of the residual 1x1, and skip channels 64w.."""
+    import numpy as np
+    out = []
+    for w in range(4):
+        for ks in range(4):       # conv: k < R: tap 0 (the delayed tap, ops.py:6-10), k >= R: tap 1; W[k][i][o] at ((l*2+k)*R + i)*R + o
+            tap, i0 = ks // 2, 32 * (ks % 2)
+            out.append(frag16_index(sec_wf + (l * 2 + tap) * R * R, 16 * w, i0, 1, R, R, R))
+        for ks in range(2):       # residual 1x1: W[i][o] at (l*R + i)*R + o
+            out.append(frag16_index(sec_wr + l * R * R, 16 * w, 32 * ks, 1, R, R, R))
+        for rb in range(4):       # skip 1x1: W[i][s] at (l*R + i)*S + s
+            for ks in range(2):
+                out.append(frag16_index(sec_ws + l * R * S, 64 * w + 16 * rb, 32 * ks, 1, S, S, R))
+    return np.stack(out)
+
+
+def gen16_head_index(sec_w: int, Cin: int, Cout_ld: int, Cout_valid: int):
+    """[4 waves][rb 0..3][ks 0..7] fragments of a 256 -> 256 head 1x1 stored [Cin, Cout_ld] (rows >= Cout_valid zero)."""
+    import numpy as np
+    out = []
+    for w in range(4):
+        for rb in range(4):
+            for ks in range(8):
+                out.append(frag16_index(sec_w, 64 * w + 16 * rb, 32 * ks, 1, Cout_ld, Cout_valid, Cin))
+    return np.stack(out)
