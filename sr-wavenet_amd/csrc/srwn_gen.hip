@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a) {
   float* c_b2 = c_b1 + S;            // [LGS]
   float* c_iw = c_b2 + LGS;          // [2][R]
   float* c_ib = c_iw + 2 * R;        // [R]
+  float* c_dec = c_ib + R;           // [256] mu-law decode of every code (ops.py:96-104 has a pow(): one table per launch)
 
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int col = lane & 31, half = lane >> 5;
@@ -104,6 +105,7 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a) {
   if (threadIdx.x < 2 * R) c_iw[threadIdx.x] = a.init_w[threadIdx.x];
   if (threadIdx.x < R) c_ib[threadIdx.x] = a.init_b[threadIdx.x];
   if (threadIdx.x < 64) prev[threadIdx.x] = 0.0f;
+  if (a.Q >= 2) c_dec[threadIdx.x] = gen_mu_law_decode(threadIdx.x < a.Q ? threadIdx.x : a.Q - 1, a.Q);
   lds_dma_copy(wcr, wbuf, LAYER_B, wave, lane, 4);
   __syncthreads();
 
@@ -387,7 +389,7 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a) {
         code = __shfl(pick, src);
       }
       if (lane == 0) {
-        const float smp = gen_mu_law_decode(code, a.Q);
+        const float smp = c_dec[code];
         if (u < a.B) {
           a.audio_out[(size_t)u * a.Tout + t] = smp;
           a.codes_out[(size_t)u * a.Tout + t] = code;
@@ -455,14 +457,14 @@ static int generate_impl(const void* wcr, const void* wskip, const void* w1, con
   if (dtype == SRWN_BF16) {
     auto kfn = SRWN_GEN_PICK(bf16_t, 2);
     const size_t sh = 2 * lfr * sizeof(Frag<bf16_t>) * 64 + 32 * S * sizeof(bf16_t) + 32 * 256 * 4 + 64 * 4 +
-                      (size_t)(2 * nlayers * R + 2 * S + 256 + 3 * R) * 4;
+                      (size_t)(2 * nlayers * R + 2 * S + 256 + 3 * R + 256) * 4;
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     if (e != hipSuccess) return set_error((int)e, "generate: LDS %zu: %s", sh, hipGetErrorString(e));
     hipLaunchKernelGGL(kfn, dim3(groups), dim3(256), sh, st, a);
   } else if (dtype == SRWN_F32) {
     auto kfn = SRWN_GEN_PICK(float, 1);
     const size_t sh = 1 * lfr * sizeof(Frag<float>) * 64 + 32 * S * sizeof(float) + 32 * 256 * 4 + 64 * 4 +
-                      (size_t)(2 * nlayers * R + 2 * S + 256 + 3 * R) * 4;
+                      (size_t)(2 * nlayers * R + 2 * S + 256 + 3 * R + 256) * 4;
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     if (e != hipSuccess) return set_error((int)e, "generate: LDS %zu: %s", sh, hipGetErrorString(e));
     hipLaunchKernelGGL(kfn, dim3(groups), dim3(256), sh, st, a);

@@ -82,6 +82,7 @@ __global__ __launch_bounds__(256) void generate16_kernel(Gen16Args a) {
   float* c_b2 = c_b1 + S;                                     // [256]
   float* c_iw = c_b2 + 256;                                   // [2][R]
   float* c_ib = c_iw + 2 * R;                                 // [R]
+  float* c_dec = c_ib + R;                                    // [256] mu-law decode of every code (one pow() each, once)
 
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int col = lane & 15, rq = lane >> 4;                  // D tile: column (utterance in its block), rows 4 rq + r
@@ -95,10 +96,21 @@ __global__ __launch_bounds__(256) void generate16_kernel(Gen16Args a) {
   if (threadIdx.x < 2 * R) c_iw[threadIdx.x] = a.init_w[threadIdx.x];
   if (threadIdx.x < R) c_ib[threadIdx.x] = a.init_b[threadIdx.x];
   if (threadIdx.x < 64) prev[threadIdx.x] = 0.0f;
+  c_dec[threadIdx.x] = g16_mu_law_decode((int)threadIdx.x < a.Q ? (int)threadIdx.x : a.Q - 1, a.Q);
   __syncthreads();
 
-  auto preload = [&](int l_, int t, Pre& p) {
-    const int l = l_ < a.L ? l_ : a.L - 1;
+  // per-layer scalars live in lane-indexed registers (lane l: layer l) and are fetched with v_readlane: the ring depth,
+  // the ring's element offset, and the slot t % depth the current step writes (kept by increment: no division per layer)
+  const int lyr = lane < a.L ? lane : a.L - 1;
+  const int depthv = a.dil[lyr] + 1;
+  const int roffv = (int)a.ring_off[lyr];
+  int curv = 0;
+  auto wrap = [](int x, int depth) { return x >= depth ? x - depth : x; };
+
+  // the operands of layer l at the step whose write slots are curv + ahead: the delayed tap x_l[t - d] sits in slot
+  // (t - d) mod (d + 1) = (t + 1) mod (d + 1), the slot after the one the step writes -- which, for t < d, nobody has
+  // written yet: the caller hands the rings over zero-filled, and that is the zero padding of the causal conv (ops.py:6-10)
+  auto preload = [&](int l, int ahead, Pre& p) {
     const T* w = wl + ((size_t)l * LAYER_FR + wave * 14) * FR + lane * 8;
 #pragma unroll
     for (int f = 0; f < 4; ++f) p.wc[f] = load_nat(w + f * FR);
@@ -108,21 +120,21 @@ __global__ __launch_bounds__(256) void generate16_kernel(Gen16Args a) {
     for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) p.ws[rb][ks] = load_nat(w + (6 + 2 * rb + ks) * FR);
-    const int d = a.dil[l], depth = d + 1;
-    const int td = t - d;
-    const int slot = (td >= 0 ? td : 0) % depth;
+    const int depth = __builtin_amdgcn_readlane(depthv, l);
+    const int roff = __builtin_amdgcn_readlane(roffv, l);
+    int slot = wrap(__builtin_amdgcn_readlane(curv, l) + 1, depth);
+    if (ahead) slot = wrap(slot + 1, depth);
+    const T* rp = ring + roff + (size_t)slot * (32 * R) + col * R + 8 * rq;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int c2 = 0; c2 < 2; ++c2)
-        p.x0[ks][c2] = load_nat(ring + a.ring_off[l] + ((size_t)slot * 32 + 16 * c2 + col) * R + 32 * ks + 8 * rq);
+      for (int c2 = 0; c2 < 2; ++c2) p.x0[ks][c2] = load_nat(rp + 16 * c2 * R + 32 * ks);
   };
 
   Pre pa, pb;
   for (int t = 0; t < a.nsteps; ++t) {
-    // (layer 0's operands were requested by the last layer of the step before -- its ring slot is at least one step old --
-    // unless the layers do not alternate back onto the same set)
-    if (t == 0 || (a.L & 1)) preload(0, t, pa);
+    // (layer 0's operands were requested by the top layer of the step before: its ring slot is at least one step old)
+    if (t == 0) preload(0, 0, pa);
     // ---- input conv with RightShift (model.py:172-173): h0[t] = w[0] audio[t-2] + w[1] audio[t-1] + b; this wave's 16 channels
     float xs[2][4];                              // the wave's slice of the current layer input (as stored: rounded)
 #pragma unroll
@@ -155,17 +167,18 @@ __global__ __launch_bounds__(256) void generate16_kernel(Gen16Args a) {
     wg_barrier();
 
     auto layer = [&](int l, const Pre& p, Pre& pnext) {
-      const int d = a.dil[l], depth = d + 1;
       // x_l[t] of the workgroup -> the layer's ring (read d steps from now): each wave copies eight utterances' rows
       {
         const int ul = 8 * wave + (lane >> 3);
         const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (size_t)ul * LSX + (lane & 7) * 8);
-        *reinterpret_cast<f32x4*>(ring + a.ring_off[l] + ((size_t)(t % depth) * 32 + ul) * R + (lane & 7) * 8) = v;
+        const int slot = __builtin_amdgcn_readlane(curv, l), roff = __builtin_amdgcn_readlane(roffv, l);
+        *reinterpret_cast<f32x4*>(ring + roff + (size_t)slot * (32 * R) + ul * R + (lane & 7) * 8) = v;
       }
       // the next layer's weights and delayed tap, one layer ahead (after the top layer: layer 0 of the next step)
-      if (l + 1 < a.L) preload(l + 1, t, pnext);
-      else if (!(a.L & 1)) preload(0, t + 1, pnext);
-      const bool tap0 = (t - d) >= 0;
+      {
+        const bool top = l + 1 >= a.L;
+        preload(top ? 0 : l + 1, top ? 1 : 0, pnext);
+      }
       f32x4 accF[2];
 #pragma unroll
       for (int c2 = 0; c2 < 2; ++c2) {
@@ -178,7 +191,7 @@ __global__ __launch_bounds__(256) void generate16_kernel(Gen16Args a) {
         for (int c2 = 0; c2 < 2; ++c2) {
           const Frag<T> x1 = load_nat(xb + (size_t)(16 * c2 + col) * LSX + 32 * ks + 8 * rq);
           mma16(accF[c2], p.wc[2 + ks], x1);
-          mma16(accF[c2], p.wc[ks], tap0 ? p.x0[ks][c2] : zero_frag<T>());
+          mma16(accF[c2], p.wc[ks], p.x0[ks][c2]);
         }
       // tanh, gate (ops.py:28-36); z as the training graph stores it
 #pragma unroll
@@ -224,20 +237,26 @@ __global__ __launch_bounds__(256) void generate16_kernel(Gen16Args a) {
       }
       wg_barrier();
     };
-    for (int l = 0; l < a.L; l += 2) {
+    for (int l = 0; l + 1 < a.L; l += 2) {         // the two operand sets alternate
       layer(l, pa, pb);
-      if (l + 1 >= a.L) break;
       layer(l + 1, pb, pa);
     }
+    if (a.L & 1) {                                 // an odd stack: the top layer leaves the next step's layer 0 in the other set
+      layer(a.L - 1, pa, pb);
+      pa = pb;
+    }
+    curv = wrap(curv + 1, depthv);
 
     // ---- head: relu(sum skip) -> 1x1 + relu -> 1x1 (model.py:51-56); each wave owns 64 of the 256 rows of both products,
     // the activations cross the waves through LDS
-    auto head_product = [&](const T* wimg, const float* bias, f32x4 (&acc)[4][2]) {
-      Frag<T> w[4][8];                          // all of the wave's fragments requested before the first is used
+    Frag<T> hw[4][8];                           // the wave's 64 rows of one head 1x1: requested well before their products
+    auto head_load = [&](const T* wimg) {
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) w[rb][ks] = load_nat(wimg + ((size_t)(wave * 4 + rb) * 8 + ks) * FR + lane * 8);
+        for (int ks = 0; ks < 8; ++ks) hw[rb][ks] = load_nat(wimg + ((size_t)(wave * 4 + rb) * 8 + ks) * FR + lane * 8);
+    };
+    auto head_product = [&](const float* bias, f32x4 (&acc)[4][2]) {
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
@@ -250,7 +269,7 @@ __global__ __launch_bounds__(256) void generate16_kernel(Gen16Args a) {
         for (int c2 = 0; c2 < 2; ++c2) {
           const Frag<T> bf = load_nat(hx + (size_t)(16 * c2 + col) * LSH + 32 * ks + 8 * rq);
 #pragma unroll
-          for (int rb = 0; rb < 4; ++rb) mma16(acc[rb][c2], w[rb][ks], bf);
+          for (int rb = 0; rb < 4; ++rb) mma16(acc[rb][c2], hw[rb][ks], bf);
         }
     };
     auto relu_to_hx = [&](const f32x4 (&acc)[4][2]) {
@@ -261,15 +280,17 @@ __global__ __launch_bounds__(256) void generate16_kernel(Gen16Args a) {
           store4(hx + (size_t)(16 * c2 + col) * LSH + 64 * wave + 16 * rb + 4 * rq, fmaxf(acc[rb][c2][0], 0.f),
                  fmaxf(acc[rb][c2][1], 0.f), fmaxf(acc[rb][c2][2], 0.f), fmaxf(acc[rb][c2][3], 0.f));
     };
+    head_load(reinterpret_cast<const T*>(a.wh1));
     relu_to_hx(accS);
     wg_barrier();
     f32x4 acc1[4][2];
-    head_product(reinterpret_cast<const T*>(a.wh1), c_b1, acc1);
+    head_product(c_b1, acc1);
+    head_load(reinterpret_cast<const T*>(a.wh2));   // behind the products, ahead of the exchange
     wg_barrier();                                 // everyone has read r0
     relu_to_hx(acc1);
     wg_barrier();
     f32x4 acc2[4][2];
-    head_product(reinterpret_cast<const T*>(a.wh2), c_b2, acc2);
+    head_product(c_b2, acc2);
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
@@ -278,56 +299,94 @@ __global__ __launch_bounds__(256) void generate16_kernel(Gen16Args a) {
     wg_barrier();
 
     // ---- softmax over the C classes, pick a code, mu-law decode: wave w serves utterances 8w..8w+7 with lanes = classes
-    // (as generate_kernel: 4 classes per lane, shuffle reductions)
-    for (int i = 0; i < 8; ++i) {
-      const int ul = 8 * wave + i;
-      const int u = u0 + ul;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(lgl + ul * LGS + 4 * lane);
-      float m = -INFINITY; int am = 0;
+    // (4 per lane, as generate_kernel -- same sums in the same order, same counter-based uniforms); the eight utterances'
+    // shuffle chains are independent and written round by round so that they overlap
+    {
+      f32x4 v[8];
+      float m[8];
+      int am[8];
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (4 * lane + e < a.C && v[e] > m) { m = v[e]; am = 4 * lane + e; }
+      for (int i = 0; i < 8; ++i) {
+        v[i] = *reinterpret_cast<const f32x4*>(lgl + (8 * wave + i) * LGS + 4 * lane);
+        m[i] = -INFINITY; am[i] = 0;
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        const float mo = __shfl_xor(m, off); const int ao = __shfl_xor(am, off);
-        if (mo > m || (mo == m && ao < am)) { m = mo; am = ao; }
+        for (int e = 0; e < 4; ++e)
+          if (4 * lane + e < a.C && v[i][e] > m[i]) { m[i] = v[i][e]; am[i] = 4 * lane + e; }
       }
-      int code = am;
-      if (a.mode == 1) {   // categorical sample from softmax(logits): inclusive prefix sums over the lanes
-        float ev[4], loc = 0.0f;
+      int code[8];
+      if (a.mode == 0) {   // argmax, ties to the lower class
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { ev[e] = (4 * lane + e < a.C) ? __expf(v[e] - m) : 0.0f; loc += ev[e]; }
-        float inc = loc;
+        for (int off = 32; off > 0; off >>= 1)
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-          const float o = __shfl_up(inc, off);
-          if (lane >= off) inc += o;
+          for (int i = 0; i < 8; ++i) {
+            const float mo = __shfl_xor(m[i], off); const int ao = __shfl_xor(am[i], off);
+            if (mo > m[i] || (mo == m[i] && ao < am[i])) { m[i] = mo; am[i] = ao; }
+          }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) code[i] = am[i];
+      } else {             // categorical sample from softmax(logits): inclusive prefix sums over the lanes
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) m[i] = fmaxf(m[i], __shfl_xor(m[i], off));
+        float ev[8][4], loc[8], inc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          loc[i] = 0.0f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { ev[i][e] = (4 * lane + e < a.C) ? __expf(v[i][e] - m[i]) : 0.0f; loc[i] += ev[i][e]; }
+          inc[i] = loc[i];
         }
-        const float total = __shfl(inc, 63);
-        const float target = g16_uniform(a.seed, (unsigned)u, (unsigned)t) * total;
-        const unsigned long long hit = __ballot(inc > target);
-        const int src = hit ? (__ffsll((long long)hit) - 1) : 63;
-        float run = inc - loc;
-        int pick = 4 * lane + 3;
 #pragma unroll
-        for (int e = 3; e >= 0; --e) { if (run + ev[0] + (e > 0 ? ev[1] : 0.f) + (e > 1 ? ev[2] : 0.f) + (e > 2 ? ev[3] : 0.f) > target) pick = 4 * lane + e; }
-        if (pick >= a.C) pick = a.C - 1;
-        code = __shfl(pick, src);
+        for (int off = 1; off < 64; off <<= 1)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float o = __shfl_up(inc[i], off);
+            if (lane >= off) inc[i] += o;
+          }
+        // lane j draws the uniform of utterance j & 7 once
+        const float uni = g16_uniform(a.seed, (unsigned)(u0 + 8 * wave + (lane & 7)), (unsigned)t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float total = __shfl(inc[i], 63);
+          const float target = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, uni), i)) * total;
+          const unsigned long long hit = __ballot(inc[i] > target);
+          const int src = hit ? (__ffsll((long long)hit) - 1) : 63;
+          const float run = inc[i] - loc[i];
+          int pick = 4 * lane + 3;
+#pragma unroll
+          for (int e = 3; e >= 0; --e) {
+            if (run + ev[i][0] + (e > 0 ? ev[i][1] : 0.f) + (e > 1 ? ev[i][2] : 0.f) + (e > 2 ? ev[i][3] : 0.f) > target)
+              pick = 4 * lane + e;
+          }
+          if (pick >= a.C) pick = a.C - 1;
+          code[i] = __shfl(pick, src);
+        }
       }
-      if (lane == 0) {
-        const float smp = g16_mu_law_decode(code, a.Q);
+      if (lane < 8) {      // lane i publishes utterance i
+        int cd = code[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) cd = (lane == i) ? code[i] : cd;
+        const int ul = 8 * wave + lane, u = u0 + ul;
+        const float smp = c_dec[cd];
         if (u < a.B) {
           a.audio_out[(size_t)u * a.Tout + t] = smp;
-          a.codes_out[(size_t)u * a.Tout + t] = code;
+          a.codes_out[(size_t)u * a.Tout + t] = cd;
         }
         prev[32 + ul] = prev[ul];
         prev[ul] = smp;
       }
-      if (a.logits_out && u < a.B && 4 * lane < a.C) {
-        float* lo = a.logits_out + ((size_t)u * a.Tout + t) * a.C + 4 * lane;
+      if (a.logits_out) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (4 * lane + e < a.C) lo[e] = v[e];
+        for (int i = 0; i < 8; ++i) {
+          const int u = u0 + 8 * wave + i;
+          if (u < a.B && 4 * lane < a.C) {
+            float* lo = a.logits_out + ((size_t)u * a.Tout + t) * a.C + 4 * lane;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (4 * lane + e < a.C) lo[e] = v[i][e];
+          }
+        }
       }
     }
     wg_barrier();
@@ -353,7 +412,8 @@ extern "C" int srwn_generate16(const void* wl, const void* wh1, const void* wh2,
       !codes_out || !dilations)
     return set_error(SRWN_E_NULL, "generate16: null pointer");
   if (C < 2 || C > 256) return set_error(SRWN_E_UNSUPPORTED, "generate16: C=%d (2..256)", C);
-  if (B < 0 || nsteps < 0 || nsteps > Tout || nlayers < 1 || nlayers > kG16MaxLayers || (mode != 0 && mode != 1))
+  if (B < 0 || nsteps < 0 || nsteps > Tout || nlayers < 1 || nlayers > kG16MaxLayers ||
+      (mode != 0 && mode != 1))
     return set_error(SRWN_E_SHAPE, "generate16: B=%d nsteps=%d Tout=%d layers=%d mode=%d", B, nsteps, Tout, nlayers, mode);
   Gen16Args a;
   a.wl = wl; a.wh1 = wh1; a.wh2 = wh2; a.bias_f = bias_f; a.bias_r = bias_r; a.bs_sum = bs_sum; a.b1 = b1; a.b2 = b2;
@@ -371,7 +431,7 @@ extern "C" int srwn_generate16(const void* wl, const void* wh1, const void* wh2,
   }
   a.ring_group_elems = off;
   const unsigned groups = (unsigned)((B + 31) / 32);
-  const size_t sh = (size_t)(2 * 32 * LSX + 32 * LSH) * sizeof(T) + (size_t)(32 * LGS + 64 + 2 * nlayers * R + 2 * S + 256 + 3 * R) * 4;
+  const size_t sh = (size_t)(2 * 32 * LSX + 32 * LSH) * sizeof(T) + (size_t)(32 * LGS + 64 + 2 * nlayers * R + 2 * S + 256 + 3 * R + 256) * 4;
   hipError_t e = hipFuncSetAttribute((const void*)generate16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
   if (e != hipSuccess) return set_error((int)e, "generate16: LDS %zu: %s", sh, hipGetErrorString(e));
   hipLaunchKernelGGL(generate16_kernel, dim3(groups), dim3(256), sh, (hipStream_t)stream, a);
