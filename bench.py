@@ -312,7 +312,7 @@ def main():
                 extra["gen_rtf_per_stream"] = g["1wg"] * 16000 / 1e6          # > 1: slower than real time
                 extra["gen_us_per_sample_2048_streams"] = g["2048"]
                 extra["gen_aggregate_x_real_time_2048_streams"] = 2048 / (g["2048"] * 16000 / 1e6)
-                extra["gen_config"] = "30-layer mu-law teacher, bf16, 256 sampled steps; 1 workgroup = 32 streams"
+                extra["gen_config"] = "30-layer mu-law teacher, bf16, 256 sampled steps; '1wg' = 32 streams (one ring group)"
             except Exception as e:
                 extra["gen_error"] = repr(e)
             out["extra"] = extra

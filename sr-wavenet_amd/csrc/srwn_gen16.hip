@@ -63,12 +63,19 @@ constexpr int FR = 512;                       // elements of one fragment image 
 constexpr int LAYER_FR = 4 * 14;              // fragment images per layer
 
 // one layer's operands of a wave that do not depend on the step's activations: its weight fragments and the delayed tap
-struct Pre {
+// NCB: 16-utterance column blocks per workgroup (2: one workgroup per ring group of 32 utterances; 1: two workgroups share
+// a ring group, each half the work per layer -- the choice whenever the utterances do not fill the chip's CUs otherwise)
+template <int NCB>
+struct PreT {
   Frag<T> wc[4], wr[2], ws[4][2];
-  Frag<T> x0[2][2];                           // [k-step of the delayed tap][column block]
+  Frag<T> x0[2][NCB];                         // [k-step of the delayed tap][column block]
 };
 
+template <int NCB>
 __global__ __launch_bounds__(256) void generate16_kernel(Gen16Args a) {
+  constexpr int NU = 16 * NCB;                // utterances of this workgroup
+  constexpr int NI = 4 * NCB;                 // utterances a wave samples
+  using Pre = PreT<NCB>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* xb = reinterpret_cast<T*>(smem);                         // [32][LSX] the layer input x_l[t]
   T* cb = xb + 32 * LSX;                                      // [32][LSX] the gate output c_l[t]
@@ -86,8 +93,9 @@ __global__ __launch_bounds__(256) void generate16_kernel(Gen16Args a) {
 
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int col = lane & 15, rq = lane >> 4;                  // D tile: column (utterance in its block), rows 4 rq + r
-  const int u0 = blockIdx.x * 32;
-  T* ring = reinterpret_cast<T*>(a.ring) + (size_t)blockIdx.x * a.ring_group_elems;
+  const int u0 = blockIdx.x * NU;
+  const int urow = u0 & 31;                                   // this workgroup's first row inside its ring group
+  T* ring = reinterpret_cast<T*>(a.ring) + (size_t)(u0 >> 5) * a.ring_group_elems + urow * R;
   const T* wl = reinterpret_cast<const T*>(a.wl);
 
   for (int i = threadIdx.x; i < a.L * R; i += 256) { c_bf[i] = a.bias_f[i]; c_br[i] = a.bias_r[i]; }
@@ -128,7 +136,7 @@ __global__ __launch_bounds__(256) void generate16_kernel(Gen16Args a) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int c2 = 0; c2 < 2; ++c2) p.x0[ks][c2] = load_nat(rp + 16 * c2 * R + 32 * ks);
+      for (int c2 = 0; c2 < NCB; ++c2) p.x0[ks][c2] = load_nat(rp + 16 * c2 * R + 32 * ks);
   };
 
   Pre pa, pb;
@@ -136,9 +144,9 @@ __global__ __launch_bounds__(256) void generate16_kernel(Gen16Args a) {
     // (layer 0's operands were requested by the top layer of the step before: its ring slot is at least one step old)
     if (t == 0) preload(0, 0, pa);
     // ---- input conv with RightShift (model.py:172-173): h0[t] = w[0] audio[t-2] + w[1] audio[t-1] + b; this wave's 16 channels
-    float xs[2][4];                              // the wave's slice of the current layer input (as stored: rounded)
+    float xs[NCB][4];                              // the wave's slice of the current layer input (as stored: rounded)
 #pragma unroll
-    for (int c2 = 0; c2 < 2; ++c2) {
+    for (int c2 = 0; c2 < NCB; ++c2) {
       const int ug = u0 + 16 * c2 + col;
       float a1 = 0.0f, a2 = 0.0f;
       if (ug < a.B) {
@@ -157,11 +165,11 @@ __global__ __launch_bounds__(256) void generate16_kernel(Gen16Args a) {
       }
       store4(xb + (size_t)(16 * c2 + col) * LSX + 16 * wave + 4 * rq, xs[c2][0], xs[c2][1], xs[c2][2], xs[c2][3]);
     }
-    f32x4 accS[4][2];
+    f32x4 accS[4][NCB];
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-      for (int c2 = 0; c2 < 2; ++c2)
+      for (int c2 = 0; c2 < NCB; ++c2)
 #pragma unroll
         for (int r = 0; r < 4; ++r) accS[rb][c2][r] = c_bs[64 * wave + 16 * rb + 4 * rq + r];
     wg_barrier();
@@ -170,32 +178,34 @@ __global__ __launch_bounds__(256) void generate16_kernel(Gen16Args a) {
       // x_l[t] of the workgroup -> the layer's ring (read d steps from now): each wave copies eight utterances' rows
       {
         const int ul = 8 * wave + (lane >> 3);
-        const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (size_t)ul * LSX + (lane & 7) * 8);
         const int slot = __builtin_amdgcn_readlane(curv, l), roff = __builtin_amdgcn_readlane(roffv, l);
-        *reinterpret_cast<f32x4*>(ring + roff + (size_t)slot * (32 * R) + ul * R + (lane & 7) * 8) = v;
+        if (8 * wave < NU) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (size_t)ul * LSX + (lane & 7) * 8);
+          *reinterpret_cast<f32x4*>(ring + roff + (size_t)slot * (32 * R) + ul * R + (lane & 7) * 8) = v;
+        }
       }
       // the next layer's weights and delayed tap, one layer ahead (after the top layer: layer 0 of the next step)
       {
         const bool top = l + 1 >= a.L;
         preload(top ? 0 : l + 1, top ? 1 : 0, pnext);
       }
-      f32x4 accF[2];
+      f32x4 accF[NCB];
 #pragma unroll
-      for (int c2 = 0; c2 < 2; ++c2) {
+      for (int c2 = 0; c2 < NCB; ++c2) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) accF[c2][r] = c_bf[l * R + 16 * wave + 4 * rq + r];
       }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2) {
+        for (int c2 = 0; c2 < NCB; ++c2) {
           const Frag<T> x1 = load_nat(xb + (size_t)(16 * c2 + col) * LSX + 32 * ks + 8 * rq);
           mma16(accF[c2], p.wc[2 + ks], x1);
           mma16(accF[c2], p.wc[ks], p.x0[ks][c2]);
         }
       // tanh, gate (ops.py:28-36); z as the training graph stores it
 #pragma unroll
-      for (int c2 = 0; c2 < 2; ++c2) {
+      for (int c2 = 0; c2 < NCB; ++c2) {
         float cv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -206,21 +216,21 @@ __global__ __launch_bounds__(256) void generate16_kernel(Gen16Args a) {
         store4(cb + (size_t)(16 * c2 + col) * LSX + 16 * wave + 4 * rq, cv[0], cv[1], cv[2], cv[3]);
       }
       wg_barrier();
-      Frag<T> cf[2][2];
+      Frag<T> cf[2][NCB];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2) cf[ks][c2] = load_nat(cb + (size_t)(16 * c2 + col) * LSX + 32 * ks + 8 * rq);
-      f32x4 accR[2];
+        for (int c2 = 0; c2 < NCB; ++c2) cf[ks][c2] = load_nat(cb + (size_t)(16 * c2 + col) * LSX + 32 * ks + 8 * rq);
+      f32x4 accR[NCB];
 #pragma unroll
-      for (int c2 = 0; c2 < 2; ++c2) {
+      for (int c2 = 0; c2 < NCB; ++c2) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) accR[c2][r] = c_br[l * R + 16 * wave + 4 * rq + r];
       }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2) mma16(accR[c2], p.wr[ks], cf[ks][c2]);
+        for (int c2 = 0; c2 < NCB; ++c2) mma16(accR[c2], p.wr[ks], cf[ks][c2]);
       // this wave's quarter of the skip 1x1 (ops.py:44), accumulated over layers (model.py:50): in the matrix pipe behind
       // the residual products while the VALU finishes the layer
 #pragma unroll
@@ -228,9 +238,9 @@ __global__ __launch_bounds__(256) void generate16_kernel(Gen16Args a) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-          for (int c2 = 0; c2 < 2; ++c2) mma16(accS[rb][c2], p.ws[rb][ks], cf[ks][c2]);
+          for (int c2 = 0; c2 < NCB; ++c2) mma16(accS[rb][c2], p.ws[rb][ks], cf[ks][c2]);
 #pragma unroll
-      for (int c2 = 0; c2 < 2; ++c2) {
+      for (int c2 = 0; c2 < NCB; ++c2) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) xs[c2][r] = (float)(T)((xs[c2][r] + accR[c2][r]) * kSqrtHalf);
         store4(xb + (size_t)(16 * c2 + col) * LSX + 16 * wave + 4 * rq, xs[c2][0], xs[c2][1], xs[c2][2], xs[c2][3]);
@@ -256,82 +266,82 @@ __global__ __launch_bounds__(256) void generate16_kernel(Gen16Args a) {
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) hw[rb][ks] = load_nat(wimg + ((size_t)(wave * 4 + rb) * 8 + ks) * FR + lane * 8);
     };
-    auto head_product = [&](const float* bias, f32x4 (&acc)[4][2]) {
+    auto head_product = [&](const float* bias, f32x4 (&acc)[4][NCB]) {
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2)
+        for (int c2 = 0; c2 < NCB; ++c2)
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[rb][c2][r] = bias[64 * wave + 16 * rb + 4 * rq + r];
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2) {
+        for (int c2 = 0; c2 < NCB; ++c2) {
           const Frag<T> bf = load_nat(hx + (size_t)(16 * c2 + col) * LSH + 32 * ks + 8 * rq);
 #pragma unroll
           for (int rb = 0; rb < 4; ++rb) mma16(acc[rb][c2], hw[rb][ks], bf);
         }
     };
-    auto relu_to_hx = [&](const f32x4 (&acc)[4][2]) {
+    auto relu_to_hx = [&](const f32x4 (&acc)[4][NCB]) {
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2)
+        for (int c2 = 0; c2 < NCB; ++c2)
           store4(hx + (size_t)(16 * c2 + col) * LSH + 64 * wave + 16 * rb + 4 * rq, fmaxf(acc[rb][c2][0], 0.f),
                  fmaxf(acc[rb][c2][1], 0.f), fmaxf(acc[rb][c2][2], 0.f), fmaxf(acc[rb][c2][3], 0.f));
     };
     head_load(reinterpret_cast<const T*>(a.wh1));
     relu_to_hx(accS);
     wg_barrier();
-    f32x4 acc1[4][2];
+    f32x4 acc1[4][NCB];
     head_product(c_b1, acc1);
     head_load(reinterpret_cast<const T*>(a.wh2));   // behind the products, ahead of the exchange
     wg_barrier();                                 // everyone has read r0
     relu_to_hx(acc1);
     wg_barrier();
-    f32x4 acc2[4][2];
+    f32x4 acc2[4][NCB];
     head_product(c_b2, acc2);
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-      for (int c2 = 0; c2 < 2; ++c2)
+      for (int c2 = 0; c2 < NCB; ++c2)
         *reinterpret_cast<f32x4*>(lgl + (size_t)(16 * c2 + col) * LGS + 64 * wave + 16 * rb + 4 * rq) = acc2[rb][c2];
     wg_barrier();
 
-    // ---- softmax over the C classes, pick a code, mu-law decode: wave w serves utterances 8w..8w+7 with lanes = classes
+    // ---- softmax over the C classes, pick a code, mu-law decode: wave w serves NI utterances with lanes = classes
     // (4 per lane, as generate_kernel -- same sums in the same order, same counter-based uniforms); the eight utterances'
     // shuffle chains are independent and written round by round so that they overlap
     {
-      f32x4 v[8];
-      float m[8];
-      int am[8];
+      f32x4 v[NI];
+      float m[NI];
+      int am[NI];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        v[i] = *reinterpret_cast<const f32x4*>(lgl + (8 * wave + i) * LGS + 4 * lane);
+      for (int i = 0; i < NI; ++i) {
+        v[i] = *reinterpret_cast<const f32x4*>(lgl + (NI * wave + i) * LGS + 4 * lane);
         m[i] = -INFINITY; am[i] = 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           if (4 * lane + e < a.C && v[i][e] > m[i]) { m[i] = v[i][e]; am[i] = 4 * lane + e; }
       }
-      int code[8];
+      int code[NI];
       if (a.mode == 0) {   // argmax, ties to the lower class
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1)
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
+          for (int i = 0; i < NI; ++i) {
             const float mo = __shfl_xor(m[i], off); const int ao = __shfl_xor(am[i], off);
             if (mo > m[i] || (mo == m[i] && ao < am[i])) { m[i] = mo; am[i] = ao; }
           }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) code[i] = am[i];
+        for (int i = 0; i < NI; ++i) code[i] = am[i];
       } else {             // categorical sample from softmax(logits): inclusive prefix sums over the lanes
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1)
 #pragma unroll
-          for (int i = 0; i < 8; ++i) m[i] = fmaxf(m[i], __shfl_xor(m[i], off));
-        float ev[8][4], loc[8], inc[8];
+          for (int i = 0; i < NI; ++i) m[i] = fmaxf(m[i], __shfl_xor(m[i], off));
+        float ev[NI][4], loc[NI], inc[NI];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NI; ++i) {
           loc[i] = 0.0f;
 #pragma unroll
           for (int e = 0; e < 4; ++e) { ev[i][e] = (4 * lane + e < a.C) ? __expf(v[i][e] - m[i]) : 0.0f; loc[i] += ev[i][e]; }
@@ -340,14 +350,14 @@ __global__ __launch_bounds__(256) void generate16_kernel(Gen16Args a) {
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1)
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
+          for (int i = 0; i < NI; ++i) {
             const float o = __shfl_up(inc[i], off);
             if (lane >= off) inc[i] += o;
           }
         // lane j draws the uniform of utterance j & 7 once
-        const float uni = g16_uniform(a.seed, (unsigned)(u0 + 8 * wave + (lane & 7)), (unsigned)t);
+        const float uni = g16_uniform(a.seed, (unsigned)(u0 + NI * wave + (lane & (NI - 1))), (unsigned)t);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NI; ++i) {
           const float total = __shfl(inc[i], 63);
           const float target = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, uni), i)) * total;
           const unsigned long long hit = __ballot(inc[i] > target);
@@ -363,11 +373,11 @@ __global__ __launch_bounds__(256) void generate16_kernel(Gen16Args a) {
           code[i] = __shfl(pick, src);
         }
       }
-      if (lane < 8) {      // lane i publishes utterance i
+      if (lane < NI) {     // lane i publishes utterance i
         int cd = code[0];
 #pragma unroll
-        for (int i = 1; i < 8; ++i) cd = (lane == i) ? code[i] : cd;
-        const int ul = 8 * wave + lane, u = u0 + ul;
+        for (int i = 1; i < NI; ++i) cd = (lane == i) ? code[i] : cd;
+        const int ul = NI * wave + lane, u = u0 + ul;
         const float smp = c_dec[cd];
         if (u < a.B) {
           a.audio_out[(size_t)u * a.Tout + t] = smp;
@@ -378,8 +388,8 @@ __global__ __launch_bounds__(256) void generate16_kernel(Gen16Args a) {
       }
       if (a.logits_out) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int u = u0 + 8 * wave + i;
+        for (int i = 0; i < NI; ++i) {
+          const int u = u0 + NI * wave + i;
           if (u < a.B && 4 * lane < a.C) {
             float* lo = a.logits_out + ((size_t)u * a.Tout + t) * a.C + 4 * lane;
 #pragma unroll
@@ -430,10 +440,14 @@ extern "C" int srwn_generate16(const void* wl, const void* wh1, const void* wh2,
     }
   }
   a.ring_group_elems = off;
-  const unsigned groups = (unsigned)((B + 31) / 32);
+  // half-size workgroups while they still find a CU each (and always for a single stream's latency)
+  bool half = (B + 15) / 16 <= num_cus();
+  if (const char* e = getenv("SRWN_GEN16_NCB")) half = atoi(e) == 1;   // (tests: both bodies at any batch)
+  const unsigned groups = half ? (unsigned)((B + 15) / 16) : (unsigned)((B + 31) / 32);
   const size_t sh = (size_t)(2 * 32 * LSX + 32 * LSH) * sizeof(T) + (size_t)(32 * LGS + 64 + 2 * nlayers * R + 2 * S + 256 + 3 * R + 256) * 4;
-  hipError_t e = hipFuncSetAttribute((const void*)generate16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+  auto kfn = half ? generate16_kernel<1> : generate16_kernel<2>;
+  hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
   if (e != hipSuccess) return set_error((int)e, "generate16: LDS %zu: %s", sh, hipGetErrorString(e));
-  hipLaunchKernelGGL(generate16_kernel, dim3(groups), dim3(256), sh, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(kfn, dim3(groups), dim3(256), sh, (hipStream_t)stream, a);
   return check_launch("generate16");
 }

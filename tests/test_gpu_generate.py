@@ -78,6 +78,64 @@ def test_sampling_follows_the_softmax():
     assert np.abs(freq - p).max() < 0.02
 
 
+@pytest.mark.parametrize("dil,B,T", [([1, 2, 4, 8, 16, 32, 1, 2, 4], 37, 150), ([1, 2, 4, 8, 16, 32, 64, 1], 16, 200),
+                                     ([3], 1, 9), ([1, 2], 70, 5)])
+def test_latency_body_equals_throughput_body(monkeypatch, dil, B, T):
+    """The bf16 teacher's latency-optimised generator (csrc/srwn_gen16.hip: a layer's channels split over the waves) against
+    the throughput kernel (csrc/srwn_gen.hip: every wave runs the whole chain) on the same weights, teacher-forced: the
+    same logits up to the accumulation order of the two MFMA shapes; its two workgroup sizes agree bit for bit; odd and
+    even stacks, ragged batches, steps before the first delayed tap exists."""
+    eng, sp = _engine(torch.bfloat16, dil, B, T)
+    assert eng.o_g16 is not None
+    audio = dev(O.synthetic_audio(B, T, seed=21))
+    out = {}
+    for name, env in (("thr", {"SRWN_GEN16": "0"}), ("lat1", {"SRWN_GEN16": "1", "SRWN_GEN16_NCB": "1"}),
+                      ("lat2", {"SRWN_GEN16": "1", "SRWN_GEN16_NCB": "2"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        out[name] = eng.generate(T, mode="sample", seed=3, forced=audio, want_logits=True)
+    assert torch.equal(out["lat1"][2], out["lat2"][2]) and torch.equal(out["lat1"][1], out["lat2"][1])
+    assert torch.equal(out["lat1"][0], out["lat2"][0])
+    a, b = out["lat1"][2].cpu().numpy(), out["thr"][2].cpu().numpy()
+    assert np.isfinite(a).all() and rel_err(a, b) < 2e-2          # bf16: one rounding of a layer output = 4e-3
+    # same uniforms, (nearly) the same distributions: the sampled codes agree except where a draw sits on a boundary
+    assert (out["lat1"][1] == out["thr"][1]).float().mean() > 0.9
+
+
+@pytest.mark.parametrize("ncb", ["1", "2"])
+def test_latency_body_free_running(monkeypatch, ncb):
+    monkeypatch.setenv("SRWN_GEN16_NCB", ncb)
+    dil = [1, 2, 4, 8, 16, 1, 2, 4]
+    eng, _ = _engine(torch.bfloat16, dil, 35, 200)
+    assert eng.o_g16 is not None
+    a1, c1, _ = eng.generate(200, mode="argmax")
+    a2, c2, _ = eng.generate(200, mode="argmax")
+    assert torch.equal(c1, c2) and torch.equal(a1, a2)          # deterministic
+    _, c3, _ = eng.generate(200, mode="argmax", forced=a1)      # its own output, teacher-forced: the same decisions
+    assert torch.equal(c1, c3)
+    dec = O.mu_law_decode(c1.cpu().numpy(), 256)                # emitted samples = decode of the emitted codes, bit-exact
+    assert np.array_equal(a1.cpu().numpy().view(np.uint32), dec.view(np.uint32))
+    _, s1, lg = eng.generate(200, mode="sample", seed=1, want_logits=True)
+    _, s1b, _ = eng.generate(200, mode="sample", seed=1)
+    _, s2, _ = eng.generate(200, mode="sample", seed=2)
+    assert torch.equal(s1, s1b) and not torch.equal(s1, s2)
+    assert int(s1.min()) >= 0 and int(s1.max()) < 256
+    # draw for draw: the code is the first class whose inclusive softmax prefix exceeds the step's uniform
+    lg = lg.cpu().numpy().astype(np.float64)
+    pr = np.exp(lg - lg.max(-1, keepdims=True))
+    cdf = np.cumsum(pr, -1) / pr.sum(-1, keepdims=True)
+    s1n = s1.cpu().numpy()
+    bad = 0
+    for u in (0, 17, 34):
+        for t in range(0, 200, 7):
+            un = float(_gen_uniform(1, u, t))
+            k = int(np.searchsorted(cdf[u, t], un, side="right"))
+            if k != s1n[u, t]:
+                lo = cdf[u, t, s1n[u, t] - 1] if s1n[u, t] > 0 else 0.0
+                bad += not (lo - 1e-4 <= un <= cdf[u, t, s1n[u, t]] + 1e-4)
+    assert bad == 0
+
+
 def test_generate_argument_errors():
     eng, _ = _engine(torch.float32, [1, 2], 2, 64)
     with pytest.raises(ValueError):
