@@ -360,6 +360,18 @@ int srwn_wgrad_layers(const void* x, const void* z, const void* df, const void* 
                       float* part_r, float* part_bf, float* part_br, int64_t rows, int32_t T, int32_t nslabs,
                       int32_t R, int32_t K, int32_t dtype, void* stream);
 
+/* ---- weight gradient of all skip 1x1s from the forward group kernel's transposed gate outputs (tf.gradients of
+ * ops.py:44 summed as model.py:50):  out[l*64 + n][s] = sum_t c_l[t][n] * d[t][s].  cT / wt_layer_stride: the cT buffer
+ * srwn_residual_group_fwd_wt wrote (layer l at cT + l * wt_layer_stride elements); st[l] / seg_rows[l]: the stride (gcd of
+ * the dilations) and the segment length (srwn_group_wt_geometry) of the group layer l was run in -- they fix which
+ * positions its tiles hold; d: dskip [B*T, d_row_stride] (256 columns used).  Partials in srwn_wgrad256's layout:
+ * partials[slab][nlayers*64][256], bias_partials[slab][256] (column sums of d; may be NULL); nslabs from
+ * srwn_wgrad_skip_wt_slabs.  bf16, R = 64, S = 256 (csrc/srwn_wgradt.hip); other shapes: srwn_wgrad_wide on z. */
+int32_t srwn_wgrad_skip_wt_slabs(const int32_t* st, const int32_t* seg_rows, int32_t nlayers, int32_t T);
+int srwn_wgrad_skip_wt(const void* cT, int64_t wt_layer_stride, const int32_t* st, const int32_t* seg_rows,
+                       int32_t nlayers, const void* d, int64_t d_row_stride, float* partials, float* bias_partials,
+                       int32_t nslabs, int32_t B, int32_t T, int32_t R, int32_t S, int32_t dtype, void* stream);
+
 /* ---- queue-cached incremental generation (BASELINE config 5; the reference only has the O(T^2 L) loop
  * of teacher.py:140-171).  Persistent workgroups generate `nsteps` samples, 32 utterances per workgroup,
  * with the arithmetic of the training graph (RightShift input conv model.py:172-173, layers ops.py:23-46,

@@ -17,7 +17,7 @@ MANIFEST = os.path.join(HERE, "libsrwn.manifest.json")   # sha256 of every sourc
 IO_LIB = os.path.join(HERE, "libsrwn_io.so")     # host-only data path (TFRecord reader), plain g++
 IO_SOURCES = ["srwn_tfrecord.cpp"]
 CXX = os.environ.get("CXX", "g++")
-SOURCES = ["srwn_util.hip", "srwn_fwd.hip", "srwn_bwd.hip", "srwn_opt.hip", "srwn_pool.hip", "srwn_gemm.hip", "srwn_wgrad2.hip", "srwn_gen.hip", "srwn_gen16.hip", "srwn_flow.hip", "srwn_enc.hip", "srwn_nc.hip", "srwn_group.hip", "srwn_groupw.hip", "srwn_ops.hip", "srwn_head.hip"]
+SOURCES = ["srwn_util.hip", "srwn_fwd.hip", "srwn_bwd.hip", "srwn_opt.hip", "srwn_pool.hip", "srwn_gemm.hip", "srwn_wgrad2.hip", "srwn_gen.hip", "srwn_gen16.hip", "srwn_flow.hip", "srwn_enc.hip", "srwn_nc.hip", "srwn_group.hip", "srwn_groupw.hip", "srwn_wgradt.hip", "srwn_ops.hip", "srwn_head.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-pass-failed", "-ffp-contract=on"]
 

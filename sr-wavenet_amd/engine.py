@@ -423,6 +423,9 @@ class WaveNetEngine:
             self.xTs = z(L, wt_elems)
             self.cTs = z(L, wt_elems)
             self.nslabs = max(g[3] for g in geo)
+            # per layer: the stride and segment length of its group (what fixes the positions its tiles hold)
+            self.wt_layer_st = [math.gcd(*self.dil[l0:l1]) for l0, l1 in self.groups for _ in range(l0, l1)]
+            self.wt_layer_seg = [self.wt_seg_rows[i] for i, (l0, l1) in enumerate(self.groups) for _ in range(l0, l1)]
         elif self.fused_wg:
             # one partial per workgroup of the fused backward kernel (slabs it does not reach stay zero)
             self.nslabs = K.group_wgrad_slabs()
@@ -476,6 +479,12 @@ class WaveNetEngine:
             self.ns_skip = K.wgrad256_slabs(N, L, R)
             self.ns_head = K.wgrad256_slabs(N, S // 64)
             big = max(big, -(-max(self.ns_skip * L * R * S, self.ns_head * S * 256) // self.nslabs))
+        # skip weight gradients from the forward's transposed gate outputs (csrc/srwn_wgradt.hip)
+        self.skip_wt = (self.use_w256 and self.fused_wt and self.dt == torch.bfloat16 and (R, S) == (64, 256)
+                        and _os_environ_flag("SRWN_WGRAD_WT", True))
+        if self.skip_wt:
+            self.ns_skip_wt = K.wgrad_skip_wt_slabs(self.wt_layer_st, self.wt_layer_seg, T)
+            big = max(big, -(-self.ns_skip_wt * L * R * S // self.nslabs))
         self.wg_parts = z(self.nslabs * big, dt=torch.float32)
         self.wg_bparts = z(max(self.nslabs * max(L * S, Cp), 256 * 256), dt=torch.float32)
         # the two head products keep partials of their own, so that skip + head finish in ONE reduction launch
@@ -875,15 +884,21 @@ class WaveNetEngine:
         NR = N * R
         zs_p = self.zs.data_ptr()
         if self.batch_reduce:
+            ns_skip = self.ns_skip
             with _Span(self, "wgrad_skip"):
-                K.wgrad256(zs_p, NR, R, L, self.dtotal, self.wg_parts, self.wg_bparts, N, self.ns_skip,
-                           pro=K.PRO_GATE, chunk_width=R)
+                if self.skip_wt and self.fused_wt:
+                    ns_skip = self.ns_skip_wt
+                    K.wgrad_skip_wt(self.cTs, self.wt_layer_st, self.wt_layer_seg, self.dtotal, self.wg_parts,
+                                    self.wg_bparts, ns_skip, self.B, T, R)
+                else:
+                    K.wgrad256(zs_p, NR, R, L, self.dtotal, self.wg_parts, self.wg_bparts, N, self.ns_skip,
+                               pro=K.PRO_GATE, chunk_width=R)
             K.wgrad256(self.r0.data_ptr(), 64, S, S // 64, self.da1, self.hd_parts[0], self.hd_bparts[0], N, self.ns_head)
             K.wgrad256(self.r1.data_ptr(), 64, S, S // 64, self.dlogits, self.hd_parts[1], self.hd_bparts[1], N,
                        self.ns_head)                                                  # last 1x1 (S->C)
             K.reduce_partials_multi([
-                (self.wg_parts, self.ns_skip, L * R * S, 1, True, 1.0, gp + 4 * sec["WS"].offset, 0),
-                (self.wg_bparts, self.ns_skip, S, L, False, 1.0, gp + 4 * sec["BS"].offset, S),
+                (self.wg_parts, ns_skip, L * R * S, 1, True, 1.0, gp + 4 * sec["WS"].offset, 0),
+                (self.wg_bparts, ns_skip, S, L, False, 1.0, gp + 4 * sec["BS"].offset, S),
                 (self.hd_parts[0], self.ns_head, S * S, 1, True, 1.0, gp + 4 * sec["head_w1"].offset, 0),
                 (self.hd_bparts[0], self.ns_head, S, 1, True, 1.0, gp + 4 * sec["head_b1"].offset, 0),
                 (self.hd_parts[1], self.ns_head, S * Cp, 1, True, 1.0, gp + 4 * sec["head_w2"].offset, 0),

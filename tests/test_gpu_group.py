@@ -180,6 +180,29 @@ def test_group_wt_equals_twin(monkeypatch, dt, dil, B, T, R, S, seg):
         assert _rel(gf[n], gr[n]) < tol, "%s: %g" % (n, _rel(gf[n], gr[n]))
 
 
+@pytest.mark.parametrize("dil,B,T,seg", [([1, 2, 4, 8, 16], 2, 700, 0), ([32, 64, 128, 256, 512], 2, 2100, 0),
+                                         ([4, 8, 16, 32], 2, 515, 96), ([1, 2, 4, 8, 16, 32, 64, 128], 1, 1100, 64),
+                                         ([1, 2, 4], 3, 1, 0), ([2, 2, 2], 1, 31, 0), ([512, 1], 1, 600, 0),
+                                         ([1, 2, 4, 8, 16, 32, 64, 128, 256, 512] * 3, 1, 2000, 0)])
+def test_skip_wgrad_from_tiles_equals_wgrad256(monkeypatch, dil, B, T, seg):
+    """srwn_wgrad_skip_wt (the skip 1x1s' weight gradients contracted from the forward kernel's transposed gate outputs,
+    dskip through LDS-DMA) against srwn_wgrad256 on z in the same engine: the same bf16 operands -- c is rounded once in
+    both -- so only the order of the fp32 sums differs; the bias gradient (column sums of dskip) by a block's idle waves
+    or, when every block has four layers, by the column-sum kernel."""
+    _, eng = _pair(monkeypatch, dil, B, T, 64, 256, 64, torch.bfloat16, seg_rows=seg, fuse_wt="1", ref_fuse="1")
+    assert eng.fused_wt and eng.skip_wt
+    out = {}
+    for mode in (True, False):
+        eng.skip_wt = mode
+        eng.grads.zero_()
+        eng.forward(); eng.backward()
+        torch.cuda.synchronize()
+        out[mode] = {n: eng.view(n, eng.grads).clone() for n in ("WS", "BS")}
+    for n in ("WS", "BS"):
+        assert torch.isfinite(out[True][n]).all()
+        assert _rel(out[True][n], out[False][n]) < 2e-5, "%s: %g" % (n, _rel(out[True][n], out[False][n]))
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_group_wt_conditioned(monkeypatch, dt):
     """Conditioned decoder (model.py:176-189) in the weight-gradient-tile mode: the stored layer inputs include the
