@@ -161,16 +161,24 @@ __global__ __launch_bounds__(512) void wgrad_skip_wt_kernel(WtSkipArgs a) {
     bf.v = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     return bf;
   };
-  auto compute = [&](int buf, const f32x4 (&A)[4]) {
+  // B fragments run two groups of four MFMAs (128 cycles) ahead of their use -- one group ahead left every group waiting
+  // on its transposing reads -- and the first two of the NEXT chunk (published by this iteration's barrier) are read
+  // behind the last products, so a chunk starts without a bubble
+  Frag<T> bq0 = zero_frag<T>(), bq1 = zero_frag<T>();
+  auto compute = [&](int buf, int nbuf, const f32x4 (&A)[4]) {
     Frag<T> af[4];
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) af[mb].v = __builtin_bit_cast(bf16x8, A[mb]);
+    Frag<T> b[10];
+    b[0] = bq0; b[1] = bq1;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const Frag<T> bf = bfrag(buf, i);
+      b[i + 2] = (i + 2 < 8) ? bfrag(buf, i + 2) : bfrag(nbuf, i + 2 - 8);
 #pragma unroll
-      for (int mb = 0; mb < 4; ++mb) mma16(acc[mb][i], af[mb], bf);
+      for (int mb = 0; mb < 4; ++mb) mma16(acc[mb][i], af[mb], b[i]);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    bq0 = b[8]; bq1 = b[9];
   };
   // the column sums of dskip (the skip biases' gradient, the same for every layer): by the two waves of a block with
   // fewer than four layers that have no products to do (a test per fragment inside compute() splits the MFMA sequence
@@ -187,7 +195,7 @@ __global__ __launch_bounds__(512) void wgrad_skip_wt_kernel(WtSkipArgs a) {
     wg_barrier();                                                                                               \
     load_a(ca, ANEW); advance(ca);                                                                              \
     dma_tile(cd, ((IT) + 3) & (kNB - 1)); advance(cd);                                                          \
-    if (live) compute((IT) & (kNB - 1), ACUR);                                                                  \
+    if (live) compute((IT) & (kNB - 1), ((IT) + 1) & (kNB - 1), ACUR);                                          \
     else if (do_bias) bias_only((IT) & (kNB - 1));                                                              \
   }
   for (int it = 0; it < nit; it += 3) {
