@@ -398,14 +398,23 @@ int srwn_generate(const void* wcr, const void* wskip, const void* w1, const void
  * the weights stream from L2 into registers one layer ahead (csrc/srwn_gen16.hip).  wl: per layer
  * [4 waves][conv k-steps 0..3 (k < R: delayed tap, k >= R: current tap) | residual k-steps 0..1 | skip (row blocks 0..3)
  * x (k-steps 0..1)] fragment images of 64 lanes x 8 elements, lane l = row (l & 15), k = 8 (l >> 4) + j; wave w owns conv /
- * residual rows 16w.. and skip rows 64w..; wh1 / wh2: [4 waves][4 row blocks][8 k-steps] of the two head 1x1s (rows of
- * wh2 beyond ceil(C/32)*32 zero).  srwn_generate16_image_elems(nlayers, 0 | 1) = elements of wl | of each head image. */
+ * residual rows 16w.. and skip rows 64w..; wh1 / wh2: [4 waves][4 row blocks][8 k-steps] of the two head 1x1s -- wave w,
+ * block rb = rows 64w + 16rb of wh1 but rows 16 (4 rb + w) of wh2 (a head with few outputs still splits over the waves;
+ * rows beyond ceil(C/32)*32 zero).  The rings must be handed over zero-filled.  srwn_generate16_image_elems(nlayers, 0 | 1) = elements of wl | of each head image. */
 int64_t srwn_generate16_image_elems(int32_t nlayers, int32_t which);
 int srwn_generate16(const void* wl, const void* wh1, const void* wh2, const float* bias_f, const float* bias_r,
                     const float* bs_sum, const float* b1, const float* b2, const float* init_w, const float* init_b,
                     void* ring, float* audio_out, int32_t* codes_out, float* logits_out, const float* forced,
                     const int32_t* dilations, int32_t nlayers, int32_t B, int32_t Tout, int32_t nsteps, int32_t C,
                     int32_t mode, uint64_t seed, void* stream);
+/* ... and for the conditioned mixture-of-logistics decoder (the model generator.py:150-170 samples from; arguments as
+ * srwn_generate_mol): cond [B*cond_frames, cond_ld] bf16 (cond_ld a multiple of 4) or NULL. */
+int srwn_generate16_mol(const void* wl, const void* wh1, const void* wh2, const float* bias_f, const float* bias_r,
+                        const float* bs_sum, const float* b1, const float* b2, const float* init_w,
+                        const float* init_b, void* ring, float* audio_out, int32_t* codes_out, float* logits_out,
+                        const float* forced, const int32_t* dilations, int32_t nlayers, int32_t B, int32_t Tout,
+                        int32_t nsteps, int32_t num_mixtures, const void* cond, int32_t cond_frames,
+                        int32_t pool_stride, int64_t cond_ld, int32_t mode, uint64_t seed, void* stream);
 
 /* The same generator for the conditioned mixture-of-logistics decoder of WaveNetAutoEncoder (model.py:158-200; the
  * reference samples it with one whole-clip pass per sample, generator.py:150-170): cond [B*cond_frames, cond_ld] in

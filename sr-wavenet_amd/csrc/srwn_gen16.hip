@@ -14,6 +14,7 @@
 // registers), so no MFMA waits for LDS or memory; the skip products run in the matrix pipe behind the residual ones
 // while the VALU finishes the layer.  Pinned by the same tests as the throughput kernel (tests/test_gpu_generate.py).
 #include <cstdlib>
+#include <type_traits>
 #include "srwn_common.h"
 #include "srwn_group.h"
 #include "srwn_host.h"
@@ -36,6 +37,8 @@ struct Gen16Args {
   void* ring;
   float* audio_out; int32_t* codes_out; float* logits_out; const float* forced;
   int B, Tout, nsteps, L, C, Cp, mode, Q;       // Cp: entries of b2 / rows of the last 1x1 (ceil(C/32)*32)
+  int M;                                        // > 0: mixture-of-logistics head with M mixtures (C = 4M)
+  const void* cond; int cond_frames, pool; long long cond_ld;   // conditioning biases cb_l (COND instantiation)
   long long ring_group_elems;
   unsigned long long seed;
   int dil[kG16MaxLayers];
@@ -65,17 +68,19 @@ constexpr int LAYER_FR = 4 * 14;              // fragment images per layer
 // one layer's operands of a wave that do not depend on the step's activations: its weight fragments and the delayed tap
 // NCB: 16-utterance column blocks per workgroup (2: one workgroup per ring group of 32 utterances; 1: two workgroups share
 // a ring group, each half the work per layer -- the choice whenever the utterances do not fill the chip's CUs otherwise)
-template <int NCB>
-struct PreT {
+struct G16NoCond {};
+template <int NCB> struct G16Cond { bf16x4 cc[NCB]; };   // cb_l of the current frame: this wave's channels 16w + 4rq..
+template <int NCB, bool COND>
+struct PreT : std::conditional<COND, G16Cond<NCB>, G16NoCond>::type {
   Frag<T> wc[4], wr[2], ws[4][2];
   Frag<T> x0[2][NCB];                         // [k-step of the delayed tap][column block]
 };
 
-template <int NCB>
+template <int NCB, bool COND, bool MOL>
 __global__ __launch_bounds__(256) void generate16_kernel(Gen16Args a) {
   constexpr int NU = 16 * NCB;                // utterances of this workgroup
   constexpr int NI = 4 * NCB;                 // utterances a wave samples
-  using Pre = PreT<NCB>;
+  using Pre = PreT<NCB, COND>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* xb = reinterpret_cast<T*>(smem);                         // [32][LSX] the layer input x_l[t]
   T* cb = xb + 32 * LSX;                                      // [32][LSX] the gate output c_l[t]
@@ -118,7 +123,18 @@ __global__ __launch_bounds__(256) void generate16_kernel(Gen16Args a) {
   // the operands of layer l at the step whose write slots are curv + ahead: the delayed tap x_l[t - d] sits in slot
   // (t - d) mod (d + 1) = (t + 1) mod (d + 1), the slot after the one the step writes -- which, for t < d, nobody has
   // written yet: the caller hands the rings over zero-filled, and that is the zero padding of the causal conv (ops.py:6-10)
-  auto preload = [&](int l, int ahead, Pre& p) {
+  const T* condp = reinterpret_cast<const T*>(a.cond);
+  auto preload = [&](int l, int ahead, int t, Pre& p) {
+    if constexpr (COND) {   // (first: the epilogue of the layer below needs it before anything else of this set)
+      const int tt = t + ahead;
+      const int fc = tt / a.pool < a.cond_frames ? tt / a.pool : a.cond_frames - 1;
+#pragma unroll
+      for (int c2 = 0; c2 < NCB; ++c2) {
+        const int ug = u0 + 16 * c2 + col;
+        const int uc = ug < a.B ? ug : a.B - 1;
+        p.cc[c2] = *reinterpret_cast<const bf16x4*>(condp + ((size_t)uc * a.cond_frames + fc) * a.cond_ld + (size_t)l * R + 16 * wave + 4 * rq);
+      }
+    }
     const T* w = wl + ((size_t)l * LAYER_FR + wave * 14) * FR + lane * 8;
 #pragma unroll
     for (int f = 0; f < 4; ++f) p.wc[f] = load_nat(w + f * FR);
@@ -142,7 +158,7 @@ __global__ __launch_bounds__(256) void generate16_kernel(Gen16Args a) {
   Pre pa, pb;
   for (int t = 0; t < a.nsteps; ++t) {
     // (layer 0's operands were requested by the top layer of the step before: its ring slot is at least one step old)
-    if (t == 0) preload(0, 0, pa);
+    if (t == 0) preload(0, 0, 0, pa);
     // ---- input conv with RightShift (model.py:172-173): h0[t] = w[0] audio[t-2] + w[1] audio[t-1] + b; this wave's 16 channels
     float xs[NCB][4];                              // the wave's slice of the current layer input (as stored: rounded)
 #pragma unroll
@@ -162,6 +178,9 @@ __global__ __launch_bounds__(256) void generate16_kernel(Gen16Args a) {
       for (int r = 0; r < 4; ++r) {
         const int n = 16 * wave + 4 * rq + r;
         xs[c2][r] = (float)(T)fmaf(c_iw[n], a2, fmaf(c_iw[R + n], a1, c_ib[n]));
+        // (conditioned decoder, model.py:176-189: the layer's input is the output below + cb_l, rounded once more --
+        // the input conv's output was stored rounded first, as srwn_residual_layer_fwd sees it)
+        if constexpr (COND) xs[c2][r] = (float)(T)(xs[c2][r] + (float)pa.cc[c2][r]);
       }
       store4(xb + (size_t)(16 * c2 + col) * LSX + 16 * wave + 4 * rq, xs[c2][0], xs[c2][1], xs[c2][2], xs[c2][3]);
     }
@@ -187,7 +206,7 @@ __global__ __launch_bounds__(256) void generate16_kernel(Gen16Args a) {
       // the next layer's weights and delayed tap, one layer ahead (after the top layer: layer 0 of the next step)
       {
         const bool top = l + 1 >= a.L;
-        preload(top ? 0 : l + 1, top ? 1 : 0, pnext);
+        preload(top ? 0 : l + 1, top ? 1 : 0, t, pnext);
       }
       f32x4 accF[NCB];
 #pragma unroll
@@ -242,7 +261,11 @@ __global__ __launch_bounds__(256) void generate16_kernel(Gen16Args a) {
 #pragma unroll
       for (int c2 = 0; c2 < NCB; ++c2) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) xs[c2][r] = (float)(T)((xs[c2][r] + accR[c2][r]) * kSqrtHalf);
+        for (int r = 0; r < 4; ++r) {
+          float y = (xs[c2][r] + accR[c2][r]) * kSqrtHalf;
+          if constexpr (COND) y += (l + 1 < a.L) ? (float)pnext.cc[c2][r] : 0.0f;   // the next layer's cb, rounded once with it
+          xs[c2][r] = (float)(T)y;
+        }
         store4(xb + (size_t)(16 * c2 + col) * LSX + 16 * wave + 4 * rq, xs[c2][0], xs[c2][1], xs[c2][2], xs[c2][3]);
       }
       wg_barrier();
@@ -257,29 +280,37 @@ __global__ __launch_bounds__(256) void generate16_kernel(Gen16Args a) {
     }
     curv = wrap(curv + 1, depthv);
 
-    // ---- head: relu(sum skip) -> 1x1 + relu -> 1x1 (model.py:51-56); each wave owns 64 of the 256 rows of both products,
-    // the activations cross the waves through LDS
+    // ---- head: relu(sum skip) -> 1x1 + relu -> 1x1 (model.py:51-56); the activations cross the waves through LDS.
+    // First product: wave w owns rows 64w..64w+63.  Second product: wave w owns the 16-row blocks w, w + 4, w + 8, w + 12,
+    // so that a head with few outputs (4M mixture parameters: 40 of 256 rows) still splits over the four waves; blocks
+    // beyond the padded output count (nrb2 per wave) are skipped.
     Frag<T> hw[4][8];                           // the wave's 64 rows of one head 1x1: requested well before their products
-    auto head_load = [&](const T* wimg) {
+    const int nrb2 = MOL ? (a.Cp + 63) / 64 : 4;
+    auto head_load = [&](const T* wimg, int nrb) {
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb)
+        if (rb < nrb) {
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) hw[rb][ks] = load_nat(wimg + ((size_t)(wave * 4 + rb) * 8 + ks) * FR + lane * 8);
+          for (int ks = 0; ks < 8; ++ks) hw[rb][ks] = load_nat(wimg + ((size_t)(wave * 4 + rb) * 8 + ks) * FR + lane * 8);
+        }
     };
-    auto head_product = [&](const float* bias, f32x4 (&acc)[4][NCB]) {
+    // row of (row block rb, accumulator row r) of this lane: SECOND = the interleaved blocks of the second product
+    auto hrow = [&](int rb, bool second) { return (second ? 16 * (4 * rb + wave) : 64 * wave + 16 * rb) + 4 * rq; };
+    auto head_product = [&](const float* bias, f32x4 (&acc)[4][NCB], bool second, int nrb) {
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
         for (int c2 = 0; c2 < NCB; ++c2)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[rb][c2][r] = bias[64 * wave + 16 * rb + 4 * rq + r];
+          for (int r = 0; r < 4; ++r) acc[rb][c2][r] = bias[hrow(rb, second) + r];
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
         for (int c2 = 0; c2 < NCB; ++c2) {
           const Frag<T> bf = load_nat(hx + (size_t)(16 * c2 + col) * LSH + 32 * ks + 8 * rq);
 #pragma unroll
-          for (int rb = 0; rb < 4; ++rb) mma16(acc[rb][c2], hw[rb][ks], bf);
+          for (int rb = 0; rb < 4; ++rb)
+            if (rb < nrb) mma16(acc[rb][c2], hw[rb][ks], bf);
         }
     };
     auto relu_to_hx = [&](const f32x4 (&acc)[4][NCB]) {
@@ -290,24 +321,68 @@ __global__ __launch_bounds__(256) void generate16_kernel(Gen16Args a) {
           store4(hx + (size_t)(16 * c2 + col) * LSH + 64 * wave + 16 * rb + 4 * rq, fmaxf(acc[rb][c2][0], 0.f),
                  fmaxf(acc[rb][c2][1], 0.f), fmaxf(acc[rb][c2][2], 0.f), fmaxf(acc[rb][c2][3], 0.f));
     };
-    head_load(reinterpret_cast<const T*>(a.wh1));
+    head_load(reinterpret_cast<const T*>(a.wh1), 4);
     relu_to_hx(accS);
     wg_barrier();
     f32x4 acc1[4][NCB];
-    head_product(c_b1, acc1);
-    head_load(reinterpret_cast<const T*>(a.wh2));   // behind the products, ahead of the exchange
+    head_product(c_b1, acc1, false, 4);
+    head_load(reinterpret_cast<const T*>(a.wh2), nrb2);   // behind the products, ahead of the exchange
     wg_barrier();                                 // everyone has read r0
     relu_to_hx(acc1);
     wg_barrier();
     f32x4 acc2[4][NCB];
-    head_product(c_b2, acc2);
+    head_product(c_b2, acc2, true, nrb2);
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
       for (int c2 = 0; c2 < NCB; ++c2)
-        *reinterpret_cast<f32x4*>(lgl + (size_t)(16 * c2 + col) * LGS + 64 * wave + 16 * rb + 4 * rq) = acc2[rb][c2];
+        *reinterpret_cast<f32x4*>(lgl + (size_t)(16 * c2 + col) * LGS + hrow(rb, true)) = acc2[rb][c2];
     wg_barrier();
 
+    if constexpr (MOL) {
+      // ---- mixture-of-logistics head (model.py:196-198): sample_from_discretized_mix_logistic (ops.py:178-201) with the
+      // counter-based uniforms of generate_kernel, lanes = (utterance, mixture): four utterances of 16 mixture slots per
+      // pass; Gumbel-max over a 16-lane group (ties to the lower mixture), then the group's first lane draws the sample
+#pragma unroll
+      for (int ps = 0; ps < NI / 4; ++ps) {
+        const int ul = NI * wave + 4 * ps + (lane >> 4);
+        const int u = u0 + ul, mx = lane & 15;
+        const float* lg = lgl + ul * LGS;
+        float v = -INFINITY;
+        if (mx < a.M) {
+          const float u1 = 1e-5f + (1.0f - 2e-5f) * g16_uniform(a.seed, (unsigned)u, (unsigned)(t * (a.M + 1) + mx));
+          v = lg[mx] - logf(-logf(u1));
+        }
+        int sel = mx;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+          const float vo = __shfl_xor(v, off); const int so = __shfl_xor(sel, off);
+          if (vo > v || (vo == v && so < sel)) { v = vo; sel = so; }
+        }
+        if (mx == 0) {
+          float smp = lg[a.M + sel];                               // mode 0: the selected mean (no logistic noise)
+          if (a.mode == 1) {
+            const float u2 = 1e-5f + (1.0f - 2e-5f) * g16_uniform(a.seed, (unsigned)u, (unsigned)(t * (a.M + 1) + a.M));
+            smp += expf(fmaxf(lg[2 * a.M + sel], -7.0f)) * (logf(u2) - logf(1.0f - u2));
+          }
+          smp = fminf(fmaxf(smp, -1.0f), 1.0f);
+          if (u < a.B) {
+            a.audio_out[(size_t)u * a.Tout + t] = smp;
+            a.codes_out[(size_t)u * a.Tout + t] = sel;
+          }
+          prev[32 + ul] = prev[ul];
+          prev[ul] = smp;
+        }
+      }
+      if (a.logits_out) {
+        for (int i = threadIdx.x; i < NU * a.C; i += 256) {
+          const int ul = i / a.C, c = i - ul * a.C;
+          if (u0 + ul < a.B) a.logits_out[((size_t)(u0 + ul) * a.Tout + t) * a.C + c] = lgl[ul * LGS + c];
+        }
+      }
+      wg_barrier();
+      continue;
+    }
     // ---- softmax over the C classes, pick a code, mu-law decode: wave w serves NI utterances with lanes = classes
     // (4 per lane, as generate_kernel -- same sums in the same order, same counter-based uniforms); the eight utterances'
     // shuffle chains are independent and written round by round so that they overlap
@@ -411,25 +486,25 @@ extern "C" int64_t srwn_generate16_image_elems(int32_t nlayers, int32_t which) {
   return (int64_t)4 * 4 * 8 * FR;
 }
 
-extern "C" int srwn_generate16(const void* wl, const void* wh1, const void* wh2, const float* bias_f,
-                               const float* bias_r, const float* bs_sum, const float* b1, const float* b2,
-                               const float* init_w, const float* init_b, void* ring, float* audio_out,
-                               int32_t* codes_out, float* logits_out, const float* forced, const int32_t* dilations,
-                               int32_t nlayers, int32_t B, int32_t Tout, int32_t nsteps, int32_t C, int32_t mode,
-                               uint64_t seed, void* stream) {
+static int generate16_impl(const void* wl, const void* wh1, const void* wh2, const float* bias_f, const float* bias_r,
+                           const float* bs_sum, const float* b1, const float* b2, const float* init_w,
+                           const float* init_b, void* ring, float* audio_out, int32_t* codes_out, float* logits_out,
+                           const float* forced, const int32_t* dilations, int32_t nlayers, int32_t B, int32_t Tout,
+                           int32_t nsteps, int32_t C, int32_t mode, uint64_t seed, void* stream, int32_t M,
+                           const void* cond, int32_t cond_frames, int32_t pool, int64_t cond_ld) {
   if (B == 0 || nsteps == 0) return 0;
   if (!wl || !wh1 || !wh2 || !bias_f || !bias_r || !bs_sum || !b1 || !b2 || !init_w || !init_b || !ring || !audio_out ||
       !codes_out || !dilations)
     return set_error(SRWN_E_NULL, "generate16: null pointer");
   if (C < 2 || C > 256) return set_error(SRWN_E_UNSUPPORTED, "generate16: C=%d (2..256)", C);
-  if (B < 0 || nsteps < 0 || nsteps > Tout || nlayers < 1 || nlayers > kG16MaxLayers ||
-      (mode != 0 && mode != 1))
+  if (B < 0 || nsteps < 0 || nsteps > Tout || nlayers < 1 || nlayers > kG16MaxLayers || (mode != 0 && mode != 1))
     return set_error(SRWN_E_SHAPE, "generate16: B=%d nsteps=%d Tout=%d layers=%d mode=%d", B, nsteps, Tout, nlayers, mode);
   Gen16Args a;
   a.wl = wl; a.wh1 = wh1; a.wh2 = wh2; a.bias_f = bias_f; a.bias_r = bias_r; a.bs_sum = bs_sum; a.b1 = b1; a.b2 = b2;
   a.init_w = init_w; a.init_b = init_b; a.ring = ring; a.audio_out = audio_out; a.codes_out = codes_out;
   a.logits_out = logits_out; a.forced = forced;
   a.B = B; a.Tout = Tout; a.nsteps = nsteps; a.L = nlayers; a.C = C; a.Cp = (C + 31) / 32 * 32; a.mode = mode; a.Q = C; a.seed = seed;
+  a.M = M; a.cond = cond; a.cond_frames = cond_frames; a.pool = pool; a.cond_ld = cond_ld;
   long long off = 0;
   for (int l = 0; l < kG16MaxLayers; ++l) {
     a.dil[l] = (l < nlayers) ? dilations[l] : 1;
@@ -445,9 +520,41 @@ extern "C" int srwn_generate16(const void* wl, const void* wh1, const void* wh2,
   if (const char* e = getenv("SRWN_GEN16_NCB")) half = atoi(e) == 1;   // (tests: both bodies at any batch)
   const unsigned groups = half ? (unsigned)((B + 15) / 16) : (unsigned)((B + 31) / 32);
   const size_t sh = (size_t)(2 * 32 * LSX + 32 * LSH) * sizeof(T) + (size_t)(32 * LGS + 64 + 2 * nlayers * R + 2 * S + 256 + 3 * R + 256) * 4;
-  auto kfn = half ? generate16_kernel<1> : generate16_kernel<2>;
+  auto kfn = M > 0 ? (cond ? (half ? generate16_kernel<1, true, true> : generate16_kernel<2, true, true>)
+                           : (half ? generate16_kernel<1, false, true> : generate16_kernel<2, false, true>))
+                   : (half ? generate16_kernel<1, false, false> : generate16_kernel<2, false, false>);
+  if (M == 0 && cond) return set_error(SRWN_E_UNSUPPORTED, "generate16: the conditioned softmax teacher is not built");
   hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
   if (e != hipSuccess) return set_error((int)e, "generate16: LDS %zu: %s", sh, hipGetErrorString(e));
   hipLaunchKernelGGL(kfn, dim3(groups), dim3(256), sh, (hipStream_t)stream, a);
   return check_launch("generate16");
+}
+
+extern "C" int srwn_generate16(const void* wl, const void* wh1, const void* wh2, const float* bias_f,
+                               const float* bias_r, const float* bs_sum, const float* b1, const float* b2,
+                               const float* init_w, const float* init_b, void* ring, float* audio_out,
+                               int32_t* codes_out, float* logits_out, const float* forced, const int32_t* dilations,
+                               int32_t nlayers, int32_t B, int32_t Tout, int32_t nsteps, int32_t C, int32_t mode,
+                               uint64_t seed, void* stream) {
+  return generate16_impl(wl, wh1, wh2, bias_f, bias_r, bs_sum, b1, b2, init_w, init_b, ring, audio_out, codes_out,
+                         logits_out, forced, dilations, nlayers, B, Tout, nsteps, C, mode, seed, stream, 0, nullptr, 1, 1, 0);
+}
+
+// the same body for the conditioned mixture-of-logistics decoder (srwn_generate_mol's arguments; wh2 / b2 cover
+// ceil(4M/32)*32 rows)
+extern "C" int srwn_generate16_mol(const void* wl, const void* wh1, const void* wh2, const float* bias_f,
+                                   const float* bias_r, const float* bs_sum, const float* b1, const float* b2,
+                                   const float* init_w, const float* init_b, void* ring, float* audio_out,
+                                   int32_t* codes_out, float* logits_out, const float* forced,
+                                   const int32_t* dilations, int32_t nlayers, int32_t B, int32_t Tout, int32_t nsteps,
+                                   int32_t num_mixtures, const void* cond, int32_t cond_frames, int32_t pool_stride,
+                                   int64_t cond_ld, int32_t mode, uint64_t seed, void* stream) {
+  if (num_mixtures < 1 || num_mixtures > 16)
+    return set_error(SRWN_E_SHAPE, "generate16_mol: num_mixtures=%d (1..16)", num_mixtures);
+  if (cond && (cond_frames < 1 || pool_stride < 1 || cond_ld < (int64_t)nlayers * R || (cond_ld % 4)))
+    return set_error(SRWN_E_SHAPE, "generate16_mol: cond_frames=%d pool_stride=%d cond_ld=%lld", cond_frames, pool_stride,
+                     (long long)cond_ld);
+  return generate16_impl(wl, wh1, wh2, bias_f, bias_r, bs_sum, b1, b2, init_w, init_b, ring, audio_out, codes_out,
+                         logits_out, forced, dilations, nlayers, B, Tout, nsteps, 4 * num_mixtures, mode, seed, stream,
+                         num_mixtures, cond, cond ? cond_frames : 1, cond ? pool_stride : 1, cond_ld);
 }

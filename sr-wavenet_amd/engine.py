@@ -360,12 +360,12 @@ class WaveNetEngine:
                               ks_offset=l * R // 16, ks_count=R // 16, perm=True)
         # the latency-optimised generator's fragment images (csrc/srwn_gen16.hip): the benchmark's teacher only
         self.o_g16 = None
-        if (self.o_gen is not None and R == 64 and S == 256 and self.dt == torch.bfloat16 and not self.E
-                and self.cfg.head_mode == "per_timestep"):
+        if (self.o_gen is not None and R == 64 and S == 256 and self.dt == torch.bfloat16
+                and ((self.cfg.head_mode == "per_timestep" and not self.E) or self.cfg.head_mode == "mol")):
             self.o_g16 = pk.reserve_raw(np.concatenate([P.gen16_layer_index(sec["WF"].offset, sec["WR"].offset,
                                                                             sec["WS"].offset, l, R, S) for l in range(L)]))
             self.o_g16_h1 = pk.reserve_raw(P.gen16_head_index(sec["head_w1"].offset, S, S, S))
-            self.o_g16_h2 = pk.reserve_raw(P.gen16_head_index(sec["head_w2"].offset, S, Cp, Cp))
+            self.o_g16_h2 = pk.reserve_raw(P.gen16_head_index(sec["head_w2"].offset, S, Cp, Cp, interleave=True))
         # transposed skip kernels of all layers back to back (srwn_skip_dgrad_all streams them in order)
         per = (R // 32) * (S // 16) * 512
         self.o_skipT_all = pk.reserve(L * (R // 32), S // 16)
@@ -1044,9 +1044,15 @@ class WaveNetEngine:
                             cond_all, self.L * self.R, self.L * self.R, B * frames)          # model.py:180
             elif cond is not None:
                 raise ValueError("this decoder is not conditioned")
-            _lib.call("srwn_generate_mol", *common, self.Kw, self.C // 4,
-                      None if cond_all is None else cond_all.data_ptr(), frames, self.cfg.pool_stride, self.L * self.R,
-                      md, int(seed), K.abi_dtype(self.dt), st)
+            import os as _os
+            if self.o_g16 is not None and _os.environ.get("SRWN_GEN16", "1") != "0":
+                _lib.call("srwn_generate16_mol", self.wptr(self.o_g16), self.wptr(self.o_g16_h1), self.wptr(self.o_g16_h2),
+                          *common[4:21], self.C // 4, None if cond_all is None else cond_all.data_ptr(), frames,
+                          self.cfg.pool_stride, self.L * self.R, md, int(seed), st)
+            else:
+                _lib.call("srwn_generate_mol", *common, self.Kw, self.C // 4,
+                          None if cond_all is None else cond_all.data_ptr(), frames, self.cfg.pool_stride, self.L * self.R,
+                          md, int(seed), K.abi_dtype(self.dt), st)
         else:
             if self.E or cond is not None:
                 raise NotImplementedError("generate: the conditioned softmax teacher is not built (the conditioned "

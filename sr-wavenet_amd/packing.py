@@ -109,12 +109,15 @@ def gen16_layer_index(sec_wf: int, sec_wr: int, sec_ws: int, l: int, R: int, S: 
     return np.stack(out)
 
 
-def gen16_head_index(sec_w: int, Cin: int, Cout_ld: int, Cout_valid: int):
-    """[4 waves][rb 0..3][ks 0..7] fragments of a 256 -> 256 head 1x1 stored [Cin, Cout_ld] (rows >= Cout_valid zero)."""
+def gen16_head_index(sec_w: int, Cin: int, Cout_ld: int, Cout_valid: int, interleave: bool = False):
+    """[4 waves][rb 0..3][ks 0..7] fragments of a 256 -> 256 head 1x1 stored [Cin, Cout_ld] (rows >= Cout_valid zero);
+    wave w, block rb = rows 64 w + 16 rb, or rows 16 (4 rb + w) with `interleave` (the last 1x1: few outputs still split
+    over the four waves)."""
     import numpy as np
     out = []
     for w in range(4):
         for rb in range(4):
+            row0 = 16 * (4 * rb + w) if interleave else 64 * w + 16 * rb
             for ks in range(8):
-                out.append(frag16_index(sec_w, 64 * w + 16 * rb, 32 * ks, 1, Cout_ld, Cout_valid, Cin))
+                out.append(frag16_index(sec_w, row0, 32 * ks, 1, Cout_ld, Cout_valid, Cin))
     return np.stack(out)

@@ -209,6 +209,42 @@ def test_mol_decoder_incremental_equals_full_forward(dt, tol, B, T, M, E, pool, 
     assert np.abs(a.cpu().numpy()).max() <= 1.0 and int(sel.max()) < M and int(sel.min()) >= 0
 
 
+@pytest.mark.parametrize("B,T,M,E,pool", [(35, 160, 10, 20, 16), (3, 256, 5, 6, 32), (17, 90, 10, 0, 1), (2, 40, 16, 8, 8)])
+def test_mol_latency_body_equals_throughput_body(monkeypatch, B, T, M, E, pool):
+    """srwn_generate16_mol (channels split over the waves, conditioning bias added in the epilogue of the layer below,
+    the last 1x1's row blocks interleaved over the waves, Gumbel-max over 16-lane groups) against srwn_generate_mol on
+    the same weights, teacher-forced: logits to the accumulation order, the same mixture and sample wherever the logits
+    agree; both workgroup sizes bit for bit."""
+    EG = sub("engine")
+    dil = [1, 2, 4, 8, 16, 32, 1, 2, 5]
+    sp = O.init_stack_params(7, dil, 2, 64, 256, 4 * M, cond_channels=E, bias_scale=0.05)
+    cfg = EG.StackConfig(dilations=dil, dilation_channels=64, skip_channels=256, output_channels=4 * M, cond_channels=E,
+                         pool_stride=pool if E else 1, shift_input=True, head_mode="mol", dtype=torch.bfloat16)
+    eng = EG.WaveNetEngine(cfg, B, T, DEV)
+    eng.load_oracle_params(sp)
+    assert eng.o_g16 is not None
+    rng = np.random.default_rng(5)
+    audio = dev(O.synthetic_audio(B, T, seed=2))
+    cond = dev(rng.standard_normal((B, -(-T // pool), E))) if E else None
+    out = {}
+    for name, env in (("thr", {"SRWN_GEN16": "0"}), ("lat1", {"SRWN_GEN16": "1", "SRWN_GEN16_NCB": "1"}),
+                      ("lat2", {"SRWN_GEN16": "1", "SRWN_GEN16_NCB": "2"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        out[name] = eng.generate(T, mode="sample", seed=3, forced=audio, want_logits=True, cond=cond)
+    for i in range(3):
+        assert torch.equal(out["lat1"][i], out["lat2"][i])
+    a, b = out["lat1"][2].cpu().numpy(), out["thr"][2].cpu().numpy()
+    assert np.isfinite(a).all() and rel_err(a, b) < 2e-2
+    assert (out["lat1"][1] == out["thr"][1]).float().mean() > 0.9
+    assert float(out["lat1"][0].abs().max()) <= 1.0
+    # free running: deterministic, and its own output teacher-forced gives the same draws
+    a1, s1, _ = eng.generate(T, mode="sample", seed=9, cond=cond)
+    a2, s2, _ = eng.generate(T, mode="sample", seed=9, cond=cond)
+    a3, s3, _ = eng.generate(T, mode="sample", seed=9, cond=cond, forced=a1)
+    assert torch.equal(a1, a2) and torch.equal(s1, s2) and torch.equal(a1, a3) and torch.equal(s1, s3)
+
+
 def test_mol_decoder_free_running_and_model_api(tmp_path):
     """Free-running generation feeds its own samples back (closed loop); WaveNetAutoEncoder.generate wraps it."""
     M = sub("model")
