@@ -198,6 +198,11 @@ __global__ __launch_bounds__(512) void wgrad_skip_wt_kernel(WtSkipArgs a) {
     if (live) compute((IT) & (kNB - 1), ((IT) + 1) & (kNB - 1), ACUR);                                          \
     else if (do_bias) bias_only((IT) & (kNB - 1));                                                              \
   }
+  if (nit > 0) {   // the first chunk's first two B fragments: tile 0 (and 1) landed, the barrier publishes them
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    wg_barrier();
+    if (live) { bq0 = bfrag(0, 0); bq1 = bfrag(0, 1); }
+  }
   for (int it = 0; it < nit; it += 3) {
     SRWN_WT_ITER(it, A0, A2)
     SRWN_WT_ITER(it + 1, A1, A0)

@@ -906,11 +906,17 @@ class WaveNetEngine:
             return
         if self.use_w256:
             # every skip 1x1 at once: out[L*R, S] = c_all^T . dtotal (dtotal re-read once per 4 layers)
+            ns_skip = self.ns_skip
             with _Span(self, "wgrad_skip"):
-                K.wgrad256(zs_p, NR, R, L, self.dtotal, self.wg_parts, self.wg_bparts, N, self.ns_skip,
-                           pro=K.PRO_GATE, chunk_width=R)
-            K.reduce_partials(self.wg_parts, self.ns_skip, L * R * S, 1, True, 1.0, gp + 4 * sec["WS"].offset, 0)
-            K.reduce_partials(self.wg_bparts, self.ns_skip, S, L, False, 1.0, gp + 4 * sec["BS"].offset, S)
+                if self.skip_wt and self.fused_wt:
+                    ns_skip = self.ns_skip_wt
+                    K.wgrad_skip_wt(self.cTs, self.wt_layer_st, self.wt_layer_seg, self.dtotal, self.wg_parts,
+                                    self.wg_bparts, ns_skip, self.B, T, R)
+                else:
+                    K.wgrad256(zs_p, NR, R, L, self.dtotal, self.wg_parts, self.wg_bparts, N, self.ns_skip,
+                               pro=K.PRO_GATE, chunk_width=R)
+            K.reduce_partials(self.wg_parts, ns_skip, L * R * S, 1, True, 1.0, gp + 4 * sec["WS"].offset, 0)
+            K.reduce_partials(self.wg_bparts, ns_skip, S, L, False, 1.0, gp + 4 * sec["BS"].offset, S)
             K.wgrad256(self.r0.data_ptr(), 64, S, S // 64, self.da1, self.wg_parts, self.wg_bparts, N, self.ns_head)
             K.reduce_partials(self.wg_parts, self.ns_head, S * S, 1, True, 1.0, gp + 4 * sec["head_w1"].offset, 0)
             K.reduce_partials(self.wg_bparts, self.ns_head, S, 1, True, 1.0, gp + 4 * sec["head_b1"].offset, 0)
