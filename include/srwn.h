@@ -142,7 +142,7 @@ int srwn_residual_group_bwd_wgrad(const void* g_top, void* g_out, int32_t write_
 /* ---- layer weight gradients summed inside the backward group kernel, 8 waves, output-split ("wt" mode).
  * The two kernels of a group are given the SAME segment cut (srwn_group_wt_geometry).  srwn_residual_group_fwd_wt is
  * srwn_residual_group_fwd that also writes, per layer g of the group and per 32-step tile of every segment, the
- * TRANSPOSED layer input x_g and gate output c_g = z_g sigmoid(z_g) ("weight-gradient tiles", [channel][32 steps],
+ * TRANSPOSED layer input x_g and gate output c_g = z_g sigmoid(z_g) ("weight-gradient tiles", per 16 channels x 32 steps one MFMA fragment in lane order,
  * layer g at xT / cT + g*wt_layer_stride elements; steps a segment does not own are zero in xT).  With
  * store_inner_x = 0 only the group's top layer stores its output rows (x_out + (nlayers-1)*layer_stride): in this mode
  * nothing reads the inner layers' (their transposed copies feed the weight gradients).

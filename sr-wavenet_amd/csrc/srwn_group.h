@@ -47,13 +47,13 @@ __device__ __forceinline__ void dma_image(const void* gsrc, unsigned lds_dst, in
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // ----------------------------------------------------------------------------------------------
-// "Weight-gradient tiles": 32 consecutive positions of a segment x R channels, stored TRANSPOSED ([channel][32 steps])
-// so that a lane's eight consecutive elements are eight time steps of one channel -- directly the A fragment of a
+// "Weight-gradient tiles": 32 consecutive positions of a segment x R channels, stored TRANSPOSED (fragment by fragment of
+// 16 channels, see wt_load) so that a lane's eight consecutive elements are eight time steps of one channel -- directly the A fragment of a
 // v_mfma_f32_16x16x32_bf16 that contracts over time (lane l: row l & 15, k = 8 (l >> 4) + j).  The forward group kernel
 // writes them (the layer input x and the gate output c = z sigmoid z, from the LDS image with transposing reads), the
 // backward group kernel loads them as fragments and contracts them with df / G from its own LDS image:
 //   dWf[k] = x^T . df(shifted),  dWr = c^T . G       (tf.gradients of ops.py:27,39)
-// Element (c, kg, j) of a tile, at c*32 + kg*8 + j, is time step kordW(kg, j) of the tile: the order in which a
+// Element (c, kg, j) of a tile is time step kordW(kg, j) of the tile: the order in which a
 // transposing LDS read (ds_read_b64_tr_b16: four rows per read) is free of bank conflicts at the image's row stride of
 // 36 dwords (rows 4 apart), and -- the only requirement -- the same for both operands of a product.
 // ----------------------------------------------------------------------------------------------
@@ -140,15 +140,19 @@ __device__ __forceinline__ float frag_dot(float acc, const Frag<float>& f, const
   return acc;
 }
 
-// the fragment of channels c0..c0+15 of a weight-gradient tile in HBM, and its store
+// the fragment of channels c0..c0+15 of a weight-gradient tile in HBM, and its store.  A tile is R/16 fragments of 64
+// lanes x 8 elements IN LANE ORDER (lane l = 16 kg + channel: element (c, kg, j) of block c0 at (c0/16)*512 + (16 kg + c)*8
+// + j): a wave's load or store of a fragment is one contiguous KiB.  (Round 3 first stored [channel][kg][j]: the same
+// KiB, but consecutive lanes 64 bytes apart -- four address-coalescer cycles per quad of lanes instead of one, on every
+// fragment of the forward kernel's stores and of the backward kernels' contraction loops.)
 template <typename T> __device__ __forceinline__ Frag<T> wt_load(const T* tile, int c0, int lane) {
-  return load_nat(tile + (size_t)(c0 + (lane & 15)) * 32 + (lane >> 4) * 8);
+  return load_nat(tile + (size_t)(c0 >> 4) * 512 + lane * 8);
 }
 __device__ __forceinline__ void wt_store(bf16_t* tile, int c0, int lane, const Frag<bf16_t>& f) {
-  *reinterpret_cast<bf16x8*>(tile + (size_t)(c0 + (lane & 15)) * 32 + (lane >> 4) * 8) = f.v;
+  *reinterpret_cast<bf16x8*>(tile + (size_t)(c0 >> 4) * 512 + lane * 8) = f.v;
 }
 __device__ __forceinline__ void wt_store(float* tile, int c0, int lane, const Frag<float>& f) {
-  float* p = tile + (size_t)(c0 + (lane & 15)) * 32 + (lane >> 4) * 8;
+  float* p = tile + (size_t)(c0 >> 4) * 512 + lane * 8;
   *reinterpret_cast<f32x4*>(p) = f.lo;
   *reinterpret_cast<f32x4*>(p + 4) = f.hi;
 }

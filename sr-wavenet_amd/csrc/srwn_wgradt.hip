@@ -4,7 +4,7 @@
 // srwn_wgrad256 reads z in its natural [time][channel] layout, recomputes the gate (an exp and a reciprocal per element,
 // 245 M elements), writes both operands to LDS through registers (ds_write_b128: 79 B/clk/CU) and reads both back with
 // transposing reads: 194 us for 126 GFLOP.  Here the A operand is what srwn_residual_group_fwd_wt already left in HBM
-// for the backward group kernel's dWr: c in "weight-gradient tiles" ([channel][32 positions], a lane's 16 bytes = eight
+// for the backward group kernel's dWr: c in "weight-gradient tiles" (64 channels x 32 positions as four fragments in lane order, a lane's 16 bytes = eight
 // time steps of one channel = one v_mfma_f32_16x16x32_bf16 A fragment), loaded straight into registers; only dskip goes
 // through LDS, by LDS-DMA (no VGPR round trip, no ds_write), dense 512-byte rows with the 32-byte blocks of a row XOR-ed
 // by (row >> 1) & 7 -- the transposing reads of a 16-column block touch rows 2 apart, so eight rows' blocks land on
@@ -114,11 +114,11 @@ __global__ __launch_bounds__(512) void wgrad_skip_wt_kernel(WtSkipArgs a) {
     glds16_untracked(gb, __builtin_amdgcn_readfirstlane(l + 8 * 1024));
   };
   // ---- c tile of this wave's layer -> registers (four fragments = 64 channels x 32 positions)
-  const T* ct_layer = reinterpret_cast<const T*>(a.cT) + (size_t)layer * a.wt_stride + (size_t)(lane & 15) * 32 + (lane >> 4) * 8;
+  const T* ct_layer = reinterpret_cast<const T*>(a.cT) + (size_t)layer * a.wt_stride + lane * 8;   // (wt_load's layout)
   auto load_a = [&](const Cursor& c, f32x4 (&f)[4]) {
     const T* t = ct_layer + ((size_t)c.seg * KT + c.k) * (64 * 32);
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) f[mb] = gload16_untracked(t + mb * 16 * 32);
+    for (int mb = 0; mb < 4; ++mb) f[mb] = gload16_untracked(t + mb * 512);
   };
 
   // ---- transposing reads: lane (kg, q, p) reads rows 16 (kg >> 1) + 2 (kg & 1) + 4 q (+1), 8 bytes at 8 p of block nb

@@ -219,7 +219,9 @@ def test_skip_wgrad_from_tiles_equals_wgrad256(monkeypatch, dil, B, T, seg):
         st, W = eng.wt_layer_st[l], eng.wt_layer_seg[l]
         J = -(-Tn // st); nsub = -(-J // W); KT = -(-W // 32)
         nseg = B * st * nsub
-        tiles = eng.cTs[l][:nseg * KT * R * 32].view(nseg, KT, R, 4, 8).double()
+        # (a tile = four fragments of 16 channels, each [kg][channel][j]: csrc/srwn_group.h wt_load)
+        tiles = eng.cTs[l][:nseg * KT * R * 32].view(nseg, KT, R // 16, 4, 16, 8).permute(0, 1, 2, 4, 3, 5)
+        tiles = tiles.reshape(nseg, KT, R, 4, 8).double()
         seg = np.arange(nseg)
         b, rem = seg // (st * nsub), seg % (st * nsub)
         r, j0 = (rem, np.zeros_like(rem)) if nsub == 1 else (rem // nsub, (rem % nsub) * W)
