@@ -337,6 +337,12 @@ int32_t srwn_wgrad_wide_slabs(int64_t rows, int32_t m_chunks, int32_t chunk_widt
 int srwn_wgrad_wide(const void* a, int64_t a_chunk_stride, int64_t a_row_stride, int32_t m_chunks, int32_t chunk_width,
                     const void* d, int64_t d_row_stride, int32_t d_width, float* partials, float* bias_partials,
                     int64_t rows, int32_t nslabs, int32_t pro, int32_t dtype, void* stream);
+/* two such products of ONE shape as one launch (the head's two 1x1s, model.py:53,56: 46 us each alone -- 256 workgroups
+ * of 4 MFMAs per barrier -- side by side their workgroups share the CUs and hide each other's waits) */
+int srwn_wgrad_wide_pair(const void* a0, const void* d0, float* partials0, float* bias_partials0, const void* a1,
+                         const void* d1, float* partials1, float* bias_partials1, int64_t a_chunk_stride,
+                         int64_t a_row_stride, int32_t m_chunks, int32_t chunk_width, int64_t d_row_stride,
+                         int32_t d_width, int64_t rows, int32_t nslabs, int32_t pro, int32_t dtype, void* stream);
 int srwn_wgrad256(const void* a, int64_t a_chunk_stride, int64_t a_row_stride, int32_t m_chunks, const void* d,
                   int64_t d_row_stride, float* partials, float* bias_partials, int64_t rows, int32_t nslabs,
                   int32_t pro, int32_t dtype, void* stream);

@@ -93,6 +93,8 @@ SIGNATURES = {
     "srwn_wgrad256_slabs": (_i32, [_i64, _i32]),
     "srwn_wgrad256": (C.c_int, [_p, _i64, _i64, _i32, _p, _i64, _p, _p, _i64, _i32, _i32, _i32, _p]),
     "srwn_wgrad_wide_slabs": (_i32, [_i64, _i32, _i32]),
+    "srwn_wgrad_wide_pair": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _i32, _i64, _i32, _i64, _i32, _i32,
+                                       _i32, _p]),
     "srwn_wgrad_wide": (C.c_int, [_p, _i64, _i64, _i32, _i32, _p, _i64, _i32, _p, _p, _i64, _i32, _i32, _i32, _p]),
     "srwn_tap_linear": (C.c_int, [_p, _i64, _i32, _i32, _i32, _i32, _p, _p, _p, _i64, _i32, _i64, _p, _i64, _p, _i64,
                                   _i32, _i32, _f32, _i32, _i32, _p]),

@@ -21,6 +21,9 @@ struct Wg2Args {
   float* partials; float* bias_partials;
   int64_t rows; int rows_per_slab; int nslabs;
 };
+// up to two independent products of the same shape in one launch (grid.z): the head's two 1x1s are 46 us each alone,
+// 256 workgroups of 4-16 MFMAs per barrier -- side by side their workgroups share the CUs and hide each other's waits
+struct Wg2Pair { Wg2Args p[2]; };
 
 namespace {
 
@@ -55,7 +58,8 @@ constexpr int kStride = 288;   // LDS row stride in elements: 576 B (bf16) puts 
 // DW = width of D (256, or 128 for the reference scripts' skip_channels); CW = width of one A chunk (64, or 32 for
 // their dilation_channels): the block still stages MB*64 A columns, i.e. MB*64/CW chunks.
 template <typename T, int PRO, int MB, int DW, int CW>
-__global__ __launch_bounds__(512) void wgrad256_kernel(Wg2Args a) {
+__global__ __launch_bounds__(512) void wgrad256_kernel(Wg2Pair pp) {
+  const Wg2Args& a = pp.p[blockIdx.z];
   constexpr int kW = DW;
   constexpr int NTW = (MB == 4) ? DW / 64 : 1;   // n-tiles per wave (MB = 1: one tile per wave, waves >= DW/32 idle)
   constexpr int AW = MB * 64;                // staged A tile width (channels)
@@ -309,25 +313,30 @@ extern "C" int srwn_wgrad256(const void* a, int64_t a_chunk_stride, int64_t a_ro
                          rows, nslabs, pro, dtype, stream);
 }
 
-extern "C" int srwn_wgrad_wide(const void* a, int64_t a_chunk_stride, int64_t a_row_stride, int32_t m_chunks,
-                               int32_t chunk_width, const void* d, int64_t d_row_stride, int32_t d_width,
-                               float* partials, float* bias_partials, int64_t rows, int32_t nslabs, int32_t pro,
-                               int32_t dtype, void* stream) {
+static int wgrad_wide_launch(const void* const* a, const void* const* d, float* const* partials,
+                             float* const* bias_partials, int nsets, int64_t a_chunk_stride, int64_t a_row_stride,
+                             int32_t m_chunks, int32_t chunk_width, int64_t d_row_stride, int32_t d_width, int64_t rows,
+                             int32_t nslabs, int32_t pro, int32_t dtype, void* stream) {
   if (rows == 0 || m_chunks == 0) return 0;
-  if (!a || !d || !partials) return set_error(SRWN_E_NULL, "wgrad_wide: null pointer");
+  for (int i = 0; i < nsets; ++i)
+    if (!a[i] || !d[i] || !partials[i]) return set_error(SRWN_E_NULL, "wgrad_wide: null pointer");
   if ((chunk_width != 64 && chunk_width != 32) || (d_width != 256 && d_width != 128))
     return set_error(SRWN_E_UNSUPPORTED, "wgrad_wide: chunk_width %d (64, 32) / d_width %d (256, 128)", chunk_width, d_width);
   if (rows < 0 || m_chunks < 0 || nslabs < 1 || d_row_stride < d_width || a_row_stride < chunk_width ||
       ((int64_t)m_chunks * chunk_width) % 64)
     return set_error(SRWN_E_SHAPE, "wgrad_wide: rows=%lld m_chunks=%d nslabs=%d strides a=%lld d=%lld", (long long)rows,
                      m_chunks, nslabs, (long long)a_row_stride, (long long)d_row_stride);
-  Wg2Args g{a, a_chunk_stride, a_row_stride, m_chunks, d, d_row_stride, partials, bias_partials, rows, 0, nslabs};
   int64_t rps = (rows + nslabs - 1) / nslabs;
   rps = (rps + kRows - 1) / kRows * kRows;
-  g.rows_per_slab = (int)rps;
+  Wg2Pair g;
+  for (int i = 0; i < 2; ++i) {
+    const int j = i < nsets ? i : 0;
+    g.p[i] = Wg2Args{a[j], a_chunk_stride, a_row_stride, m_chunks, d[j], d_row_stride, partials[j], bias_partials[j], rows,
+                     (int)rps, nslabs};
+  }
   const int m64 = (int)((int64_t)m_chunks * chunk_width / 64);
   const int mb = wg2_chunks_per_block(m64);
-  dim3 grid((unsigned)nslabs, (unsigned)((m64 + mb - 1) / mb)), block(512);
+  dim3 grid((unsigned)nslabs, (unsigned)((m64 + mb - 1) / mb), (unsigned)nsets), block(512);
   hipStream_t st = (hipStream_t)stream;
 #define SRWN_W2(TT, P)                                                                                        \
   if (mb == 4) SRWN_W2C(TT, P, 4) else SRWN_W2C(TT, P, 1)
@@ -360,6 +369,28 @@ extern "C" int srwn_wgrad_wide(const void* a, int64_t a_chunk_stride, int64_t a_
 #undef SRWN_W2B
 #undef SRWN_W2C
   return set_error(SRWN_E_UNSUPPORTED, "wgrad_wide: pro %d", pro);
+}
+
+extern "C" int srwn_wgrad_wide(const void* a, int64_t a_chunk_stride, int64_t a_row_stride, int32_t m_chunks,
+                               int32_t chunk_width, const void* d, int64_t d_row_stride, int32_t d_width,
+                               float* partials, float* bias_partials, int64_t rows, int32_t nslabs, int32_t pro,
+                               int32_t dtype, void* stream) {
+  return wgrad_wide_launch(&a, &d, &partials, &bias_partials, 1, a_chunk_stride, a_row_stride, m_chunks, chunk_width,
+                           d_row_stride, d_width, rows, nslabs, pro, dtype, stream);
+}
+
+// two products of one shape as one launch (model.py:53,56: the head's two 1x1s -- out0 = a0^T . d0, out1 = a1^T . d1)
+extern "C" int srwn_wgrad_wide_pair(const void* a0, const void* d0, float* partials0, float* bias_partials0,
+                                    const void* a1, const void* d1, float* partials1, float* bias_partials1,
+                                    int64_t a_chunk_stride, int64_t a_row_stride, int32_t m_chunks, int32_t chunk_width,
+                                    int64_t d_row_stride, int32_t d_width, int64_t rows, int32_t nslabs, int32_t pro,
+                                    int32_t dtype, void* stream) {
+  const void* a[2] = {a0, a1};
+  const void* d[2] = {d0, d1};
+  float* p[2] = {partials0, partials1};
+  float* b[2] = {bias_partials0, bias_partials1};
+  return wgrad_wide_launch(a, d, p, b, 2, a_chunk_stride, a_row_stride, m_chunks, chunk_width, d_row_stride, d_width, rows,
+                           nslabs, pro, dtype, stream);
 }
 
 // ------------------------------------------------------------------------------------------

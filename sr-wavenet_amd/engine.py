@@ -893,9 +893,14 @@ class WaveNetEngine:
                 else:
                     K.wgrad256(zs_p, NR, R, L, self.dtotal, self.wg_parts, self.wg_bparts, N, self.ns_skip,
                                pro=K.PRO_GATE, chunk_width=R)
-            K.wgrad256(self.r0.data_ptr(), 64, S, S // 64, self.da1, self.hd_parts[0], self.hd_bparts[0], N, self.ns_head)
-            K.wgrad256(self.r1.data_ptr(), 64, S, S // 64, self.dlogits, self.hd_parts[1], self.hd_bparts[1], N,
-                       self.ns_head)                                                  # last 1x1 (S->C)
+            if S == Cp:   # both head 1x1s (S->S, S->C) as one launch
+                K.wgrad256_pair(self.r0.data_ptr(), self.da1, self.hd_parts[0], self.hd_bparts[0],
+                                self.r1.data_ptr(), self.dlogits, self.hd_parts[1], self.hd_bparts[1], 64, S, S // 64, N,
+                                self.ns_head)
+            else:
+                K.wgrad256(self.r0.data_ptr(), 64, S, S // 64, self.da1, self.hd_parts[0], self.hd_bparts[0], N, self.ns_head)
+                K.wgrad256(self.r1.data_ptr(), 64, S, S // 64, self.dlogits, self.hd_parts[1], self.hd_bparts[1], N,
+                           self.ns_head)
             K.reduce_partials_multi([
                 (self.wg_parts, ns_skip, L * R * S, 1, True, 1.0, gp + 4 * sec["WS"].offset, 0),
                 (self.wg_bparts, ns_skip, S, L, False, 1.0, gp + 4 * sec["BS"].offset, S),

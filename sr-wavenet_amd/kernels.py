@@ -565,6 +565,23 @@ def wgrad256(a_ptr: int, a_chunk_stride: int, a_row_stride: int, m_chunks: int, 
          pp, pb, int(rows), int(nslabs), int(pro), abi_dtype(d.dtype), _stream())
 
 
+def wgrad256_pair(a0_ptr: int, d0: torch.Tensor, parts0: torch.Tensor, bparts0: torch.Tensor, a1_ptr: int,
+                  d1: torch.Tensor, parts1: torch.Tensor, bparts1: torch.Tensor, a_chunk_stride: int, a_row_stride: int,
+                  m_chunks: int, rows: int, nslabs: int, chunk_width: int = 64):
+    """Two wgrad256 products of one shape (the head's two 1x1s) as one launch."""
+    dw = d0.shape[-1]
+    if d0.shape != d1.shape or d0.shape[0] != rows or dw not in (128, 256):
+        raise ValueError("wgrad256_pair: d0 %s d1 %s" % (tuple(d0.shape), tuple(d1.shape)))
+    need = nslabs * m_chunks * chunk_width * dw
+    for t, n in ((parts0, need), (parts1, need), (bparts0, nslabs * dw), (bparts1, nslabs * dw)):
+        if t.numel() < n:
+            raise ValueError("wgrad256_pair: partial buffer needs %d floats" % n)
+    call("srwn_wgrad_wide_pair", a0_ptr, _chk(d0, "d0"), _chk(parts0, "partials0", torch.float32),
+         _chk(bparts0, "bias_partials0", torch.float32), a1_ptr, _chk(d1, "d1"), _chk(parts1, "partials1", torch.float32),
+         _chk(bparts1, "bias_partials1", torch.float32), int(a_chunk_stride), int(a_row_stride), int(m_chunks),
+         int(chunk_width), dw, dw, int(rows), int(nslabs), PRO_NONE, abi_dtype(d0.dtype), _stream())
+
+
 def _i32_array(vals):
     import ctypes as C
     return (C.c_int32 * len(vals))(*[int(v) for v in vals])
