@@ -13,7 +13,7 @@ eng.set_inputs(a, torch.randint(0, 256, (8, 16000), dtype=torch.int32, device="c
 eng.forward(); eng.backward()
 torch.cuda.synchronize()
 l0, l1 = eng.groups[1]
-cases = {"group_bwd": lambda: eng._group_bwd_wt(l0, l1), "group_fwd": lambda: eng._group_fwd(l0, l1),
+cases = {"group_bwd": lambda: eng._group_bwd_wt(l0, l1), "group_fwd": lambda: eng._group_fwd(l0, l1, None),
          "group_bwd_g0": lambda: eng._group_bwd_wt(*eng.groups[0])}
 for name, fn in cases.items():
     for n in (1, 2, 4, 8):
