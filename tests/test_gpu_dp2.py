@@ -68,7 +68,9 @@ def test_two_ranks_equal_one_process_on_the_global_batch(tmp_path, mode, buckets
     assert gerr < (1e-4 if mode == "deep" else 1e-5), gerr
     # parameters after the first Adam step and after the two graph-replayed ones, where the gradient is not numerically
     # zero (Adam turns the sign of a ~1e-9 gradient entry into a 1e-3 step, and later steps amplify that)
-    live = gref.abs() > 1e-4 * gref.abs().max()
+    # ("deep": the bf16 gradients of two ranks and one process may differ by 1e-4 of the largest entry -- the bound
+    # above -- so an entry has to be ten times that to keep its sign and size through Adam's normalisation)
+    live = gref.abs() > (1e-3 if mode == "deep" else 1e-4) * gref.abs().max()
     err1 = float((r0["params1"].double() - ref["params1"].double())[live].abs().max())
     assert err1 < 1e-6, err1
     p, q = r0["params"].double(), ref["params"].double()
