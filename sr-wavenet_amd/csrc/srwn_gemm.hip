@@ -27,6 +27,7 @@ struct RgArgs {
   // TAPS: k-chunk c is time tap c -> row + c*tap_step inside the same clip of tap_T rows (zero outside);
   // frame_add (fp32 [clips*frames, frame_add_ld]) * frame_add_scale is added per row before the epilogue
   int tap_T; int tap_step; const float* frame_add; int64_t frame_add_ld; int frames; int pool; float frame_add_scale;
+  int safe_wait;   // SRWN_SAFE_WAIT: vmcnt(0) instead of the counted wait
 };
 
 template <typename T> __device__ __forceinline__ void glds16(const void* g, void* l) {
@@ -183,7 +184,8 @@ __global__ __launch_bounds__(64 * rg_waves(EPI, NT), (EPI == SRWN_EPI_SOFTMAX_CE
           for (int nt = 0; nt < NT; ++nt) mma(acc[mt][nt], af, bcur[nt][ks]);
         }
     }
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NT * KSC) : "memory");
+    if (a.safe_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NT * KSC) : "memory");
     __syncthreads();
   };
   {
@@ -322,6 +324,7 @@ __global__ __launch_bounds__(64 * rg_waves(EPI, NT), (EPI == SRWN_EPI_SOFTMAX_CE
 // ------------------------------------------------------------------------------------------
 struct CgArgs {
   const void* x; int64_t x_row_stride; const void* wpack; void* y; int64_t y_layer_stride; int nlayers; int64_t rows;
+  int safe_wait;
 };
 
 // NW waves per workgroup share each layer's weight image (every workgroup streams all of them: 8 waves halve that
@@ -412,7 +415,8 @@ __global__ __launch_bounds__(64 * NW) void colgemm_kernel(CgArgs a) {
       constexpr int STORES = 32 / (64 / (R / RowStage<T>::VEC));    // store instructions of one tile (whole rows, 16 B per lane)
       if (rows_valid > 0) {                                         // (wave-uniform)
         store_rows_via_lds<T, RT, true>(stage, ytile, R, v, rows_valid, lane);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STORES) : "memory");   // next image landed, older stores out; these fly on
+        if (a.safe_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STORES) : "memory");   // next image landed, older stores out; these fly on
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
@@ -445,7 +449,7 @@ extern "C" int srwn_skip_dgrad_all(const void* dtotal, const void* wskipT_all, v
   if (rows == 0 || nlayers == 0) return 0;
   if (!dtotal || !wskipT_all || !dcs) return set_error(SRWN_E_NULL, "skip_dgrad_all: null pointer");
   if (rows < 0 || nlayers < 0) return set_error(SRWN_E_SHAPE, "skip_dgrad_all: rows=%lld layers=%d", (long long)rows, nlayers);
-  CgArgs a{dtotal, S, wskipT_all, dcs, dcs_layer_stride, nlayers, rows};
+  CgArgs a{dtotal, S, wskipT_all, dcs, dcs_layer_stride, nlayers, rows, safe_wait()};
   hipStream_t st = (hipStream_t)stream;
   if (R == 64 && S == 256) {
     if (dtype == SRWN_BF16) return launch_cg<bf16_t, 2, 16, 2>(a, st);
@@ -528,14 +532,14 @@ int rowgemm_dispatch(const void* x, int64_t x_row_stride, int64_t x_chunk_stride
   if (cout_pad == 128) {   // 128-wide products (the reference scripts' skip_channels=128): 4 row tiles per wave
     if (epi == SRWN_EPI_SOFTMAX_CE) return 0;
     RgArgs a4{x, x_row_stride, x_chunk_stride, chunk_len, Cin / 16, wpack, bias, y, y_row_stride, cout_valid, rows,
-              aux, aux_row_stride, targets, loss_partials, logits_out, grad_scale, 0, 0, nullptr, 0, 0, 1, 0.0f};
+              aux, aux_row_stride, targets, loss_partials, logits_out, grad_scale, 0, 0, nullptr, 0, 0, 1, 0.0f, safe_wait()};
     if (dtype == SRWN_BF16) *rc = launch_rg<bf16_t, 4, 4, 1>(a4, pro, epi, st);
     else if (dtype == SRWN_F32) *rc = launch_rg<float, 4, 2, 1>(a4, pro, epi, st);
     else return 0;
     return 1;
   }
   RgArgs a{x, x_row_stride, x_chunk_stride, chunk_len, Cin / 16, wpack, bias, y, y_row_stride, cout_valid, rows,
-           aux, aux_row_stride, targets, loss_partials, logits_out, grad_scale, 0, 0, nullptr, 0, 0, 1, 0.0f};
+           aux, aux_row_stride, targets, loss_partials, logits_out, grad_scale, 0, 0, nullptr, 0, 0, 1, 0.0f, safe_wait()};
   if (dtype == SRWN_BF16) *rc = launch_rg<bf16_t, 8, 4, 1>(a, pro, epi, st);   // (two row tiles per wave measured slower: DESIGN.md 5)
   else if (dtype == SRWN_F32) *rc = launch_rg<float, 8, 2, 1>(a, pro, epi, st);
   else return 0;
@@ -563,7 +567,8 @@ extern "C" int srwn_tap_linear(const void* x, int64_t x_row_stride, int32_t ntap
     return set_error(SRWN_E_SHAPE, "tap_linear: rows=%lld T=%d taps=%d Cin=%d cout=%d frames=%d pool=%d",
                      (long long)rows, T, ntaps, Cin, cout, frames, pool_stride);
   RgArgs a{x, x_row_stride, 0, Cin, ntaps * Cin / 16, wpack, bias, y, y_row_stride, cout, rows, aux, aux_row_stride,
-           nullptr, nullptr, nullptr, 0.0f, T, tap_step, frame_add, frame_add_ld, frames, pool_stride, frame_add_scale};
+           nullptr, nullptr, nullptr, 0.0f, T, tap_step, frame_add, frame_add_ld, frames, pool_stride, frame_add_scale,
+           safe_wait()};
   hipStream_t st = (hipStream_t)stream;
   if (dtype == SRWN_BF16) return cout == 128 ? launch_rg_taps<bf16_t, 4, 4>(a, epi, st) : launch_rg_taps<bf16_t, 8, 4>(a, epi, st);
   if (dtype == SRWN_F32) return cout == 128 ? launch_rg_taps<float, 4, 2>(a, epi, st) : launch_rg_taps<float, 8, 2>(a, epi, st);

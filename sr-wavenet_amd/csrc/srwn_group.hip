@@ -30,6 +30,7 @@ using namespace srwn::grp;
 namespace {
 
 struct GroupFwdArgs {
+  int safe_wait;        // SRWN_SAFE_WAIT: vmcnt(0) instead of the counted waits
   const void* x0;                 // input of the group's first layer [B,T,R]
   void* x_out;                    // layer g's output at x_out + g*layer_stride (elements)
   void* z_out;                    // layer g's z at z_out + g*layer_stride
@@ -125,11 +126,13 @@ __global__ __launch_bounds__(64 * NWV) void group_fwd_kernel(GroupFwdArgs a) {
       }
     } else if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if (xrows) {
-      if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STP) : "memory");
+      if (a.safe_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STP) : "memory");
       else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * STP) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * STP) : "memory");
     } else {
-      if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STZ) : "memory");
+      if (a.safe_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STZ) : "memory");
       else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * STZ) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * STZ) : "memory");
     }
@@ -1114,6 +1117,7 @@ static int group_fwd_impl(const void* x0, void* x_out, void* z_out, int64_t laye
     return set_error(SRWN_E_SHAPE, "residual_group_fwd: nlayers=%d (max %d) B=%d T=%d", nlayers, kMaxGroup, B, T);
   if (layer_stride < (int64_t)B * T * R) return set_error(SRWN_E_SHAPE, "residual_group_fwd: layer_stride %lld", (long long)layer_stride);
   GroupFwdArgs a;
+  a.safe_wait = safe_wait();
   a.x0 = x0; a.x_out = x_out; a.z_out = z_out; a.layer_stride = layer_stride;
   a.xT = xT; a.cT = cT; a.wt_stride = wt_stride; a.KT = 0; a.store_inner_x = store_inner_x ? 1 : 0;
   bool any_cond = false;
@@ -1258,7 +1262,13 @@ extern "C" int32_t srwn_group_plan(const int32_t* dilations, int32_t nlayers, in
 // Diagnostic hook (no reference counterpart): registers a device buffer of 1024 uint64; while one is registered, the
 // bf16 R = 64 forward group kernel runs in its stamped instantiation and workgroup 0 appends (tag << 48 | shader clock)
 // at its phase boundaries (tools/stamp_probe.py).  Pass NULL to return to the production instantiation.
-namespace srwn { unsigned long long* debug_stamps() { return g_stamps; } }
+namespace srwn {
+unsigned long long* debug_stamps() { return g_stamps; }
+int safe_wait() {
+  static const int v = [] { const char* e = getenv("SRWN_SAFE_WAIT"); return (e && atoi(e) != 0) ? 1 : 0; }();
+  return v;
+}
+}  // namespace srwn
 extern "C" int srwn_debug_stamp_buffer(void* device_buffer) {
   g_stamps = reinterpret_cast<unsigned long long*>(device_buffer);
   return 0;

@@ -61,6 +61,7 @@ struct HcArgs {
   void* r1; void* dlogits; void* da1; void* dtotal;   // [rows, 256] each
   int64_t rows;
   unsigned long long* stamps;   // diagnostic builds only (srwn_debug_stamp_buffer)
+  int safe_wait;                // SRWN_SAFE_WAIT: vmcnt(0) instead of the counted wait
 };
 
 constexpr int kHcWaves = 8;
@@ -227,7 +228,10 @@ __global__ __launch_bounds__(64 * kHcWaves) void headchain_kernel(HcArgs a) {
     }
     stamp(11);
     // chunk g+1 has landed (and this wave's older stores are out); the pieces of chunk g+2 are the youngest in flight
-    if constexpr (AHEAD > 1 && g + AHEAD < 4 * NCH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES / kHcWaves) : "memory");
+    if constexpr (AHEAD > 1 && g + AHEAD < 4 * NCH) {
+      if (a.safe_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES / kHcWaves) : "memory");
+    }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamp(12);
     if constexpr (c == NCH - 1) {
@@ -307,7 +311,7 @@ extern "C" int srwn_head_chain(const void* r0, const void* w1, const void* w2_pe
   if (rows < 0 || cout_valid < 1 || cout_valid > 256 || (rows + 31) / 32 / kHcWaves + 1 > 0x7fffffffLL)
     return set_error(SRWN_E_SHAPE, "head_chain: rows=%lld cout_valid=%d", (long long)rows, cout_valid);
   HcArgs a{r0, {w1, w2_perm, w2T_perm, w1T_perm}, b1, b2, targets, loss_partials, grad_scale, cout_valid,
-           r1, dlogits, da1, dtotal, rows, debug_stamps()};
+           r1, dlogits, da1, dtotal, rows, debug_stamps(), safe_wait()};
   const int64_t tiles = (rows + 31) / 32;
   const size_t sh = kHcBufs * (size_t)(8 * 4 * 1024) + (size_t)kHcWaves * 32 * RowStage<bf16_t>::stride(64) * sizeof(bf16_t) + 2 * 256 * sizeof(float) + (size_t)kHcWaves * 32 * 33;
   auto kfn = a.stamps ? headchain_kernel<bf16_t, true> : headchain_kernel<bf16_t, false>;

@@ -16,4 +16,7 @@ int rowgemm_dispatch(const void* x, int64_t x_row_stride, int64_t x_chunk_stride
                      hipStream_t st, int* rc);
 // srwn_group.hip: the buffer registered with srwn_debug_stamp_buffer (nullptr = production kernels)
 unsigned long long* debug_stamps();
+// SRWN_SAFE_WAIT=1: every hand-counted s_waitcnt vmcnt(N) of the kernels becomes vmcnt(0) (a test runs both and compares
+// bits: a count that a compiler change had made too large would show there)
+int safe_wait();
 }  // namespace srwn

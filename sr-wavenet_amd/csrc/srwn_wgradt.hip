@@ -38,6 +38,7 @@ struct WtSkipArgs {
   const void* d; long long d_row_stride;
   float* partials; float* bias_partials;
   int B, Tlen, nslabs, mtotal;
+  int safe_wait;                         // SRWN_SAFE_WAIT: vmcnt(0) instead of the counted waits
   int bias_blk;                          // the block whose idle waves sum dskip's columns (-1: none does)
   WtBlk blk[kMaxBlk];
 };
@@ -191,7 +192,8 @@ __global__ __launch_bounds__(512) void wgrad_skip_wt_kernel(WtSkipArgs a) {
   // the barrier publishes that tile and frees the one read an iteration ago
 #define SRWN_WT_ITER(IT, ACUR, ANEW)                                                                            \
   {                                                                                                             \
-    asm volatile("s_waitcnt vmcnt(6)" : "+v"(ACUR[0]), "+v"(ACUR[1]), "+v"(ACUR[2]), "+v"(ACUR[3])::"memory");  \
+    if (a.safe_wait) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ACUR[0]), "+v"(ACUR[1]), "+v"(ACUR[2]), "+v"(ACUR[3])::"memory"); \
+    else asm volatile("s_waitcnt vmcnt(6)" : "+v"(ACUR[0]), "+v"(ACUR[1]), "+v"(ACUR[2]), "+v"(ACUR[3])::"memory"); \
     wg_barrier();                                                                                               \
     load_a(ca, ANEW); advance(ca);                                                                              \
     dma_tile(cd, ((IT) + 3) & (kNB - 1)); advance(cd);                                                          \
@@ -199,7 +201,8 @@ __global__ __launch_bounds__(512) void wgrad_skip_wt_kernel(WtSkipArgs a) {
     else if (do_bias) bias_only((IT) & (kNB - 1));                                                              \
   }
   if (nit > 0) {   // the first chunk's first two B fragments: tile 0 (and 1) landed, the barrier publishes them
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if (a.safe_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     wg_barrier();
     if (live) { bq0 = bfrag(0, 0); bq1 = bfrag(0, 1); }
   }
@@ -306,6 +309,7 @@ extern "C" int srwn_wgrad_skip_wt(const void* cT, int64_t wt_layer_stride, const
                        (long long)wt_layer_stride);
   }
   a.bias_blk = -1;
+  a.safe_wait = safe_wait();
   if (bias_partials)
     for (int i = 0; i < nb && a.bias_blk < 0; ++i)
       if (a.blk[i].nl < 4) a.bias_blk = i;

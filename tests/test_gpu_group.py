@@ -109,6 +109,42 @@ def test_group_forward_eight_wave_body(monkeypatch):
         assert torch.equal(outs[0][k], outs[1][k]), k
 
 
+def test_hand_counted_waits_against_full_drains():
+    """The kernels that retire their LDS-DMA with a hand-counted s_waitcnt vmcnt(N) -- group_fwd, rowgemm, colgemm, the
+    one-launch head, the skip weight gradient -- leave N younger loads / stores in flight; N is right only while the
+    compiler emits as many of them as the source counts.  SRWN_SAFE_WAIT=1 replaces every such wait by vmcnt(0): one
+    training step of the default bf16 path (hipGraph-free) must give the same bits either way (a count grown too large
+    would let MFMAs read a buffer the DMA has not finished: different bits, or the same by luck -- run under both)."""
+    import subprocess, sys, os, textwrap
+    from tests._pkg import ROOT
+    code = textwrap.dedent("""
+        import importlib, sys, torch, numpy as np
+        sys.path.insert(0, %r)
+        EG = importlib.import_module("sr-wavenet_amd.engine")
+        cfg = EG.StackConfig(dilations=[1, 2, 4, 8, 16, 32, 64, 128, 256, 512], dilation_channels=64, skip_channels=256,
+                             output_channels=256, shift_input=True, dtype=torch.bfloat16)
+        eng = EG.WaveNetEngine(cfg, 2, 2100, "cuda", seed=3)
+        assert eng.fused_wt and eng.skip_wt and eng.head_chain
+        rng = np.random.default_rng(3)
+        eng.set_inputs(torch.tensor(np.clip(0.3 * rng.normal(size=(2, 2100)), -1, 1), dtype=torch.float32, device="cuda"),
+                       torch.tensor(rng.integers(0, 256, size=(2, 2100)), dtype=torch.int32, device="cuda"))
+        for _ in range(2):
+            eng.forward(); eng.backward(); eng.optimizer_step()
+        torch.cuda.synchronize()
+        torch.save({"zs": eng.zs.cpu(), "loss": eng.loss.cpu(), "grads": eng.grads.cpu(), "dtotal": eng.dtotal.cpu(),
+                    "dcs": eng.dcs.cpu(), "params": eng.params.cpu()}, sys.argv[1])
+    """ % ROOT)
+    outs = []
+    for safe in ("0", "1"):
+        out = os.path.join(str(os.environ.get("TMPDIR", "/tmp")), "srwn_safe_wait_%s_%d.pt" % (safe, os.getpid()))
+        env = dict(os.environ, SRWN_SAFE_WAIT=safe)
+        subprocess.run([sys.executable, "-c", code, out], env=env, check=True, cwd=ROOT, timeout=300)
+        outs.append(torch.load(out, weights_only=True))
+        os.remove(out)
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("E,pool", [(16, 8), (40, 50)])
 def test_group_forward_conditioned(monkeypatch, dt, E, pool):
