@@ -284,3 +284,13 @@ def test_duplicate_feature_key_resolves_to_the_last_entry(tmp_path):
     ts = [threading.Thread(target=work) for _ in range(8)]
     [t.start() for t in ts]; [t.join() for t in ts]
     assert out == [[77]] * 8
+    # a trailing duplicate with an EMPTY Feature body is still the last entry: it replaces the value (no kind, no
+    # elements), it does not leave the earlier one in place
+    ex2 = ld(1, entry("pitch", [10]) + ld(1, ld(1, b"pitch") + ld(2, b"")) + entry("audio", np.arange(2, dtype=np.float32)))
+    path2 = tmp_path / "dup_empty.tfrecord"
+    with open(path2, "wb") as f:
+        f.write(record(ex2))
+    r2 = NS.TFRecordFile(str(path2))
+    assert len(r2.feature(0, "pitch")) == 0
+    assert r2.feature(0, "audio").tolist() == [0.0, 1.0]
+    r2.close()
