@@ -398,29 +398,32 @@ int srwn_generate(const void* wcr, const void* wskip, const void* w1, const void
                   int32_t nsteps, int32_t R, int32_t S, int32_t C, int32_t K, int32_t mode, uint64_t seed,
                   int32_t dtype, void* stream);
 
-/* The latency-optimised body of srwn_generate for the benchmark's teacher (bf16, R = 64, S = 256, K = 2, unconditioned
- * softmax head): same arithmetic, same rings, same outputs, same RNG (teacher.py:140-171 is the loop it replaces), but
- * a layer's channels are split over the four waves on 16x16x32 tiles instead of every wave running the whole chain, and
- * the weights stream from L2 into registers one layer ahead (csrc/srwn_gen16.hip).  wl: per layer
- * [4 waves][conv k-steps 0..3 (k < R: delayed tap, k >= R: current tap) | residual k-steps 0..1 | skip (row blocks 0..3)
- * x (k-steps 0..1)] fragment images of 64 lanes x 8 elements, lane l = row (l & 15), k = 8 (l >> 4) + j; wave w owns conv /
- * residual rows 16w.. and skip rows 64w..; wh1 / wh2: [4 waves][4 row blocks][8 k-steps] of the two head 1x1s -- wave w,
- * block rb = rows 64w + 16rb of wh1 but rows 16 (4 rb + w) of wh2 (a head with few outputs still splits over the waves;
- * rows beyond ceil(C/32)*32 zero).  The rings must be handed over zero-filled.  srwn_generate16_image_elems(nlayers, 0 | 1) = elements of wl | of each head image. */
-int64_t srwn_generate16_image_elems(int32_t nlayers, int32_t which);
+/* The latency-optimised body of srwn_generate / srwn_generate_mol for bf16 stacks of R = 64 or 32 residual and S = 256 or
+ * 128 skip channels, K = 2: same arithmetic, same rings (handed over ZERO-FILLED: a step before the first delayed tap
+ * exists reads the slot nobody has written), same outputs, same RNG (teacher.py:140-171 / generator.py:150-170 are the
+ * loops it replaces), but a layer's channels are split over the four waves on 16x16x32 tiles instead of every wave
+ * running the whole chain, and the weights stream from L2 into registers one layer ahead (csrc/srwn_gen16.hip).
+ * Fragment images of 64 lanes x 8 elements, lane l = row (l & 15), k = 8 (l >> 4) + j.  wl: per layer [4 waves][conv
+ * k-steps 0..2R/32-1 (k < R: delayed tap, k >= R: current tap) | residual k-steps 0..R/32-1 | skip (S/64 row blocks) x
+ * (R/32 k-steps)]; wave w owns conv / residual rows 16w.. (none for w >= R/16: zero fragments) and skip rows (S/4)w..;
+ * wh1: [4 waves][S/64 row blocks][S/32 k-steps], wave w, block rb = rows (S/4) w + 16 rb; wh2: [4 waves][4 row
+ * blocks][S/32 k-steps], rows 16 (4 rb + w) -- a head with few outputs still splits over the waves; rows beyond
+ * ceil(C/32)*32 zero.  srwn_generate16_image_elems(nlayers, 0 | 1 | 2, R, S) = elements of wl | wh1 | wh2. */
+int64_t srwn_generate16_image_elems(int32_t nlayers, int32_t which, int32_t R, int32_t S);
 int srwn_generate16(const void* wl, const void* wh1, const void* wh2, const float* bias_f, const float* bias_r,
                     const float* bs_sum, const float* b1, const float* b2, const float* init_w, const float* init_b,
                     void* ring, float* audio_out, int32_t* codes_out, float* logits_out, const float* forced,
-                    const int32_t* dilations, int32_t nlayers, int32_t B, int32_t Tout, int32_t nsteps, int32_t C,
-                    int32_t mode, uint64_t seed, void* stream);
+                    const int32_t* dilations, int32_t nlayers, int32_t B, int32_t Tout, int32_t nsteps, int32_t R,
+                    int32_t S, int32_t C, int32_t mode, uint64_t seed, void* stream);
 /* ... and for the conditioned mixture-of-logistics decoder (the model generator.py:150-170 samples from; arguments as
  * srwn_generate_mol): cond [B*cond_frames, cond_ld] bf16 (cond_ld a multiple of 4) or NULL. */
 int srwn_generate16_mol(const void* wl, const void* wh1, const void* wh2, const float* bias_f, const float* bias_r,
                         const float* bs_sum, const float* b1, const float* b2, const float* init_w,
                         const float* init_b, void* ring, float* audio_out, int32_t* codes_out, float* logits_out,
                         const float* forced, const int32_t* dilations, int32_t nlayers, int32_t B, int32_t Tout,
-                        int32_t nsteps, int32_t num_mixtures, const void* cond, int32_t cond_frames,
-                        int32_t pool_stride, int64_t cond_ld, int32_t mode, uint64_t seed, void* stream);
+                        int32_t nsteps, int32_t R, int32_t S, int32_t num_mixtures, const void* cond,
+                        int32_t cond_frames, int32_t pool_stride, int64_t cond_ld, int32_t mode, uint64_t seed,
+                        void* stream);
 
 /* The same generator for the conditioned mixture-of-logistics decoder of WaveNetAutoEncoder (model.py:158-200; the
  * reference samples it with one whole-clip pass per sample, generator.py:150-170): cond [B*cond_frames, cond_ld] in

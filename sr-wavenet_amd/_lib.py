@@ -82,11 +82,11 @@ SIGNATURES = {
     "srwn_generate_ring_elems": (_i64, [_p, _i32, _i32]),
     "srwn_generate": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32,
                                 _i32, _i32, _i32, _i32, _i32, _i32, C.c_uint64, _i32, _p]),
-    "srwn_generate16_image_elems": (_i64, [_i32, _i32]),
+    "srwn_generate16_image_elems": (_i64, [_i32, _i32, _i32, _i32]),
     "srwn_generate16": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32,
-                                  _i32, _i32, C.c_uint64, _p]),
+                                  _i32, _i32, _i32, _i32, C.c_uint64, _p]),
     "srwn_generate16_mol": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32,
-                                      _i32, _i32, _p, _i32, _i32, _i64, _i32, C.c_uint64, _p]),
+                                      _i32, _i32, _i32, _i32, _p, _i32, _i32, _i64, _i32, C.c_uint64, _p]),
     "srwn_generate_mol": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32,
                                     _i32, _i32, _i32, _i32, _i32, _p, _i32, _i32, _i64, _i32, C.c_uint64, _i32, _p]),
     "srwn_mol_loss": (C.c_int, [_p, _i64, _p, _i32, _p, _p, _i64, _i64, _f32, _i32, _p]),

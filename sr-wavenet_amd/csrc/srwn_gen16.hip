@@ -61,26 +61,38 @@ __device__ __forceinline__ float g16_uniform(unsigned long long seed, unsigned u
 }
 
 typedef bf16_t T;
-constexpr int R = 64, S = 256, LSX = 72, LSH = 264, LGS = 256;
+constexpr int LGS = 256;
 constexpr int FR = 512;                       // elements of one fragment image (64 lanes x 8)
-constexpr int LAYER_FR = 4 * 14;              // fragment images per layer
+// widths: R residual channels (64; 32 = the reference scripts' dilation_channels: only two waves have channels of the
+// layer chain, all four share the skip and head rows), S skip channels (256 or 128)
+template <int R, int S> struct G16W {
+  static constexpr int KR = R / 32;           // k-steps of one tap / of the residual 1x1
+  static constexpr int KC = 2 * KR;           // k-steps of the conv: [delayed tap | current tap]
+  static constexpr int SRB = S / 64;          // 16-row blocks of the skip 1x1 / of the first head 1x1 per wave
+  static constexpr int HKS = S / 32;          // k-steps of the head 1x1s
+  static constexpr int CW = R / 16;           // waves that own channels of the layer chain
+  static constexpr int WFR = KC + KR + SRB * KR;   // fragments of one layer per wave
+  static constexpr int LSX = R + 8, LSH = S + 8;
+};
 
 // one layer's operands of a wave that do not depend on the step's activations: its weight fragments and the delayed tap
 // NCB: 16-utterance column blocks per workgroup (2: one workgroup per ring group of 32 utterances; 1: two workgroups share
 // a ring group, each half the work per layer -- the choice whenever the utterances do not fill the chip's CUs otherwise)
 struct G16NoCond {};
 template <int NCB> struct G16Cond { bf16x4 cc[NCB]; };   // cb_l of the current frame: this wave's channels 16w + 4rq..
-template <int NCB, bool COND>
+template <int NCB, bool COND, int R, int S>
 struct PreT : std::conditional<COND, G16Cond<NCB>, G16NoCond>::type {
-  Frag<T> wc[4], wr[2], ws[4][2];
-  Frag<T> x0[2][NCB];                         // [k-step of the delayed tap][column block]
+  Frag<T> wc[G16W<R, S>::KC], wr[G16W<R, S>::KR], ws[G16W<R, S>::SRB][G16W<R, S>::KR];
+  Frag<T> x0[G16W<R, S>::KR][NCB];            // [k-step of the delayed tap][column block]
 };
 
-template <int NCB, bool COND, bool MOL>
+template <int NCB, bool COND, bool MOL, int R, int S>
 __global__ __launch_bounds__(256) void generate16_kernel(Gen16Args a) {
   constexpr int NU = 16 * NCB;                // utterances of this workgroup
   constexpr int NI = 4 * NCB;                 // utterances a wave samples
-  using Pre = PreT<NCB, COND>;
+  using W = G16W<R, S>;
+  constexpr int KR = W::KR, KC = W::KC, SRB = W::SRB, HKS = W::HKS, LSX = W::LSX, LSH = W::LSH;
+  using Pre = PreT<NCB, COND, R, S>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* xb = reinterpret_cast<T*>(smem);                         // [32][LSX] the layer input x_l[t]
   T* cb = xb + 32 * LSX;                                      // [32][LSX] the gate output c_l[t]
@@ -102,6 +114,7 @@ __global__ __launch_bounds__(256) void generate16_kernel(Gen16Args a) {
   const int urow = u0 & 31;                                   // this workgroup's first row inside its ring group
   T* ring = reinterpret_cast<T*>(a.ring) + (size_t)(u0 >> 5) * a.ring_group_elems + urow * R;
   const T* wl = reinterpret_cast<const T*>(a.wl);
+  const bool chw = W::CW == 4 || wave < W::CW;                // this wave owns 16 channels of the layer chain
 
   for (int i = threadIdx.x; i < a.L * R; i += 256) { c_bf[i] = a.bias_f[i]; c_br[i] = a.bias_r[i]; }
   for (int i = threadIdx.x; i < S; i += 256) { c_bs[i] = a.bs_sum[i]; c_b1[i] = a.b1[i]; }
@@ -126,6 +139,7 @@ __global__ __launch_bounds__(256) void generate16_kernel(Gen16Args a) {
   const T* condp = reinterpret_cast<const T*>(a.cond);
   auto preload = [&](int l, int ahead, int t, Pre& p) {
     if constexpr (COND) {   // (first: the epilogue of the layer below needs it before anything else of this set)
+      if (chw) {
       const int tt = t + ahead;
       const int fc = tt / a.pool < a.cond_frames ? tt / a.pool : a.cond_frames - 1;
 #pragma unroll
@@ -134,23 +148,24 @@ __global__ __launch_bounds__(256) void generate16_kernel(Gen16Args a) {
         const int uc = ug < a.B ? ug : a.B - 1;
         p.cc[c2] = *reinterpret_cast<const bf16x4*>(condp + ((size_t)uc * a.cond_frames + fc) * a.cond_ld + (size_t)l * R + 16 * wave + 4 * rq);
       }
+      }
     }
-    const T* w = wl + ((size_t)l * LAYER_FR + wave * 14) * FR + lane * 8;
+    const T* w = wl + ((size_t)l * 4 + wave) * (W::WFR * FR) + lane * 8;
 #pragma unroll
-    for (int f = 0; f < 4; ++f) p.wc[f] = load_nat(w + f * FR);
+    for (int f = 0; f < KC; ++f) p.wc[f] = load_nat(w + f * FR);
 #pragma unroll
-    for (int f = 0; f < 2; ++f) p.wr[f] = load_nat(w + (4 + f) * FR);
+    for (int f = 0; f < KR; ++f) p.wr[f] = load_nat(w + (KC + f) * FR);
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb)
+    for (int rb = 0; rb < SRB; ++rb)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) p.ws[rb][ks] = load_nat(w + (6 + 2 * rb + ks) * FR);
+      for (int ks = 0; ks < KR; ++ks) p.ws[rb][ks] = load_nat(w + (KC + KR + KR * rb + ks) * FR);
     const int depth = __builtin_amdgcn_readlane(depthv, l);
     const int roff = __builtin_amdgcn_readlane(roffv, l);
     int slot = wrap(__builtin_amdgcn_readlane(curv, l) + 1, depth);
     if (ahead) slot = wrap(slot + 1, depth);
     const T* rp = ring + roff + (size_t)slot * (32 * R) + col * R + 8 * rq;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int ks = 0; ks < KR; ++ks)
 #pragma unroll
       for (int c2 = 0; c2 < NCB; ++c2) p.x0[ks][c2] = load_nat(rp + 16 * c2 * R + 32 * ks);
   };
@@ -176,31 +191,32 @@ __global__ __launch_bounds__(256) void generate16_kernel(Gen16Args a) {
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int n = 16 * wave + 4 * rq + r;
+        const int n = chw ? 16 * wave + 4 * rq + r : 0;
         xs[c2][r] = (float)(T)fmaf(c_iw[n], a2, fmaf(c_iw[R + n], a1, c_ib[n]));
         // (conditioned decoder, model.py:176-189: the layer's input is the output below + cb_l, rounded once more --
         // the input conv's output was stored rounded first, as srwn_residual_layer_fwd sees it)
         if constexpr (COND) xs[c2][r] = (float)(T)(xs[c2][r] + (float)pa.cc[c2][r]);
       }
-      store4(xb + (size_t)(16 * c2 + col) * LSX + 16 * wave + 4 * rq, xs[c2][0], xs[c2][1], xs[c2][2], xs[c2][3]);
+      if (chw) store4(xb + (size_t)(16 * c2 + col) * LSX + 16 * wave + 4 * rq, xs[c2][0], xs[c2][1], xs[c2][2], xs[c2][3]);
     }
-    f32x4 accS[4][NCB];
+    f32x4 accS[SRB][NCB];
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb)
+    for (int rb = 0; rb < SRB; ++rb)
 #pragma unroll
       for (int c2 = 0; c2 < NCB; ++c2)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) accS[rb][c2][r] = c_bs[64 * wave + 16 * rb + 4 * rq + r];
+        for (int r = 0; r < 4; ++r) accS[rb][c2][r] = c_bs[16 * SRB * wave + 16 * rb + 4 * rq + r];
     wg_barrier();
 
     auto layer = [&](int l, const Pre& p, Pre& pnext) {
       // x_l[t] of the workgroup -> the layer's ring (read d steps from now): each wave copies eight utterances' rows
       {
-        const int ul = 8 * wave + (lane >> 3);
+        constexpr int LPRW = R / 8, RPW = 64 / LPRW;          // lanes per row, rows per wave-instruction
+        const int ul = RPW * wave + lane / LPRW;
         const int slot = __builtin_amdgcn_readlane(curv, l), roff = __builtin_amdgcn_readlane(roffv, l);
-        if (8 * wave < NU) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (size_t)ul * LSX + (lane & 7) * 8);
-          *reinterpret_cast<f32x4*>(ring + roff + (size_t)slot * (32 * R) + ul * R + (lane & 7) * 8) = v;
+        if (RPW * wave < NU) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (size_t)ul * LSX + (lane % LPRW) * 8);
+          *reinterpret_cast<f32x4*>(ring + roff + (size_t)slot * (32 * R) + ul * R + (lane % LPRW) * 8) = v;
         }
       }
       // the next layer's weights and delayed tap, one layer ahead (after the top layer: layer 0 of the next step)
@@ -208,65 +224,71 @@ __global__ __launch_bounds__(256) void generate16_kernel(Gen16Args a) {
         const bool top = l + 1 >= a.L;
         preload(top ? 0 : l + 1, top ? 1 : 0, t, pnext);
       }
-      f32x4 accF[NCB];
-#pragma unroll
-      for (int c2 = 0; c2 < NCB; ++c2) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) accF[c2][r] = c_bf[l * R + 16 * wave + 4 * rq + r];
-      }
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+      if (chw) {
+        f32x4 accF[NCB];
 #pragma unroll
         for (int c2 = 0; c2 < NCB; ++c2) {
-          const Frag<T> x1 = load_nat(xb + (size_t)(16 * c2 + col) * LSX + 32 * ks + 8 * rq);
-          mma16(accF[c2], p.wc[2 + ks], x1);
-          mma16(accF[c2], p.wc[ks], p.x0[ks][c2]);
-        }
-      // tanh, gate (ops.py:28-36); z as the training graph stores it
 #pragma unroll
-      for (int c2 = 0; c2 < NCB; ++c2) {
-        float cv[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float z = Math<T>::tanh_(accF[c2][r]);
-          z = (float)(T)z;
-          cv[r] = gate_of_z<T>(z);
+          for (int r = 0; r < 4; ++r) accF[c2][r] = c_bf[l * R + 16 * wave + 4 * rq + r];
         }
-        store4(cb + (size_t)(16 * c2 + col) * LSX + 16 * wave + 4 * rq, cv[0], cv[1], cv[2], cv[3]);
+#pragma unroll
+        for (int ks = 0; ks < KR; ++ks)
+#pragma unroll
+          for (int c2 = 0; c2 < NCB; ++c2) {
+            const Frag<T> x1 = load_nat(xb + (size_t)(16 * c2 + col) * LSX + 32 * ks + 8 * rq);
+            mma16(accF[c2], p.wc[KR + ks], x1);
+            mma16(accF[c2], p.wc[ks], p.x0[ks][c2]);
+          }
+        // tanh, gate (ops.py:28-36); z as the training graph stores it
+#pragma unroll
+        for (int c2 = 0; c2 < NCB; ++c2) {
+          float cv[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float z = Math<T>::tanh_(accF[c2][r]);
+            z = (float)(T)z;
+            cv[r] = gate_of_z<T>(z);
+          }
+          store4(cb + (size_t)(16 * c2 + col) * LSX + 16 * wave + 4 * rq, cv[0], cv[1], cv[2], cv[3]);
+        }
       }
       wg_barrier();
-      Frag<T> cf[2][NCB];
+      Frag<T> cf[KR][NCB];
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+      for (int ks = 0; ks < KR; ++ks)
 #pragma unroll
         for (int c2 = 0; c2 < NCB; ++c2) cf[ks][c2] = load_nat(cb + (size_t)(16 * c2 + col) * LSX + 32 * ks + 8 * rq);
       f32x4 accR[NCB];
+      if (chw) {
 #pragma unroll
-      for (int c2 = 0; c2 < NCB; ++c2) {
+        for (int c2 = 0; c2 < NCB; ++c2) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) accR[c2][r] = c_br[l * R + 16 * wave + 4 * rq + r];
+          for (int r = 0; r < 4; ++r) accR[c2][r] = c_br[l * R + 16 * wave + 4 * rq + r];
+        }
+#pragma unroll
+        for (int ks = 0; ks < KR; ++ks)
+#pragma unroll
+          for (int c2 = 0; c2 < NCB; ++c2) mma16(accR[c2], p.wr[ks], cf[ks][c2]);
       }
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int c2 = 0; c2 < NCB; ++c2) mma16(accR[c2], p.wr[ks], cf[ks][c2]);
       // this wave's quarter of the skip 1x1 (ops.py:44), accumulated over layers (model.py:50): in the matrix pipe behind
       // the residual products while the VALU finishes the layer
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb)
+      for (int rb = 0; rb < SRB; ++rb)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < KR; ++ks)
 #pragma unroll
           for (int c2 = 0; c2 < NCB; ++c2) mma16(accS[rb][c2], p.ws[rb][ks], cf[ks][c2]);
+      if (chw) {
 #pragma unroll
-      for (int c2 = 0; c2 < NCB; ++c2) {
+        for (int c2 = 0; c2 < NCB; ++c2) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float y = (xs[c2][r] + accR[c2][r]) * kSqrtHalf;
-          if constexpr (COND) y += (l + 1 < a.L) ? (float)pnext.cc[c2][r] : 0.0f;   // the next layer's cb, rounded once with it
-          xs[c2][r] = (float)(T)y;
+          for (int r = 0; r < 4; ++r) {
+            float y = (xs[c2][r] + accR[c2][r]) * kSqrtHalf;
+            if constexpr (COND) y += (l + 1 < a.L) ? (float)pnext.cc[c2][r] : 0.0f;   // the next layer's cb, rounded once with it
+            xs[c2][r] = (float)(T)y;
+          }
+          store4(xb + (size_t)(16 * c2 + col) * LSX + 16 * wave + 4 * rq, xs[c2][0], xs[c2][1], xs[c2][2], xs[c2][3]);
         }
-        store4(xb + (size_t)(16 * c2 + col) * LSX + 16 * wave + 4 * rq, xs[c2][0], xs[c2][1], xs[c2][2], xs[c2][3]);
       }
       wg_barrier();
     };
@@ -281,62 +303,78 @@ __global__ __launch_bounds__(256) void generate16_kernel(Gen16Args a) {
     curv = wrap(curv + 1, depthv);
 
     // ---- head: relu(sum skip) -> 1x1 + relu -> 1x1 (model.py:51-56); the activations cross the waves through LDS.
-    // First product: wave w owns rows 64w..64w+63.  Second product: wave w owns the 16-row blocks w, w + 4, w + 8, w + 12,
-    // so that a head with few outputs (4M mixture parameters: 40 of 256 rows) still splits over the four waves; blocks
-    // beyond the padded output count (nrb2 per wave) are skipped.
-    Frag<T> hw[4][8];                           // the wave's 64 rows of one head 1x1: requested well before their products
+    // First product: wave w owns rows (S/4) w .. of the S outputs.  Second product (up to 256 outputs): wave w owns the
+    // 16-row blocks w, w + 4, w + 8, w + 12, so that a head with few outputs (4M mixture parameters: 40 of 256 rows)
+    // still splits over the four waves; blocks beyond the padded output count (nrb2 per wave) are skipped.
+    Frag<T> hw[4][HKS];                         // the wave's rows of one head 1x1: requested well before their products
     const int nrb2 = MOL ? (a.Cp + 63) / 64 : 4;
-    auto head_load = [&](const T* wimg, int nrb) {
+    auto head_load1 = [&](const T* wimg) {
+#pragma unroll
+      for (int rb = 0; rb < SRB; ++rb)
+#pragma unroll
+        for (int ks = 0; ks < HKS; ++ks) hw[rb][ks] = load_nat(wimg + ((size_t)(wave * SRB + rb) * HKS + ks) * FR + lane * 8);
+    };
+    auto head_load2 = [&](const T* wimg) {
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb)
-        if (rb < nrb) {
+        if (rb < nrb2) {
 #pragma unroll
-          for (int ks = 0; ks < 8; ++ks) hw[rb][ks] = load_nat(wimg + ((size_t)(wave * 4 + rb) * 8 + ks) * FR + lane * 8);
+          for (int ks = 0; ks < HKS; ++ks) hw[rb][ks] = load_nat(wimg + ((size_t)(wave * 4 + rb) * HKS + ks) * FR + lane * 8);
         }
     };
-    // row of (row block rb, accumulator row r) of this lane: SECOND = the interleaved blocks of the second product
-    auto hrow = [&](int rb, bool second) { return (second ? 16 * (4 * rb + wave) : 64 * wave + 16 * rb) + 4 * rq; };
-    auto head_product = [&](const float* bias, f32x4 (&acc)[4][NCB], bool second, int nrb) {
+    auto hrow1 = [&](int rb) { return 16 * SRB * wave + 16 * rb + 4 * rq; };
+    auto hrow2 = [&](int rb) { return 16 * (4 * rb + wave) + 4 * rq; };    // (the interleaved blocks of the second product)
+    auto relu_to_hx = [&](const f32x4 (&acc)[SRB][NCB]) {
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-        for (int c2 = 0; c2 < NCB; ++c2)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[rb][c2][r] = bias[hrow(rb, second) + r];
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks)
-#pragma unroll
-        for (int c2 = 0; c2 < NCB; ++c2) {
-          const Frag<T> bf = load_nat(hx + (size_t)(16 * c2 + col) * LSH + 32 * ks + 8 * rq);
-#pragma unroll
-          for (int rb = 0; rb < 4; ++rb)
-            if (rb < nrb) mma16(acc[rb][c2], hw[rb][ks], bf);
-        }
-    };
-    auto relu_to_hx = [&](const f32x4 (&acc)[4][NCB]) {
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb)
+      for (int rb = 0; rb < SRB; ++rb)
 #pragma unroll
         for (int c2 = 0; c2 < NCB; ++c2)
-          store4(hx + (size_t)(16 * c2 + col) * LSH + 64 * wave + 16 * rb + 4 * rq, fmaxf(acc[rb][c2][0], 0.f),
+          store4(hx + (size_t)(16 * c2 + col) * LSH + hrow1(rb), fmaxf(acc[rb][c2][0], 0.f),
                  fmaxf(acc[rb][c2][1], 0.f), fmaxf(acc[rb][c2][2], 0.f), fmaxf(acc[rb][c2][3], 0.f));
     };
-    head_load(reinterpret_cast<const T*>(a.wh1), 4);
+    head_load1(reinterpret_cast<const T*>(a.wh1));
     relu_to_hx(accS);
     wg_barrier();
-    f32x4 acc1[4][NCB];
-    head_product(c_b1, acc1, false, 4);
-    head_load(reinterpret_cast<const T*>(a.wh2), nrb2);   // behind the products, ahead of the exchange
+    f32x4 acc1[SRB][NCB];
+#pragma unroll
+    for (int rb = 0; rb < SRB; ++rb)
+#pragma unroll
+      for (int c2 = 0; c2 < NCB; ++c2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc1[rb][c2][r] = c_b1[hrow1(rb) + r];
+#pragma unroll
+    for (int ks = 0; ks < HKS; ++ks)
+#pragma unroll
+      for (int c2 = 0; c2 < NCB; ++c2) {
+        const Frag<T> bf = load_nat(hx + (size_t)(16 * c2 + col) * LSH + 32 * ks + 8 * rq);
+#pragma unroll
+        for (int rb = 0; rb < SRB; ++rb) mma16(acc1[rb][c2], hw[rb][ks], bf);
+      }
+    head_load2(reinterpret_cast<const T*>(a.wh2));   // behind the products, ahead of the exchange
     wg_barrier();                                 // everyone has read r0
     relu_to_hx(acc1);
     wg_barrier();
     f32x4 acc2[4][NCB];
-    head_product(c_b2, acc2, true, nrb2);
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
       for (int c2 = 0; c2 < NCB; ++c2)
-        *reinterpret_cast<f32x4*>(lgl + (size_t)(16 * c2 + col) * LGS + hrow(rb, true)) = acc2[rb][c2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc2[rb][c2][r] = c_b2[hrow2(rb) + r];
+#pragma unroll
+    for (int ks = 0; ks < HKS; ++ks)
+#pragma unroll
+      for (int c2 = 0; c2 < NCB; ++c2) {
+        const Frag<T> bf = load_nat(hx + (size_t)(16 * c2 + col) * LSH + 32 * ks + 8 * rq);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+          if (rb < nrb2) mma16(acc2[rb][c2], hw[rb][ks], bf);
+      }
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+      for (int c2 = 0; c2 < NCB; ++c2)
+        *reinterpret_cast<f32x4*>(lgl + (size_t)(16 * c2 + col) * LGS + hrow2(rb)) = acc2[rb][c2];
     wg_barrier();
 
     if constexpr (MOL) {
@@ -480,31 +518,18 @@ __global__ __launch_bounds__(256) void generate16_kernel(Gen16Args a) {
 
 }  // namespace
 
-// elements of the three weight images srwn_generate16 takes (in the activation type), for nlayers layers
-extern "C" int64_t srwn_generate16_image_elems(int32_t nlayers, int32_t which) {
-  if (which == 0) return (int64_t)nlayers * LAYER_FR * FR;
-  return (int64_t)4 * 4 * 8 * FR;
+// elements of the three weight images srwn_generate16 takes (in the activation type), for nlayers layers of R residual /
+// S skip channels: which = 0 the layers' image, 1 the first head 1x1's, 2 the second's
+extern "C" int64_t srwn_generate16_image_elems(int32_t nlayers, int32_t which, int32_t R, int32_t S) {
+  if ((R != 64 && R != 32) || (S != 256 && S != 128)) return 0;
+  const int KR = R / 32, SRB = S / 64, HKS = S / 32;
+  if (which == 0) return (int64_t)nlayers * 4 * (2 * KR + KR + SRB * KR) * FR;
+  if (which == 1) return (int64_t)4 * SRB * HKS * FR;
+  return (int64_t)4 * 4 * HKS * FR;
 }
 
-static int generate16_impl(const void* wl, const void* wh1, const void* wh2, const float* bias_f, const float* bias_r,
-                           const float* bs_sum, const float* b1, const float* b2, const float* init_w,
-                           const float* init_b, void* ring, float* audio_out, int32_t* codes_out, float* logits_out,
-                           const float* forced, const int32_t* dilations, int32_t nlayers, int32_t B, int32_t Tout,
-                           int32_t nsteps, int32_t C, int32_t mode, uint64_t seed, void* stream, int32_t M,
-                           const void* cond, int32_t cond_frames, int32_t pool, int64_t cond_ld) {
-  if (B == 0 || nsteps == 0) return 0;
-  if (!wl || !wh1 || !wh2 || !bias_f || !bias_r || !bs_sum || !b1 || !b2 || !init_w || !init_b || !ring || !audio_out ||
-      !codes_out || !dilations)
-    return set_error(SRWN_E_NULL, "generate16: null pointer");
-  if (C < 2 || C > 256) return set_error(SRWN_E_UNSUPPORTED, "generate16: C=%d (2..256)", C);
-  if (B < 0 || nsteps < 0 || nsteps > Tout || nlayers < 1 || nlayers > kG16MaxLayers || (mode != 0 && mode != 1))
-    return set_error(SRWN_E_SHAPE, "generate16: B=%d nsteps=%d Tout=%d layers=%d mode=%d", B, nsteps, Tout, nlayers, mode);
-  Gen16Args a;
-  a.wl = wl; a.wh1 = wh1; a.wh2 = wh2; a.bias_f = bias_f; a.bias_r = bias_r; a.bs_sum = bs_sum; a.b1 = b1; a.b2 = b2;
-  a.init_w = init_w; a.init_b = init_b; a.ring = ring; a.audio_out = audio_out; a.codes_out = codes_out;
-  a.logits_out = logits_out; a.forced = forced;
-  a.B = B; a.Tout = Tout; a.nsteps = nsteps; a.L = nlayers; a.C = C; a.Cp = (C + 31) / 32 * 32; a.mode = mode; a.Q = C; a.seed = seed;
-  a.M = M; a.cond = cond; a.cond_frames = cond_frames; a.pool = pool; a.cond_ld = cond_ld;
+template <int R, int S>
+static int generate16_launch(Gen16Args& a, const int32_t* dilations, int32_t nlayers, int32_t B, bool cond, int32_t M, void* stream) {
   long long off = 0;
   for (int l = 0; l < kG16MaxLayers; ++l) {
     a.dil[l] = (l < nlayers) ? dilations[l] : 1;
@@ -519,25 +544,56 @@ static int generate16_impl(const void* wl, const void* wh1, const void* wh2, con
   bool half = (B + 15) / 16 <= num_cus();
   if (const char* e = getenv("SRWN_GEN16_NCB")) half = atoi(e) == 1;   // (tests: both bodies at any batch)
   const unsigned groups = half ? (unsigned)((B + 15) / 16) : (unsigned)((B + 31) / 32);
-  const size_t sh = (size_t)(2 * 32 * LSX + 32 * LSH) * sizeof(T) + (size_t)(32 * LGS + 64 + 2 * nlayers * R + 2 * S + 256 + 3 * R + 256) * 4;
-  auto kfn = M > 0 ? (cond ? (half ? generate16_kernel<1, true, true> : generate16_kernel<2, true, true>)
-                           : (half ? generate16_kernel<1, false, true> : generate16_kernel<2, false, true>))
-                   : (half ? generate16_kernel<1, false, false> : generate16_kernel<2, false, false>);
-  if (M == 0 && cond) return set_error(SRWN_E_UNSUPPORTED, "generate16: the conditioned softmax teacher is not built");
+  using W = G16W<R, S>;
+  const size_t sh = (size_t)(2 * 32 * W::LSX + 32 * W::LSH) * sizeof(T) +
+                    (size_t)(32 * LGS + 64 + 2 * nlayers * R + 2 * S + 256 + 3 * R + 256) * 4;
+  auto kfn = M > 0 ? (cond ? (half ? generate16_kernel<1, true, true, R, S> : generate16_kernel<2, true, true, R, S>)
+                           : (half ? generate16_kernel<1, false, true, R, S> : generate16_kernel<2, false, true, R, S>))
+                   : (half ? generate16_kernel<1, false, false, R, S> : generate16_kernel<2, false, false, R, S>);
   hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
   if (e != hipSuccess) return set_error((int)e, "generate16: LDS %zu: %s", sh, hipGetErrorString(e));
   hipLaunchKernelGGL(kfn, dim3(groups), dim3(256), sh, (hipStream_t)stream, a);
   return check_launch("generate16");
 }
 
+static int generate16_impl(const void* wl, const void* wh1, const void* wh2, const float* bias_f, const float* bias_r,
+                           const float* bs_sum, const float* b1, const float* b2, const float* init_w,
+                           const float* init_b, void* ring, float* audio_out, int32_t* codes_out, float* logits_out,
+                           const float* forced, const int32_t* dilations, int32_t nlayers, int32_t B, int32_t Tout,
+                           int32_t nsteps, int32_t R, int32_t S, int32_t C, int32_t mode, uint64_t seed, void* stream,
+                           int32_t M, const void* cond, int32_t cond_frames, int32_t pool, int64_t cond_ld) {
+  if (B == 0 || nsteps == 0) return 0;
+  if (!wl || !wh1 || !wh2 || !bias_f || !bias_r || !bs_sum || !b1 || !b2 || !init_w || !init_b || !ring || !audio_out ||
+      !codes_out || !dilations)
+    return set_error(SRWN_E_NULL, "generate16: null pointer");
+  if ((R != 64 && R != 32) || (S != 256 && S != 128) || C < 2 || C > 256)
+    return set_error(SRWN_E_UNSUPPORTED, "generate16: built for R = 64 or 32, S = 256 or 128, C <= 256 (got R=%d S=%d C=%d)", R, S, C);
+  if (B < 0 || nsteps < 0 || nsteps > Tout || nlayers < 1 || nlayers > kG16MaxLayers || (mode != 0 && mode != 1))
+    return set_error(SRWN_E_SHAPE, "generate16: B=%d nsteps=%d Tout=%d layers=%d mode=%d", B, nsteps, Tout, nlayers, mode);
+  if (M == 0 && cond) return set_error(SRWN_E_UNSUPPORTED, "generate16: the conditioned softmax teacher is not built");
+  if (cond && (cond_frames < 1 || pool < 1 || cond_ld < (int64_t)nlayers * R || (cond_ld % 4)))
+    return set_error(SRWN_E_SHAPE, "generate16_mol: cond_frames=%d pool_stride=%d cond_ld=%lld", cond_frames, pool, (long long)cond_ld);
+  Gen16Args a;
+  a.wl = wl; a.wh1 = wh1; a.wh2 = wh2; a.bias_f = bias_f; a.bias_r = bias_r; a.bs_sum = bs_sum; a.b1 = b1; a.b2 = b2;
+  a.init_w = init_w; a.init_b = init_b; a.ring = ring; a.audio_out = audio_out; a.codes_out = codes_out;
+  a.logits_out = logits_out; a.forced = forced;
+  a.B = B; a.Tout = Tout; a.nsteps = nsteps; a.L = nlayers; a.C = C; a.Cp = (C + 31) / 32 * 32; a.mode = mode; a.Q = C; a.seed = seed;
+  a.M = M; a.cond = cond; a.cond_frames = cond_frames; a.pool = pool; a.cond_ld = cond_ld;
+  if (R == 64 && S == 256) return generate16_launch<64, 256>(a, dilations, nlayers, B, cond != nullptr, M, stream);
+  if (R == 64) return generate16_launch<64, 128>(a, dilations, nlayers, B, cond != nullptr, M, stream);
+  if (S == 256) return generate16_launch<32, 256>(a, dilations, nlayers, B, cond != nullptr, M, stream);
+  return generate16_launch<32, 128>(a, dilations, nlayers, B, cond != nullptr, M, stream);
+}
+
 extern "C" int srwn_generate16(const void* wl, const void* wh1, const void* wh2, const float* bias_f,
                                const float* bias_r, const float* bs_sum, const float* b1, const float* b2,
                                const float* init_w, const float* init_b, void* ring, float* audio_out,
                                int32_t* codes_out, float* logits_out, const float* forced, const int32_t* dilations,
-                               int32_t nlayers, int32_t B, int32_t Tout, int32_t nsteps, int32_t C, int32_t mode,
-                               uint64_t seed, void* stream) {
+                               int32_t nlayers, int32_t B, int32_t Tout, int32_t nsteps, int32_t R, int32_t S,
+                               int32_t C, int32_t mode, uint64_t seed, void* stream) {
   return generate16_impl(wl, wh1, wh2, bias_f, bias_r, bs_sum, b1, b2, init_w, init_b, ring, audio_out, codes_out,
-                         logits_out, forced, dilations, nlayers, B, Tout, nsteps, C, mode, seed, stream, 0, nullptr, 1, 1, 0);
+                         logits_out, forced, dilations, nlayers, B, Tout, nsteps, R, S, C, mode, seed, stream, 0, nullptr, 1,
+                         1, 0);
 }
 
 // the same body for the conditioned mixture-of-logistics decoder (srwn_generate_mol's arguments; wh2 / b2 cover
@@ -547,14 +603,11 @@ extern "C" int srwn_generate16_mol(const void* wl, const void* wh1, const void* 
                                    const float* init_w, const float* init_b, void* ring, float* audio_out,
                                    int32_t* codes_out, float* logits_out, const float* forced,
                                    const int32_t* dilations, int32_t nlayers, int32_t B, int32_t Tout, int32_t nsteps,
-                                   int32_t num_mixtures, const void* cond, int32_t cond_frames, int32_t pool_stride,
-                                   int64_t cond_ld, int32_t mode, uint64_t seed, void* stream) {
+                                   int32_t R, int32_t S, int32_t num_mixtures, const void* cond, int32_t cond_frames,
+                                   int32_t pool_stride, int64_t cond_ld, int32_t mode, uint64_t seed, void* stream) {
   if (num_mixtures < 1 || num_mixtures > 16)
     return set_error(SRWN_E_SHAPE, "generate16_mol: num_mixtures=%d (1..16)", num_mixtures);
-  if (cond && (cond_frames < 1 || pool_stride < 1 || cond_ld < (int64_t)nlayers * R || (cond_ld % 4)))
-    return set_error(SRWN_E_SHAPE, "generate16_mol: cond_frames=%d pool_stride=%d cond_ld=%lld", cond_frames, pool_stride,
-                     (long long)cond_ld);
   return generate16_impl(wl, wh1, wh2, bias_f, bias_r, bs_sum, b1, b2, init_w, init_b, ring, audio_out, codes_out,
-                         logits_out, forced, dilations, nlayers, B, Tout, nsteps, 4 * num_mixtures, mode, seed, stream,
+                         logits_out, forced, dilations, nlayers, B, Tout, nsteps, R, S, 4 * num_mixtures, mode, seed, stream,
                          num_mixtures, cond, cond ? cond_frames : 1, cond ? pool_stride : 1, cond_ld);
 }

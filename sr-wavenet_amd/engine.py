@@ -360,7 +360,7 @@ class WaveNetEngine:
                               ks_offset=l * R // 16, ks_count=R // 16, perm=True)
         # the latency-optimised generator's fragment images (csrc/srwn_gen16.hip): the benchmark's teacher only
         self.o_g16 = None
-        if (self.o_gen is not None and R == 64 and S == 256 and self.dt == torch.bfloat16
+        if (self.o_gen is not None and R in (32, 64) and S in (128, 256) and self.dt == torch.bfloat16
                 and ((self.cfg.head_mode == "per_timestep" and not self.E) or self.cfg.head_mode == "mol")):
             self.o_g16 = pk.reserve_raw(np.concatenate([P.gen16_layer_index(sec["WF"].offset, sec["WR"].offset,
                                                                             sec["WS"].offset, l, R, S) for l in range(L)]))
@@ -1058,7 +1058,7 @@ class WaveNetEngine:
             import os as _os
             if self.o_g16 is not None and _os.environ.get("SRWN_GEN16", "1") != "0":
                 _lib.call("srwn_generate16_mol", self.wptr(self.o_g16), self.wptr(self.o_g16_h1), self.wptr(self.o_g16_h2),
-                          *common[4:21], self.C // 4, None if cond_all is None else cond_all.data_ptr(), frames,
+                          *common[4:21], self.R, self.S, self.C // 4, None if cond_all is None else cond_all.data_ptr(), frames,
                           self.cfg.pool_stride, self.L * self.R, md, int(seed), st)
             else:
                 _lib.call("srwn_generate_mol", *common, self.Kw, self.C // 4,
@@ -1071,7 +1071,7 @@ class WaveNetEngine:
             import os as _os
             if self.o_g16 is not None and _os.environ.get("SRWN_GEN16", "1") != "0":
                 _lib.call("srwn_generate16", self.wptr(self.o_g16), self.wptr(self.o_g16_h1), self.wptr(self.o_g16_h2),
-                          *common[4:21], self.C, md, int(seed), st)
+                          *common[4:21], self.R, self.S, self.C, md, int(seed), st)
             else:
                 _lib.call("srwn_generate", *common, self.C, self.Kw, md, int(seed), K.abi_dtype(self.dt), st)
         return audio, codes, logits

@@ -93,31 +93,34 @@ def frag16_index(src_offset: int, row0: int, k0: int, row_stride: int, k_stride:
 
 
 def gen16_layer_index(sec_wf: int, sec_wr: int, sec_ws: int, l: int, R: int, S: int):
-    """[4 waves][conv ks 0..3 | res ks 0..1 | skip (rb 0..3) x (ks 0..1)] fragment images of layer l: wave w owns output
-    channels 16w.. of the conv (contraction over [tap 0 | tap 1] x R) and of the residual 1x1, and skip channels 64w.."""
+    """[4 waves][conv k-steps | residual k-steps | skip (row blocks) x (k-steps)] fragment images of layer l: wave w owns
+    output channels 16w.. of the conv (contraction over [delayed tap | current tap] x R: R/32 k-steps each) and of the
+    residual 1x1 (waves beyond R/16: zero fragments), and skip channels (S/4) w .. in S/64 blocks of 16."""
     import numpy as np
+    KR, SRB = R // 32, S // 64
     out = []
     for w in range(4):
-        for ks in range(4):       # conv: k < R: tap 0 (the delayed tap, ops.py:6-10), k >= R: tap 1; W[k][i][o] at ((l*2+k)*R + i)*R + o
-            tap, i0 = ks // 2, 32 * (ks % 2)
+        for ks in range(2 * KR):  # conv: k < R: tap 0 (the delayed tap, ops.py:6-10), k >= R: tap 1; W[k][i][o] at ((l*2+k)*R + i)*R + o
+            tap, i0 = ks // KR, 32 * (ks % KR)
             out.append(frag16_index(sec_wf + (l * 2 + tap) * R * R, 16 * w, i0, 1, R, R, R))
-        for ks in range(2):       # residual 1x1: W[i][o] at (l*R + i)*R + o
+        for ks in range(KR):      # residual 1x1: W[i][o] at (l*R + i)*R + o
             out.append(frag16_index(sec_wr + l * R * R, 16 * w, 32 * ks, 1, R, R, R))
-        for rb in range(4):       # skip 1x1: W[i][s] at (l*R + i)*S + s
-            for ks in range(2):
-                out.append(frag16_index(sec_ws + l * R * S, 64 * w + 16 * rb, 32 * ks, 1, S, S, R))
+        for rb in range(SRB):     # skip 1x1: W[i][s] at (l*R + i)*S + s
+            for ks in range(KR):
+                out.append(frag16_index(sec_ws + l * R * S, 16 * SRB * w + 16 * rb, 32 * ks, 1, S, S, R))
     return np.stack(out)
 
 
 def gen16_head_index(sec_w: int, Cin: int, Cout_ld: int, Cout_valid: int, interleave: bool = False):
-    """[4 waves][rb 0..3][ks 0..7] fragments of a 256 -> 256 head 1x1 stored [Cin, Cout_ld] (rows >= Cout_valid zero);
-    wave w, block rb = rows 64 w + 16 rb, or rows 16 (4 rb + w) with `interleave` (the last 1x1: few outputs still split
-    over the four waves)."""
+    """[4 waves][row blocks][Cin/32 k-steps] fragments of a head 1x1 stored [Cin, Cout_ld] (rows >= Cout_valid zero): the
+    first 1x1 (Cin -> Cin): wave w, block rb < Cin/64 = rows (Cin/4) w + 16 rb; the last one (`interleave`, up to 256
+    outputs): four blocks per wave, rows 16 (4 rb + w) -- few outputs still split over the four waves."""
     import numpy as np
     out = []
+    nrb = 4 if interleave else Cin // 64
     for w in range(4):
-        for rb in range(4):
-            row0 = 16 * (4 * rb + w) if interleave else 64 * w + 16 * rb
-            for ks in range(8):
+        for rb in range(nrb):
+            row0 = 16 * (4 * rb + w) if interleave else 16 * nrb * w + 16 * rb
+            for ks in range(Cin // 32):
                 out.append(frag16_index(sec_w, row0, 32 * ks, 1, Cout_ld, Cout_valid, Cin))
     return np.stack(out)

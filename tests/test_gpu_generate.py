@@ -78,14 +78,16 @@ def test_sampling_follows_the_softmax():
     assert np.abs(freq - p).max() < 0.02
 
 
-@pytest.mark.parametrize("dil,B,T", [([1, 2, 4, 8, 16, 32, 1, 2, 4], 37, 150), ([1, 2, 4, 8, 16, 32, 64, 1], 16, 200),
-                                     ([3], 1, 9), ([1, 2], 70, 5)])
-def test_latency_body_equals_throughput_body(monkeypatch, dil, B, T):
+@pytest.mark.parametrize("dil,B,T,R,S", [([1, 2, 4, 8, 16, 32, 1, 2, 4], 37, 150, 64, 256),
+                                         ([1, 2, 4, 8, 16, 32, 64, 1], 16, 200, 64, 256), ([3], 1, 9, 64, 256),
+                                         ([1, 2], 70, 5, 64, 256), ([1, 2, 4, 8, 16, 32, 1, 2, 4], 37, 150, 32, 128),
+                                         ([1, 2, 4, 8, 1], 19, 120, 32, 256), ([1, 2, 4, 8, 16, 2], 33, 90, 64, 128)])
+def test_latency_body_equals_throughput_body(monkeypatch, dil, B, T, R, S):
     """The bf16 teacher's latency-optimised generator (csrc/srwn_gen16.hip: a layer's channels split over the waves) against
     the throughput kernel (csrc/srwn_gen.hip: every wave runs the whole chain) on the same weights, teacher-forced: the
     same logits up to the accumulation order of the two MFMA shapes; its two workgroup sizes agree bit for bit; odd and
     even stacks, ragged batches, steps before the first delayed tap exists."""
-    eng, sp = _engine(torch.bfloat16, dil, B, T)
+    eng, sp = _engine(torch.bfloat16, dil, B, T, R=R, S=S)
     assert eng.o_g16 is not None
     audio = dev(O.synthetic_audio(B, T, seed=21))
     out = {}
@@ -209,16 +211,18 @@ def test_mol_decoder_incremental_equals_full_forward(dt, tol, B, T, M, E, pool, 
     assert np.abs(a.cpu().numpy()).max() <= 1.0 and int(sel.max()) < M and int(sel.min()) >= 0
 
 
-@pytest.mark.parametrize("B,T,M,E,pool", [(35, 160, 10, 20, 16), (3, 256, 5, 6, 32), (17, 90, 10, 0, 1), (2, 40, 16, 8, 8)])
-def test_mol_latency_body_equals_throughput_body(monkeypatch, B, T, M, E, pool):
+@pytest.mark.parametrize("B,T,M,E,pool,R,S", [(35, 160, 10, 20, 16, 64, 256), (3, 256, 5, 6, 32, 64, 256),
+                                              (17, 90, 10, 0, 1, 64, 256), (2, 40, 16, 8, 8, 64, 256),
+                                              (35, 160, 10, 16, 16, 32, 128), (5, 96, 10, 16, 32, 32, 256)])
+def test_mol_latency_body_equals_throughput_body(monkeypatch, B, T, M, E, pool, R, S):
     """srwn_generate16_mol (channels split over the waves, conditioning bias added in the epilogue of the layer below,
     the last 1x1's row blocks interleaved over the waves, Gumbel-max over 16-lane groups) against srwn_generate_mol on
     the same weights, teacher-forced: logits to the accumulation order, the same mixture and sample wherever the logits
     agree; both workgroup sizes bit for bit."""
     EG = sub("engine")
     dil = [1, 2, 4, 8, 16, 32, 1, 2, 5]
-    sp = O.init_stack_params(7, dil, 2, 64, 256, 4 * M, cond_channels=E, bias_scale=0.05)
-    cfg = EG.StackConfig(dilations=dil, dilation_channels=64, skip_channels=256, output_channels=4 * M, cond_channels=E,
+    sp = O.init_stack_params(7, dil, 2, R, S, 4 * M, cond_channels=E, bias_scale=0.05)
+    cfg = EG.StackConfig(dilations=dil, dilation_channels=R, skip_channels=S, output_channels=4 * M, cond_channels=E,
                          pool_stride=pool if E else 1, shift_input=True, head_mode="mol", dtype=torch.bfloat16)
     eng = EG.WaveNetEngine(cfg, B, T, DEV)
     eng.load_oracle_params(sp)
