@@ -20,6 +20,11 @@ CXX = os.environ.get("CXX", "g++")
 SOURCES = ["srwn_util.hip", "srwn_fwd.hip", "srwn_bwd.hip", "srwn_opt.hip", "srwn_pool.hip", "srwn_gemm.hip", "srwn_wgrad2.hip", "srwn_gen.hip", "srwn_gen16.hip", "srwn_flow.hip", "srwn_enc.hip", "srwn_nc.hip", "srwn_group.hip", "srwn_groupw.hip", "srwn_wgradt.hip", "srwn_ops.hip", "srwn_head.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-pass-failed", "-ffp-contract=on"]
+# Kernels that fetch REGISTER operands with loads the compiler does not see (inline asm, hand-counted waits) must not
+# spill: the compiler takes such a load's destination for written when the statement ends, so under register pressure
+# it may spill or move it while the data is still in flight -- garbage operands, or a wild address once the register has
+# been reused for a pointer (seen on a prototype: HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION).  The build refuses them.
+NO_SPILL = {"srwn_wgradt.hip": ["wgrad_skip_wt_kernel"]}
 
 
 def _deps():
@@ -48,6 +53,26 @@ def _stale(target, srcs):
     return any(os.path.getmtime(s) > t for s in srcs)
 
 
+def _check_no_spill(src, obj, remarks, kernels):
+    """Parses hipcc's kernel-resource-usage remarks: every kernel of `kernels` must report `VGPRs Spill: 0`."""
+    import re
+    seen = {}
+    name = None
+    for line in remarks.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.search(r"VGPRs Spill: (\d+)", line)
+        if m and name:
+            seen[name] = int(m.group(1))
+    for k in kernels:
+        hit = [(n, v) for n, v in seen.items() if k in n]
+        if not hit or any(v for _, v in hit):
+            if os.path.exists(obj):
+                os.remove(obj)
+            raise RuntimeError("%s: kernel %s must not spill registers (untracked register loads): %s" % (src, k, hit or "not found"))
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     objs = [os.path.join(CSRC, os.path.splitext(os.path.basename(s))[0] + ".o") for s in srcs]
@@ -56,12 +81,15 @@ def build(force: bool = False, verbose: bool = False) -> str:
     def cc(pair):
         src, obj = pair
         if force or _stale(obj, [src] + deps):
-            cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+            guarded = NO_SPILL.get(os.path.basename(src), [])
+            cmd = [HIPCC] + FLAGS + (["-Rpass-analysis=kernel-resource-usage"] if guarded else []) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:
                 raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-8000:]))
+            if guarded:
+                _check_no_spill(src, obj, r.stderr, guarded)
         return obj
 
     with ThreadPoolExecutor(max_workers=4) as ex:
