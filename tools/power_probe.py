@@ -25,7 +25,8 @@ work = {
     "group_bwd 1..16": (lambda: eng._group_bwd_wt(g1[0], g1[1])) if eng.fused_wt else (lambda: eng._group_bwd(g1[0], g1[1])),
     "group_bwd 32..512": (lambda: eng._group_bwd_wt(g32[0], g32[1])) if eng.fused_wt else (lambda: eng._group_bwd(g32[0], g32[1])),
     "skip_sum": lambda: KN.pw_linear(eng.zs.data_ptr(), R, N * R, R, L * R, eng.wptr(eng.o_skip), eng.bs_sum, eng.r0, S, S, N, pro=KN.PRO_GATE, epi=KN.EPI_RELU),
-    "wgrad_skip": lambda: KN.wgrad256(eng.zs.data_ptr(), N * R, R, L, eng.dtotal, eng.wg_parts, eng.wg_bparts, N, eng.ns_skip, pro=KN.PRO_GATE, chunk_width=R),
+    "wgrad_skip (from the tiles)": (lambda: KN.wgrad_skip_wt(eng.cTs, eng.wt_layer_st, eng.wt_layer_seg, eng.dtotal, eng.wg_parts, eng.wg_bparts, eng.ns_skip_wt, B, T, R)) if getattr(eng, "skip_wt", False) else (lambda: None),
+    "wgrad_skip (wgrad256 on z)": lambda: KN.wgrad256(eng.zs.data_ptr(), N * R, R, L, eng.dtotal, eng.wg_parts, eng.wg_bparts, N, eng.ns_skip, pro=KN.PRO_GATE, chunk_width=R),
     "colgemm": lambda: KN.skip_dgrad_all(eng.dtotal, eng.wptr(eng.o_skipT_all), eng.dcs.view(L, N, R), R, S),
     "head_chain": lambda: KN.head_chain(eng.r0, eng.wptr(eng.o_w1), eng.wptr(eng.o_w2p), eng.wptr(eng.o_w2Tp), eng.wptr(eng.o_w1Tp), eng.view("head_b1"), eng.view("head_b2"), eng.targets, eng.loss_parts, eng.r1, eng.dlogits, eng.da1, eng.dtotal, eng.C, 1.0 / N),
     "whole step": lambda: eng.train_step(),
