@@ -358,9 +358,9 @@ class WaveNetEngine:
             for l in range(L):
                 P.fill_linear(pk, self.o_skip_gen, sec["WS"].offset + l * R * S, R, S, S // 32, L * R // 16,
                               ks_offset=l * R // 16, ks_count=R // 16, perm=True)
-        # the latency-optimised generator's fragment images (csrc/srwn_gen16.hip): the benchmark's teacher only
+        # the latency-optimised generator's fragment images (csrc/srwn_gen16.hip)
         self.o_g16 = None
-        if (self.o_gen is not None and R in (32, 64) and S in (128, 256) and self.dt == torch.bfloat16
+        if (self.o_gen is not None and R in (32, 64) and S in (128, 256) and self.dt == torch.bfloat16 and L <= 64
                 and ((self.cfg.head_mode == "per_timestep" and not self.E) or self.cfg.head_mode == "mol")):
             self.o_g16 = pk.reserve_raw(np.concatenate([P.gen16_layer_index(sec["WF"].offset, sec["WR"].offset,
                                                                             sec["WS"].offset, l, R, S) for l in range(L)]))
