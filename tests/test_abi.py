@@ -44,6 +44,27 @@ def test_argument_errors_do_not_need_a_gpu():
     assert lib.srwn_residual_layer_fwd(1, None, 1, 1, 1, 1, 1, 1, 2, 64, 64, 2, 1, 1, 1, 64, 7, None) == -1   # dtype
     assert lib.srwn_pw_linear(1, 8, 0, 8, 8, 1, None, 1, 32, 32, 32, 5, None, 0, 0, 0, 1, None) == -2          # Cin % 16
     assert lib.srwn_wgrad(1, 0, 64, 1, 0, 64, None, 0, 1, 1, 64, None, 99, 1, None, 64, 64, 1, 0, 1, None) == -2
+    # the round-3 entry points: the same contract
+    import ctypes as C
+    i32 = lambda *v: (C.c_int32 * len(v))(*v)
+    assert lib.srwn_wgrad_skip_wt(None, 0, None, None, 0, None, 256, None, None, 1, 8, 100, 64, 256, 1, None) == 0    # no layers
+    assert lib.srwn_wgrad_skip_wt(None, 0, i32(1), i32(100), 1, None, 256, None, None, 1, 1, 100, 64, 256, 1, None) == -3
+    assert lib.srwn_wgrad_skip_wt(1, 1 << 20, i32(1), i32(100), 1, 1, 256, 1, None, 1, 1, 100, 64, 256, 0, None) == -4     # fp32: not built
+    assert lib.srwn_wgrad_skip_wt(1, 1 << 20, i32(1), i32(100), 1, 1, 256, 1, None, 1, 1, 100, 32, 128, 1, None) == -4     # widths
+    assert lib.srwn_wgrad_skip_wt(1, 10, i32(1), i32(100), 1, 1, 256, 1, None, 1, 1, 100, 64, 256, 1, None) == -2          # tiles exceed the layer stride
+    assert lib.srwn_wgrad_skip_wt(1, 1 << 20, i32(0), i32(100), 1, 1, 256, 1, None, 1, 1, 100, 64, 256, 1, None) == -2     # stride 0
+    assert lib.srwn_wgrad_skip_wt_slabs(i32(1, 1, 1, 1, 32, 32), i32(500, 500, 500, 500, 500, 500), 6, 16000) >= 1
+    assert lib.srwn_generate16(None, None, None, None, None, None, None, None, None, None, None, None, None, None, None, None,
+                               2, 0, 8, 8, 64, 256, 256, 0, 0, None) == 0                                                  # no utterances
+    assert lib.srwn_generate16(None, None, None, None, None, None, None, None, None, None, None, None, None, None, None, None,
+                               2, 1, 8, 8, 64, 256, 256, 0, 0, None) == -3
+    assert lib.srwn_generate16(1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, None, None, i32(1, 2), 2, 1, 8, 8, 48, 256, 256, 0, 0,
+                               None) == -4                                                                                   # R=48
+    assert lib.srwn_generate16_mol(1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, None, None, i32(1, 2), 2, 1, 8, 8, 64, 256, 17, None,
+                                   1, 1, 0, 0, 0, None) == -2                                                               # 17 mixtures
+    assert lib.srwn_generate16_image_elems(30, 0, 64, 256) == 30 * 4 * 14 * 512 and lib.srwn_generate16_image_elems(30, 0, 48, 256) == 0
+    assert lib.srwn_wgrad_wide_pair(None, None, None, None, None, None, None, None, 64, 256, 4, 64, 256, 256, 0, 4, 0, 1, None) == 0
+    assert lib.srwn_wgrad_wide_pair(1, 1, 1, None, None, 1, 1, None, 64, 256, 4, 64, 256, 256, 100, 4, 0, 1, None) == -3
     with pytest.raises(RuntimeError):
         L.call("srwn_mu_law_decode", None, None, 5, 256, None)
     assert lib.srwn_wgrad_slabs(128000) == 42 and lib.srwn_softmax_ce_partials(100) == 4
