@@ -215,6 +215,13 @@ int srwn_pw_linear(const void* x, int64_t x_row_stride, int64_t x_chunk_stride, 
                    int32_t cout_valid, int64_t rows, const void* aux, int64_t aux_row_stride, int32_t pro,
                    int32_t epi, int32_t dtype, void* stream);
 
+/* the same product (no prologue / epilogue) with its outputs in chunks of y_chunk_len channels: channel n at
+ * y + (n / y_chunk_len)*y_chunk_stride + row*y_row_stride + n % y_chunk_len -- the conditioning biases of all layers
+ * (model.py:180: L*R outputs) stored layer by layer, [L][rows][R], so that a layer's rows are dense. */
+int srwn_pw_linear_ychunks(const void* x, int64_t x_row_stride, int32_t Cin, const void* wpack, const float* bias, void* y,
+                           int64_t y_row_stride, int32_t y_chunk_len, int64_t y_chunk_stride, int32_t cout_pad,
+                           int32_t cout_valid, int64_t rows, int32_t dtype, void* stream);
+
 /* the same product split over the contraction axis (few rows, long K): slice z of nsplit writes its fp32 partial to
  * y_partials + z*rows*y_row_stride (bias in slice 0); srwn_reduce_partials(nslabs = nsplit, n = rows*y_row_stride)
  * finishes it.  Used for the encoder's pooled skip sum (model.py:150: B*frames rows, K = L*encoder_channels). */

@@ -51,6 +51,7 @@ SIGNATURES = {
     "srwn_relu": (C.c_int, [_p, _p, _i64, _p]),
     "srwn_mol_nll_rows": (C.c_int, [_p, _i64, _p, _i32, _p, _i64, _p]),
     "srwn_group_plan": (_i32, [_p, _i32, _i32, _i32, _p]),
+    "srwn_pw_linear_ychunks": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _i64, _i32, _i64, _i32, _i32, _i64, _i32, _p]),
     "srwn_pw_linear": (C.c_int, [_p, _i64, _i64, _i32, _i32, _p, _p, _p, _i64, _i32, _i32, _i64, _p, _i64, _i32,
                                  _i32, _i32, _p]),
     "srwn_pw_linear_ksplit": (C.c_int, [_p, _i64, _i64, _i32, _i32, _p, _p, _p, _i64, _i32, _i32, _i64, _i32, _i32, _p]),

@@ -338,6 +338,20 @@ __global__ __launch_bounds__(64 * NWV) void group_fwd_kernel(GroupFwdArgs a) {
         }
         stamp(14);
         // ---- 1x1 residual from registers, scaled residual add
+        // (the conditioning bias of the layer above is fetched HERE, ahead of the residual MFMAs that hide its latency;
+        // fetched where it is added, every tile of every layer waited a full L2 round trip.
+        // The frame index is a 32-bit division: t < T < 2^31, and a 64-bit one is ~150 instructions per tile.)
+        raw4 cnd[RT][4];
+        bool have_cnd = false;
+        if (COND && cg) {
+          have_cnd = true;
+          const unsigned t = (unsigned)(grow(j) - clip);      // time step of this lane's row (clamped)
+          const T* crow_ = cg + ((size_t)b * a.cond_frames + t / (unsigned)a.pool) * a.cond_stride;
+#pragma unroll
+          for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) cnd[mt][gq] = Raw4g<T>::load(crow_ + 32 * mt + 8 * gq + 4 * half);
+        }
         f32x16 accR[RT];
 #pragma unroll
         for (int mt = 0; mt < RT; ++mt)
@@ -354,20 +368,15 @@ __global__ __launch_bounds__(64 * NWV) void group_fwd_kernel(GroupFwdArgs a) {
         if (STAMP) { asm volatile("" :: "v"(accR[0][0])); stamp(15); }
         {
           float hv[RT][16];
-          const T* crow_ = nullptr;
-          if (COND && cg) {
-            size_t t = grow(j) - clip;                 // time step of this lane's row (clamped)
-            crow_ = cg + ((size_t)b * a.cond_frames + t / a.pool) * a.cond_stride;
-          }
 #pragma unroll
           for (int mt = 0; mt < RT; ++mt)
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-              f32x4 cv = {0.f, 0.f, 0.f, 0.f};
-              if (COND && crow_) cv = load4(crow_ + 32 * mt + 8 * gq + 4 * half);
 #pragma unroll
-              for (int e = 0; e < 4; ++e)
-                hv[mt][4 * gq + e] = (Raw4g<T>::get(xres[mt][gq], e) + accR[mt][4 * gq + e]) * kSqrtHalf + cv[e];
+              for (int e = 0; e < 4; ++e) {
+                const float cv = (COND && have_cnd) ? Raw4g<T>::get(cnd[mt][gq], e) : 0.0f;
+                hv[mt][4 * gq + e] = (Raw4g<T>::get(xres[mt][gq], e) + accR[mt][4 * gq + e]) * kSqrtHalf + cv;   // (one fma, as layer_fwd_kernel)
+              }
             }
           wave_lds_order();               // z row reads (and, without stores, the own-row reads) are done
 #pragma unroll

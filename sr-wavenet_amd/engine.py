@@ -444,7 +444,7 @@ class WaveNetEngine:
         self.ic_ws = z(int(_lib.load().srwn_init_conv_wgrad_partials(B, T, R, self.Kw)), dt=torch.float32)
         if self.E:
             self.cond_in = z(B * self.frames, self.Ep)
-            self.cond_all = z(B * self.frames, L * R)      # cb of every layer, [B*frames, L*R]
+            self.cond_all = z(L, B * self.frames, R)      # cb of every layer, layer by layer: a layer's frame rows are dense
             self.dcb = z(L, B * self.frames, R)
             self.nslabs_c = K.wgrad_slabs(B * self.frames)
             self.wgc_parts = z(self.nslabs_c * L * self.Ep * R, dt=torch.float32)
@@ -583,10 +583,13 @@ class WaveNetEngine:
         xs[l] always holds layer l's complete input, so taps, residual base and weight gradients never re-add it."""
         from ._lib import call
         L, R = self.L, self.R
-        K.pw_linear(self.cond_in.data_ptr(), self.Ep, 0, self.Ep, self.Ep, self.wptr(self.o_wc),
-                    self.view("BC").reshape(-1), self.cond_all, L * R, L * R, self.B * self.frames)
-        call("srwn_add_frame_bias", self.xs[0].data_ptr(), self.cond_all.data_ptr(), L * R, self.B, self.T, R,
-             self.frames, self.cfg.pool_stride, K.abi_dtype(self.dt), torch.cuda.current_stream().cuda_stream)
+        rows_c = self.B * self.frames
+        st = torch.cuda.current_stream().cuda_stream
+        call("srwn_pw_linear_ychunks", self.cond_in.data_ptr(), self.Ep, self.Ep, self.wptr(self.o_wc),
+             self.view("BC").reshape(-1).data_ptr(), self.cond_all.data_ptr(), R, R, rows_c * R, L * R, L * R, rows_c,
+             K.abi_dtype(self.dt), st)
+        call("srwn_add_frame_bias", self.xs[0].data_ptr(), self.cond_all.data_ptr(), R, self.B, self.T, R,
+             self.frames, self.cfg.pool_stride, K.abi_dtype(self.dt), st)
 
     def _stack_fwd(self, cond_all: Optional[torch.Tensor]):
         """The residual layers (model.py:42-47 / 176-189 / 428-453): xs[0] -> xs[1..L], zs[0..L-1]."""
@@ -598,15 +601,14 @@ class WaveNetEngine:
                     self._layer_fwd(l0, cond_all)
         else:
             for l in range(self.L):
-                self._layer_fwd(l, cond_all)   # layer l reads columns [l*R, (l+1)*R)
+                self._layer_fwd(l, cond_all)
 
     def _group_fwd(self, l0: int, l1: int, cond_all: Optional[torch.Tensor]):
         """Layers [l0, l1) in one launch (srwn_residual_group_fwd); same stored xs / zs as the per-layer path."""
         v = self.view
-        offs, cond3 = None, None
-        if cond_all is not None:
-            cond3 = cond_all.view(self.B, self.frames, self.L * self.R)
-            offs = [(l + 1) * self.R if l + 1 < self.L else None for l in range(l0, l1)]
+        cond3 = None
+        if cond_all is not None:      # layer l adds the bias of layer l + 1 onto its output
+            cond3 = [cond_all[l + 1].view(self.B, self.frames, self.R) if l + 1 < self.L else None for l in range(l0, l1)]
         wt = {}
         if self.fused_wt:
             # (xs of the layers inside a group is NOT written in this mode: only the weight gradients would read it, and they
@@ -616,17 +618,16 @@ class WaveNetEngine:
                              [self.wptr(self.o_conv[l]) for l in range(l0, l1)],
                              [self.wptr(self.o_res[l]) for l in range(l0, l1)],
                              [v("BF")[l] for l in range(l0, l1)], [v("BR")[l] for l in range(l0, l1)],
-                             self.dil[l0:l1], self.Kw, cond=cond3, cond_channel_offsets=offs,
+                             self.dil[l0:l1], self.Kw, cond=cond3,
                              pool_stride=self.cfg.pool_stride,
                              seg_rows=self.wt_seg_rows[self.groups.index((l0, l1))] if self.fused_wt else self.seg_rows, **wt)
 
     def _layer_fwd(self, l: int, cond_all: Optional[torch.Tensor]):
         v = self.view
         nxt = cond_all is not None and l + 1 < self.L      # the NEXT layer's conditioning bias goes onto the output
-        cond3 = cond_all.view(self.B, self.frames, self.L * self.R) if nxt else None
+        cond3 = cond_all[l + 1].view(self.B, self.frames, self.R) if nxt else None
         K.residual_layer_fwd(self.xs[l], cond3, self.wptr(self.o_conv[l]), self.wptr(self.o_res[l]), v("BF")[l],
-                             v("BR")[l], self.xs[l + 1], self.zs[l], self.Kw, self.dil[l], self.cfg.pool_stride,
-                             cond_channel_offset=(l + 1) * self.R if nxt else 0)
+                             v("BR")[l], self.xs[l + 1], self.zs[l], self.Kw, self.dil[l], self.cfg.pool_stride)
 
     # ------------------------------------------------------------------------------------------
     # backward

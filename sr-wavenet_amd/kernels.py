@@ -212,7 +212,8 @@ def residual_group_fwd(x0: torch.Tensor, x_out: torch.Tensor, z_out: torch.Tenso
                        cond_channel_offsets=None, pool_stride: int = 1, seg_rows: int = 0,
                        xT: Optional[torch.Tensor] = None, cT: Optional[torch.Tensor] = None, store_inner_x: bool = True):
     """x_out / z_out: [n,B,T,R] stacks (views of the engine's xs[l0+1:], zs[l0:]); cond: [B, frames, C] whose channels
-    [cond_channel_offsets[g], +R) hold the bias of the layer above layer g (None entries: no add).
+    [cond_channel_offsets[g], +R) hold the bias of the layer above layer g (None entries: no add), or a list of n
+    [B, frames, R] tensors / None, one per layer (the layer-by-layer layout: dense rows).
     xT / cT ([>=n, elems] each, `group_wt_geometry`): also write the layers' weight-gradient tiles (seg_rows from the same
     geometry call); store_inner_x = False: only the group's top layer stores its output rows."""
     import ctypes as C
@@ -229,7 +230,22 @@ def residual_group_fwd(x0: torch.Tensor, x_out: torch.Tensor, z_out: torch.Tenso
     pbf = [_chk(b, "bias_f", torch.float32, (R,)) for b in biases_f]
     pbr = [_chk(b, "bias_r", torch.float32, (R,)) for b in biases_r]
     frames, cstride, pcs = 1, R, None
-    if cond is not None:
+    if isinstance(cond, (list, tuple)):
+        if len(cond) != n:
+            raise ValueError("cond: %d per-layer tensors for %d layers" % (len(cond), n))
+        ptrs = []
+        for c in cond:
+            if c is None:
+                ptrs.append(None)
+                continue
+            _chk(c, "cond", x0.dtype)
+            if c.dim() != 3 or c.shape[0] != B or c.shape[2] != R or c.shape[1] * pool_stride < T or (
+                    ptrs and frames != c.shape[1] and any(p is not None for p in ptrs)):
+                raise ValueError("cond: shape %s for B=%d T=%d R=%d pool=%d" % (tuple(c.shape), B, T, R, pool_stride))
+            frames = c.shape[1]
+            ptrs.append(c.data_ptr())
+        pcs = _ptr_array(ptrs) if any(p is not None for p in ptrs) else None
+    elif cond is not None:
         _chk(cond, "cond", x0.dtype)
         frames, cstride = cond.shape[1], cond.shape[2]
         if cond.dim() != 3 or cond.shape[0] != B or frames * pool_stride < T:
