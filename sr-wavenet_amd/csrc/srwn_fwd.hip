@@ -509,7 +509,11 @@ extern "C" int srwn_pw_linear_ychunks(const void* x, int64_t x_row_stride, int32
 
 static int pw_dispatch(const PwArgs& a, int cout_pad, int pro, int epi, int dtype, hipStream_t st) {
   const int tiles = cout_pad / 32;
+  // few rows (the conditioning product: B*frames = 1 024 rows, K = 16): one row tile per wave, or the launch is 60
+  // workgroups of 128 stores per lane -- 19 us for 63 MFLOP
+  const bool few = ((a.rows + 255) / 256) * (tiles / 4) < 128;
   if (dtype == SRWN_BF16) {
+    if (few) return launch_pw<bf16_t, 1, 2>(a, cout_pad, pro, epi, st);
     if (tiles % 4 == 0) return launch_pw<bf16_t, 4, 2>(a, cout_pad, pro, epi, st);
     if (tiles % 2 == 0) return launch_pw<bf16_t, 2, 2>(a, cout_pad, pro, epi, st);
     return launch_pw<bf16_t, 1, 2>(a, cout_pad, pro, epi, st);

@@ -212,7 +212,8 @@ class EncoderStack:
         self.ds_mean = z(self.rows_c, S)
         self.da_all = f(self.rows_c, L * EC)
         self.nslabs = K.wgrad_slabs(N)
-        self.nslabs_c = K.wgrad_slabs(self.rows_c)
+        # (few frame rows: 128-row slabs, or the skip 1x1 gradients are L workgroups walking them in 32-row steps: 139 us)
+        self.nslabs_c = max(K.wgrad_slabs(self.rows_c), min(max(1, 256 // max(L, 1)), max(1, self.rows_c // 128)))
         self.wg_parts = f(max(self.nslabs * EC * EC, self.nslabs_c * L * EC * S))
         self.wg_bparts = f(max(self.nslabs * EC, self.nslabs_c * L * S))
         # fused per-layer weight-gradient pass: about two 8-wave workgroups per CU over (slab, layer)

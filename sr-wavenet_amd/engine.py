@@ -446,7 +446,10 @@ class WaveNetEngine:
             self.cond_in = z(B * self.frames, self.Ep)
             self.cond_all = z(L, B * self.frames, R)      # cb of every layer, layer by layer: a layer's frame rows are dense
             self.dcb = z(L, B * self.frames, R)
-            self.nslabs_c = K.wgrad_slabs(B * self.frames)
+            # (few rows: one slab would be L workgroups walking B*frames rows in 32-row steps -- 69 us for 31 MFLOP at
+            # 1 024 rows; 128-row slabs fill the chip)
+            rows_c = B * self.frames
+            self.nslabs_c = max(K.wgrad_slabs(rows_c), min(max(1, 256 // L), max(1, rows_c // 128)))
             self.wgc_parts = z(self.nslabs_c * L * self.Ep * R, dt=torch.float32)
             self.wgc_bparts = z(self.nslabs_c * L * R, dt=torch.float32)
             self.wc_grad_pad = z(L, self.Ep, R, dt=torch.float32)
