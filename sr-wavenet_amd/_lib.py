@@ -1,4 +1,9 @@
-"""ctypes binding of libsrwn.so (the C-ABI declared in include/srwn.h).
+"""Python binding of libsrwn.so (the C-ABI declared in include/srwn.h).
+
+Two interchangeable bindings of the SAME library and symbol table: the pybind11 module ``_srwn_pyb`` that build.py
+generates from SIGNATURES and compiles against the header's prototypes (default: the binding north_star names), and
+plain ctypes (``SRWN_BINDING=ctypes``).  Callers pass the same arguments to either -- integers for device pointers,
+None for null, ctypes arrays / byref() for the few host arrays.
 
 The product path has NO fallback: if the HIP library is missing or a symbol is absent the import
 fails loudly, and every call raises RuntimeError on a non-zero return code.
@@ -129,25 +134,84 @@ SIGNATURES = {
 }
 
 _lib = None
+BINDING = None      # "pybind11" or "ctypes" once loaded
 
 
-def load():
-    """Loads libsrwn.so once and binds every symbol; raises if anything is missing."""
-    global _lib
-    if _lib is not None:
-        return _lib
+def signature_hash() -> str:
+    """Identifies the symbol table a pybind11 module was generated from (compiled into it as SIGNATURE_HASH)."""
+    import hashlib
+    txt = ";".join("%s:%s:%s" % (n, r.__name__, ",".join(a.__name__ for a in args)) for n, (r, args) in SIGNATURES.items())
+    return hashlib.sha256(txt.encode()).hexdigest()[:16]
+
+
+def _address(a):
+    """What the pybind11 functions take for an argument the ctypes binding would have converted itself."""
+    if a is None:
+        return 0
+    if isinstance(a, (int, float)):
+        return a
+    if isinstance(a, C.Array):
+        return C.addressof(a)
+    if isinstance(a, C._SimpleCData):            # c_void_p(...) and friends
+        return a.value or 0
+    if hasattr(a, "_obj"):                       # ctypes.byref(x)
+        return C.addressof(a._obj)
+    raise TypeError("cannot pass %r through the C-ABI" % (a,))
+
+
+class _PybindLib:
+    """The pybind11 module behind the attribute interface of a ctypes library (lib.srwn_xxx(args))."""
+
+    def __init__(self, mod, keepalive):
+        self._keepalive = keepalive
+        for name in SIGNATURES:
+            fn = getattr(mod, name)              # AttributeError if the symbol is missing
+            setattr(self, name, (lambda f: lambda *args: f(*[_address(a) for a in args]))(fn))
+
+
+def pybind_path() -> str:
+    import sysconfig
+    return os.path.join(HERE, "_srwn_pyb" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def bind(kind: str):
+    """A fresh binding of libsrwn.so of the given kind ("pybind11" / "ctypes"); load() caches the default one."""
+    if kind not in ("pybind11", "ctypes"):
+        raise RuntimeError("SRWN_BINDING=%s: pybind11 or ctypes" % kind)
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             "libsrwn.so not found at %s: build it with `python sr-wavenet_amd/build.py` "
             "(there is no CPU fallback for the product path)" % LIB_PATH)
     _check_manifest()
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    if kind == "pybind11":
+        path = pybind_path()
+        if not os.path.exists(path):
+            raise RuntimeError("pybind11 module %s not built: run `python sr-wavenet_amd/build.py` "
+                               "(or SRWN_BINDING=ctypes for the ctypes binding of the same library)" % path)
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("_srwn_pyb", path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        if mod.SIGNATURE_HASH != signature_hash():
+            raise RuntimeError("the pybind11 module was generated from a different symbol table: rebuild with "
+                               "`python sr-wavenet_amd/build.py`")
+        return _PybindLib(mod, lib)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
     return lib
+
+
+def load():
+    """Loads libsrwn.so once and binds every symbol (SRWN_BINDING: pybind11, the default, or ctypes); raises if anything
+    is missing."""
+    global _lib, BINDING
+    if _lib is None:
+        kind = os.environ.get("SRWN_BINDING", "pybind11")
+        _lib, BINDING = bind(kind), kind
+    return _lib
 
 
 def _check_manifest():

@@ -15,6 +15,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsrwn.so")
 MANIFEST = os.path.join(HERE, "libsrwn.manifest.json")   # sha256 of every source the library was built from
 IO_LIB = os.path.join(HERE, "libsrwn_io.so")     # host-only data path (TFRecord reader), plain g++
+PYB_SRC = os.path.join(CSRC, "srwn_pybind.cpp")   # generated from _lib.SIGNATURES (the table tests/test_abi.py holds to srwn.h)
+PYB_NAME = "_srwn_pyb"
 IO_SOURCES = ["srwn_tfrecord.cpp"]
 CXX = os.environ.get("CXX", "g++")
 SOURCES = ["srwn_util.hip", "srwn_fwd.hip", "srwn_bwd.hip", "srwn_opt.hip", "srwn_pool.hip", "srwn_gemm.hip", "srwn_wgrad2.hip", "srwn_gen.hip", "srwn_gen16.hip", "srwn_flow.hip", "srwn_enc.hip", "srwn_nc.hip", "srwn_group.hip", "srwn_groupw.hip", "srwn_wgradt.hip", "srwn_ops.hip", "srwn_head.hip"]
@@ -100,10 +102,71 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s" % r.stderr[-8000:])
     build_io(force)
+    build_pybind(force)
     import json
     with open(MANIFEST, "w") as f:      # which sources this library came from: _lib.load() refuses a stale one
         json.dump({"flags": FLAGS, "sources": source_hashes()}, f, indent=1, sort_keys=True)
     return LIB
+
+
+def _signatures():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_srwn_lib_for_build", os.path.join(HERE, "_lib.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def pybind_source() -> str:
+    """The pybind11 module over the C-ABI: one function per entry point of include/srwn.h, with the argument list of
+    _lib.SIGNATURES -- pointers travel as integers (device pointers are integers on the Python side anyway), everything
+    else as the header's scalar types.  The calls go through the header's prototypes, so a table entry whose argument
+    count or scalar kinds disagree with srwn.h does not compile."""
+    import ctypes as C
+    L = _signatures()
+    kinds = {C.c_void_p: ("std::uintptr_t", "P{%s}"), C.c_int32: ("int32_t", "%s"), C.c_int64: ("int64_t", "%s"),
+             C.c_float: ("float", "%s"), C.c_uint64: ("uint64_t", "%s"), C.c_int: ("int", "%s")}
+    out = ["// GENERATED by sr-wavenet_amd/build.py (pybind_source) from _lib.SIGNATURES -- do not edit.",
+           "// The thin pybind11 module over the C-ABI of include/srwn.h: pointers as integers, scalars as declared.",
+           "#include <pybind11/pybind11.h>", "#include <cstdint>", '#include "../../include/srwn.h"', "namespace py = pybind11;",
+           "namespace {", "struct P {   // an address, convertible to whatever pointer type the prototype asks for",
+           "  std::uintptr_t v;", "  template <class T> operator T*() const { return reinterpret_cast<T*>(v); }", "};",
+           "}  // namespace", "", "PYBIND11_MODULE(%s, m) {" % PYB_NAME,
+           '  m.doc() = "pybind11 binding of libsrwn.so (include/srwn.h)";',
+           '  m.attr("SIGNATURE_HASH") = "%s";' % L.signature_hash()]
+    for name, (res, args) in L.SIGNATURES.items():
+        params = ", ".join("%s a%d" % (kinds[t][0], i) for i, t in enumerate(args))
+        passed = ", ".join(kinds[t][1] % ("a%d" % i) for i, t in enumerate(args))
+        if res is C.c_char_p:
+            body = "const char* r = %s(%s); return py::bytes(r ? r : \"\");" % (name, passed)
+        else:
+            body = "return %s(%s);" % (name, passed)
+        out.append('  m.def("%s", [](%s) { %s });' % (name, params, body))
+    out.append("}")
+    return "\n".join(out) + "\n"
+
+
+def pybind_path() -> str:
+    import sysconfig
+    return os.path.join(HERE, PYB_NAME + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build_pybind(force: bool = False) -> str:
+    """The pybind11 module (the binding north_star names): g++, linked against libsrwn.so next to it ($ORIGIN rpath)."""
+    import sysconfig
+    import pybind11
+    src = pybind_source()
+    if not os.path.exists(PYB_SRC) or open(PYB_SRC).read() != src:
+        with open(PYB_SRC, "w") as f:
+            f.write(src)
+    target = pybind_path()
+    if force or _stale(target, [PYB_SRC, LIB, os.path.join(HERE, "..", "include", "srwn.h")]):
+        cmd = [CXX, "-O1", "-fPIC", "-shared", "-std=c++17", "-fvisibility=hidden", "-I", pybind11.get_include(),
+               "-I", sysconfig.get_paths()["include"], PYB_SRC, "-o", target, "-L", HERE, "-lsrwn", "-Wl,-rpath,$ORIGIN"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("g++ failed for the pybind11 module:\n%s" % r.stderr[-8000:])
+    return target
 
 
 def build_io(force: bool = False) -> str:

@@ -30,9 +30,30 @@ def test_library_exports_every_declared_symbol():
     assert lib.srwn_version() >= 100
 
 
-def test_argument_errors_do_not_need_a_gpu():
+def test_pybind11_module_is_the_default_binding():
+    """The binding north_star names: a pybind11 module generated from the signature table, compiled against the prototypes
+    of include/srwn.h, exporting every entry point; ctypes binds the same library on request."""
     L = sub("_lib")
     lib = L.load()
+    assert L.BINDING == os.environ.get("SRWN_BINDING", "pybind11")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_srwn_pyb", L.pybind_path())
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    assert mod.SIGNATURE_HASH == L.signature_hash()
+    for n in _declared():
+        assert callable(getattr(mod, n)), n
+    assert mod.srwn_version() == L.bind("ctypes").srwn_version() == lib.srwn_version()
+    src = open(os.path.join(ROOT, "sr-wavenet_amd", "csrc", "srwn_pybind.cpp")).read()
+    import importlib.util as iu
+    bspec = iu.spec_from_file_location("b", os.path.join(ROOT, "sr-wavenet_amd", "build.py"))
+    b = iu.module_from_spec(bspec); bspec.loader.exec_module(b)
+    assert src == b.pybind_source(), "csrc/srwn_pybind.cpp is not what build.py generates from _lib.SIGNATURES"
+
+
+@pytest.mark.parametrize("binding", ["pybind11", "ctypes"])
+def test_argument_errors_do_not_need_a_gpu(binding):
+    L = sub("_lib")
+    lib = L.bind(binding)
     # empty work returns 0 before any launch
     assert lib.srwn_mu_law_encode(None, None, 0, 256, None) == 0
     assert lib.srwn_pw_linear(None, 0, 0, 16, 16, None, None, None, 0, 32, 32, 0, None, 0, 0, 0, 1, None) == 0
@@ -65,6 +86,10 @@ def test_argument_errors_do_not_need_a_gpu():
     assert lib.srwn_generate16_image_elems(30, 0, 64, 256) == 30 * 4 * 14 * 512 and lib.srwn_generate16_image_elems(30, 0, 48, 256) == 0
     assert lib.srwn_wgrad_wide_pair(None, None, None, None, None, None, None, None, 64, 256, 4, 64, 256, 256, 0, 4, 0, 1, None) == 0
     assert lib.srwn_wgrad_wide_pair(1, 1, 1, None, None, 1, 1, None, 64, 256, 4, 64, 256, 256, 100, 4, 0, 1, None) == -3
+    import ctypes
+    out = [ctypes.c_int32() for _ in range(2)] + [ctypes.c_int64()] + [ctypes.c_int32()]      # byref() through either binding
+    assert lib.srwn_group_wt_geometry(i32(1, 2, 4, 8, 16), 5, 8, 16000, 64, 1, 0, *[ctypes.byref(o) for o in out]) == 0
+    assert out[0].value == 500 and out[3].value == 256
     with pytest.raises(RuntimeError):
         L.call("srwn_mu_law_decode", None, None, 5, 256, None)
     assert lib.srwn_wgrad_slabs(128000) == 42 and lib.srwn_softmax_ce_partials(100) == 4
