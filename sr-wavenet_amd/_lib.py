@@ -11,6 +11,7 @@ fails loudly, and every call raises RuntimeError on a non-zero return code.
 from __future__ import annotations
 
 import ctypes as C
+import numbers
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -150,6 +151,10 @@ def _address(a):
         return 0
     if isinstance(a, (int, float)):
         return a
+    if isinstance(a, numbers.Integral):          # numpy integers
+        return int(a)
+    if isinstance(a, numbers.Real):
+        return float(a)
     if isinstance(a, C.Array):
         return C.addressof(a)
     if isinstance(a, C._SimpleCData):            # c_void_p(...) and friends
