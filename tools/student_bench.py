@@ -16,6 +16,7 @@ ap.add_argument("--flows", type=int, default=4)
 ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--length", type=int, default=16000)
 ap.add_argument("--graph", type=int, default=1)
+ap.add_argument("--trace", type=int, default=0, help="print the losses every N steps (a synchronisation each: not for timing)")
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--phases", type=int, default=0, help="time teacher fwd / flows fwd / losses / backward / update eagerly")
 a = ap.parse_args()
@@ -47,8 +48,12 @@ for _ in range(2):
     step()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-for _ in range(a.steps):
+for i in range(a.steps):
     step()
+    if a.trace and (i % a.trace == 0 or i == a.steps - 1):
+        l = stu.losses()
+        print("step %4d  loss %.6g  entropy %.6g  power %.6g  finite params %s" % (
+            i, l["loss"], l["entropy"], l["power_loss"], all(bool(torch.isfinite(f.params).all()) for f in stu.flows)), flush=True)
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / a.steps * 1e3
 l = stu.losses()
