@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras"
+B="python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --no-graph-launch-timing"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -- $B --no-extras > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- $B --graph 0 --steps 3 --warmup 1 > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- $B --graph 0 --steps 3 --warmup 1 > $OUT/write.log 2>&1
