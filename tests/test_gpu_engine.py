@@ -335,3 +335,20 @@ def test_stack_degenerate_clip_lengths(B, T, R, S):
     _check_grads(eng, grads, 1e-3)
     for name, big, n in guards:
         assert bool((big[:pad] == 12345.0).all()) and bool((big[pad + n:] == 12345.0).all()), name
+
+
+@pytest.mark.gpu
+def test_ctypes_binding_runs_the_same_smoke_step():
+    """The suite runs on the pybind11 binding (the default); the ctypes binding of the same library takes the same
+    arguments: __graft_entry__.smoke() -- a forward against the oracle and three training steps -- in a child process
+    with SRWN_BINDING=ctypes."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SRWN_BINDING="ctypes")
+    code = ("import importlib, __graft_entry__ as g; g.smoke(); "
+            "L = importlib.import_module('sr-wavenet_amd._lib'); assert L.BINDING == 'ctypes', L.BINDING; print('binding', L.BINDING)")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "smoke ok" in r.stdout and "binding ctypes" in r.stdout
