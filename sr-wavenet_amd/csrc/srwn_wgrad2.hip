@@ -855,11 +855,7 @@ __global__ __launch_bounds__(512) void wgrad_nc_kernel(WgNcArgs a) {
     }
   };
 
-  if (nit > 0) { gload(0); lstore(0); }
-  __syncthreads();
-  for (int it = 0; it < nit; ++it) {
-    const int buf = (NB == 2) ? (it & 1) : 0;
-    if (it + 1 < nit) gload(it + 1);
+  auto multiply = [&](int buf) {
     const T* ta = tileA(buf); const T* td = tileD(buf);
     if (tid < 2 * C) {
 #pragma unroll 8
@@ -875,10 +871,78 @@ __global__ __launch_bounds__(512) void wgrad_nc_kernel(WgNcArgs a) {
       for (int n = 0; n < 2; ++n)
         mma(accR[n], a_res, Ld2<T>::load(td, LD, 16 * ks, C + 32 * (2 * (wave & 1) + n), lane));
     }
-    if (NB == 1) __syncthreads();   // every wave is done reading the only buffer
-    if (it + 1 < nit) lstore((NB == 2) ? (buf ^ 1) : 0);
+  };
+  if constexpr (sizeof(T) == 2) {
+    // bf16: a ring of three register sets -- chunk it+4 is requested while chunk it is multiplied, three steps before it
+    // moves to LDS (as wgrad_layer_kernel / wgrad256_kernel).  With one chunk (40 KB) in flight per workgroup and an HBM
+    // round trip of ~2 us the pass streamed its 3.9 GB at 4.2 TB/s.  The loads are unconditional (rows clamped into the
+    // tensors, zeroed on their way to LDS) so that hipcc counts them.
+    struct Ring { f32x4 r0[NV], r1[NV], av[NV], pv[NV], hv[NV]; };
+    auto rows_of = [&](int it, int v, int64_t& row, bool& okr, bool& ok1, int& rr, int& cv) {
+      const int idx = tid + v * 512;
+      rr = idx / VPC; cv = (idx % VPC) * VEC;
+      row = r_begin + (int64_t)it * KR + rr;
+      okr = row < r_end;
+      const int64_t rowc = okr ? row : (a.rows - 1);
+      ok1 = okr && ((int)(rowc % a.Tlen) + 1 < a.Tlen);       // tap t+1 stays inside the clip
+      row = rowc;
+    };
+    auto rload = [&](int it, Ring& q) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        int64_t rowc; bool okr, ok1; int rr, cv;
+        rows_of(it, v, rowc, okr, ok1, rr, cv);
+        q.r0[v] = *reinterpret_cast<const f32x4*>(rb + rowc * C + cv);
+        q.r1[v] = *reinterpret_cast<const f32x4*>(rb + (ok1 ? rowc + 1 : rowc) * C + cv);
+        q.av[v] = *reinterpret_cast<const f32x4*>(ab + rowc * C + cv);
+        q.pv[v] = *reinterpret_cast<const f32x4*>(pb + rowc * C + cv);
+        q.hv[v] = *reinterpret_cast<const f32x4*>(hb + rowc * C + cv);
+      }
+    };
+    auto rstore = [&](int it, const Ring& q) {
+      T* ta = tileA(it & 1); T* td = tileD(it & 1);
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        int64_t rowc; bool okr, ok1; int rr, cv;
+        rows_of(it, v, rowc, okr, ok1, rr, cv);
+        *reinterpret_cast<f32x4*>(ta + rr * LA + cv) = okr ? q.r0[v] : zero;
+        *reinterpret_cast<f32x4*>(ta + rr * LA + C + cv) = ok1 ? q.r1[v] : zero;
+        *reinterpret_cast<f32x4*>(ta + rr * LA + 2 * C + cv) = okr ? q.av[v] : zero;
+        *reinterpret_cast<f32x4*>(td + rr * LD + cv) = okr ? q.pv[v] : zero;
+        *reinterpret_cast<f32x4*>(td + rr * LD + C + cv) = okr ? q.hv[v] : zero;
+      }
+    };
+    Ring q0, q1, q2;            // chunk c waits in set c % 3
+    rload(0, q0);
+    rload(1, q1);
+    rload(2, q2);
+    if (nit > 0) rstore(0, q0);
+    rload(3, q0);
     __syncthreads();
+    auto step = [&](int it, Ring& nxt) {
+      if (it < nit) multiply(it & 1);
+      if (it + 1 < nit) rstore(it + 1, nxt);
+      rload(it + 4, nxt);
+      __syncthreads();
+    };
+    for (int it = 0; it < nit; it += 3) {
+      step(it, q1);
+      step(it + 1, q2);
+      step(it + 2, q0);
+    }
+  } else {
+    if (nit > 0) { gload(0); lstore(0); }
+    __syncthreads();
+    for (int it = 0; it < nit; ++it) {
+      if (it + 1 < nit) gload(it + 1);
+      multiply(0);
+      __syncthreads();   // every wave is done reading the only buffer
+      if (it + 1 < nit) lstore(0);
+      __syncthreads();
+    }
   }
+
 
   const int col = lane & 31, half = lane >> 5;
   const int64_t ls = (int64_t)layer * a.nslabs + slab;
