@@ -16,6 +16,10 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libsrwn.so")
+# A/B measurements of kernel variants on one box: another build of the same library (ctypes binding, no manifest check)
+_ALT_LIB = os.environ.get("SRWN_LIB_PATH")
+if _ALT_LIB:
+    LIB_PATH = _ALT_LIB
 
 F32, BF16 = 0, 1
 PRO_NONE, PRO_GATE = 0, 1
@@ -187,7 +191,10 @@ def bind(kind: str):
         raise RuntimeError(
             "libsrwn.so not found at %s: build it with `python sr-wavenet_amd/build.py` "
             "(there is no CPU fallback for the product path)" % LIB_PATH)
-    _check_manifest()
+    if _ALT_LIB:
+        kind = "ctypes"
+    else:
+        _check_manifest()
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     if kind == "pybind11":
         path = pybind_path()
@@ -214,7 +221,7 @@ def load():
     is missing."""
     global _lib, BINDING
     if _lib is None:
-        kind = os.environ.get("SRWN_BINDING", "pybind11")
+        kind = "ctypes" if _ALT_LIB else os.environ.get("SRWN_BINDING", "pybind11")
         _lib, BINDING = bind(kind), kind
     return _lib
 
