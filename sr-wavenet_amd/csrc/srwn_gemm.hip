@@ -28,6 +28,16 @@ struct RgArgs {
   // frame_add (fp32 [clips*frames, frame_add_ld]) * frame_add_scale is added per row before the epilogue
   int tap_T; int tap_step; const float* frame_add; int64_t frame_add_ld; int frames; int pool; float frame_add_scale;
   int safe_wait;   // SRWN_SAFE_WAIT: vmcnt(0) instead of the counted wait
+  unsigned long long* stamps;   // diagnostic instantiation only (srwn_debug_stamp_buffer): waves 0 and 4 of workgroup 0
+};
+
+// In-kernel time stamps (as in srwn_group.hip / srwn_head.hip): lane 0 of waves 0 and 4 of workgroup 0 -- the two waves of
+// SIMD 0 -- 512 entries each (tools/rg_stamps.py).
+template <bool STAMP> struct RgStamper {
+  unsigned long long* p; int n;
+  __device__ __forceinline__ void operator()(int tag) {
+    if (STAMP && p && n < 512) { p[n] = ((unsigned long long)tag << 48) | (__builtin_amdgcn_s_memtime() & 0xffffffffffffull); ++n; }
+  }
 };
 
 template <typename T> __device__ __forceinline__ void glds16(const void* g, void* l) {
@@ -51,9 +61,12 @@ __device__ __forceinline__ void glds16_untracked(const void* g, unsigned lds_add
 // The softmax head and the NT = 2 experiment need more than 256 registers (one wave per SIMD): four waves there.
 constexpr int rg_waves(int epi, int nt) { return (epi == SRWN_EPI_SOFTMAX_CE || nt == 2) ? 4 : 8; }
 
-template <typename T, int MT, int KSC, int PRO, int EPI, int NT, bool TAPS = false>
+template <typename T, int MT, int KSC, int PRO, int EPI, int NT, bool TAPS = false, bool STAMP = false>
 __global__ __launch_bounds__(64 * rg_waves(EPI, NT), (EPI == SRWN_EPI_SOFTMAX_CE || NT == 2) ? 1 : 2) void rowgemm_kernel(RgArgs a) {
   constexpr int kRgWaves = rg_waves(EPI, NT);
+  RgStamper<STAMP> stamp{nullptr, 0};
+  if (STAMP && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) & 3) == 0) stamp.p = a.stamps + (threadIdx.x >> 8) * 512;
+  stamp(1);
   static_assert(MT % 2 == 0, "outputs are emitted in 64-channel groups");
   static_assert(EPI != SRWN_EPI_SOFTMAX_CE || NT == 1, "softmax epilogue holds one column tile");
   constexpr int FB = sizeof(Frag<T>) * 64;          // bytes of one fragment image (1 KiB bf16, 2 KiB f32)
@@ -138,6 +151,7 @@ __global__ __launch_bounds__(64 * rg_waves(EPI, NT), (EPI == SRWN_EPI_SOFTMAX_CE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   auto chunk = [&](int c, Frag<T> (&bthis)[NT][KSC], bool (&okthis)[NT][KSC]) {
+    stamp(10);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -149,8 +163,10 @@ __global__ __launch_bounds__(64 * rg_waves(EPI, NT), (EPI == SRWN_EPI_SOFTMAX_CE
           for (int j = 0; j < 8; ++j) bcur[nt][ks].set(j, gate_of_z<T>(bcur[nt][ks].get(j)));
         }
       }
+    if (STAMP) { asm volatile("" :: "v"(bcur[0][0].get(0)), "v"(bcur[0][KSC - 1].get(7))); stamp(11); }   // activations arrived, first gate values
     if (c + 1 < nchunks) stage(c + 1, (c + 1) & 1);
     load_b(c + 2 < nchunks ? c + 2 : nchunks - 1, bthis, okthis);   // (past the end: a re-fetch that keeps the count fixed)
+    stamp(12);
     const Frag<T>* lw = reinterpret_cast<const Frag<T>*>(smem + (c & 1) * CHUNK_B) + lane;
     // weight fragments one k-step ahead in registers: left to itself hipcc emits ds_read -> s_waitcnt lgkmcnt(0) ->
     // v_mfma per fragment, i.e. one exposed LDS round trip per 32-cycle MFMA; the sched barriers keep the next
@@ -184,9 +200,12 @@ __global__ __launch_bounds__(64 * rg_waves(EPI, NT), (EPI == SRWN_EPI_SOFTMAX_CE
           for (int nt = 0; nt < NT; ++nt) mma(acc[mt][nt], af, bcur[nt][ks]);
         }
     }
+    if (STAMP) { asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[MT - 1][NT - 1][15])); stamp(13); }             // the chunk's MFMAs retired
     if (a.safe_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NT * KSC) : "memory");
+    stamp(14);
     __syncthreads();
+    stamp(15);
   };
   {
     int c = 0;
@@ -479,6 +498,9 @@ static int launch_rg(const RgArgs& a, int pro, int epi, hipStream_t st) {
 #define SRWN_RG(P, E)                                                                                        \
   if (pro == P && epi == E) {                                                                                \
     auto kfn = rowgemm_kernel<T, MT, KSC, P, E, (E == SRWN_EPI_SOFTMAX_CE) ? 1 : NT>;                        \
+    if constexpr (sizeof(T) == 2 && P == SRWN_PRO_GATE && E == SRWN_EPI_RELU && NT == 1 && MT == 8) {         \
+      if (a.stamps) kfn = rowgemm_kernel<T, MT, KSC, P, E, NT, false, true>;   /* diagnostic: the skip sum */ \
+    }                                                                                                        \
     if (sh > 32768) {                                                                                        \
       hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
       if (e != hipSuccess) return set_error((int)e, "rowgemm: LDS %zu: %s", sh, hipGetErrorString(e));       \
@@ -532,14 +554,14 @@ int rowgemm_dispatch(const void* x, int64_t x_row_stride, int64_t x_chunk_stride
   if (cout_pad == 128) {   // 128-wide products (the reference scripts' skip_channels=128): 4 row tiles per wave
     if (epi == SRWN_EPI_SOFTMAX_CE) return 0;
     RgArgs a4{x, x_row_stride, x_chunk_stride, chunk_len, Cin / 16, wpack, bias, y, y_row_stride, cout_valid, rows,
-              aux, aux_row_stride, targets, loss_partials, logits_out, grad_scale, 0, 0, nullptr, 0, 0, 1, 0.0f, safe_wait()};
+              aux, aux_row_stride, targets, loss_partials, logits_out, grad_scale, 0, 0, nullptr, 0, 0, 1, 0.0f, safe_wait(), nullptr};
     if (dtype == SRWN_BF16) *rc = launch_rg<bf16_t, 4, 4, 1>(a4, pro, epi, st);
     else if (dtype == SRWN_F32) *rc = launch_rg<float, 4, 2, 1>(a4, pro, epi, st);
     else return 0;
     return 1;
   }
   RgArgs a{x, x_row_stride, x_chunk_stride, chunk_len, Cin / 16, wpack, bias, y, y_row_stride, cout_valid, rows,
-           aux, aux_row_stride, targets, loss_partials, logits_out, grad_scale, 0, 0, nullptr, 0, 0, 1, 0.0f, safe_wait()};
+           aux, aux_row_stride, targets, loss_partials, logits_out, grad_scale, 0, 0, nullptr, 0, 0, 1, 0.0f, safe_wait(), debug_stamps()};
   if (dtype == SRWN_BF16) *rc = launch_rg<bf16_t, 8, 4, 1>(a, pro, epi, st);   // (two row tiles per wave measured slower: DESIGN.md 5)
   else if (dtype == SRWN_F32) *rc = launch_rg<float, 8, 2, 1>(a, pro, epi, st);
   else return 0;
@@ -568,7 +590,7 @@ extern "C" int srwn_tap_linear(const void* x, int64_t x_row_stride, int32_t ntap
                      (long long)rows, T, ntaps, Cin, cout, frames, pool_stride);
   RgArgs a{x, x_row_stride, 0, Cin, ntaps * Cin / 16, wpack, bias, y, y_row_stride, cout, rows, aux, aux_row_stride,
            nullptr, nullptr, nullptr, 0.0f, T, tap_step, frame_add, frame_add_ld, frames, pool_stride, frame_add_scale,
-           safe_wait()};
+           safe_wait(), nullptr};
   hipStream_t st = (hipStream_t)stream;
   if (dtype == SRWN_BF16) return cout == 128 ? launch_rg_taps<bf16_t, 4, 4>(a, epi, st) : launch_rg_taps<bf16_t, 8, 4>(a, epi, st);
   if (dtype == SRWN_F32) return cout == 128 ? launch_rg_taps<float, 4, 2>(a, epi, st) : launch_rg_taps<float, 8, 2>(a, epi, st);
