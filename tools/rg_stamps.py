@@ -33,8 +33,8 @@ h = buf.cpu().numpy().astype("uint64")
 for w in (0, 1):
     st = [(int(v) >> 48, int(v) & 0xffffffffffff) for v in h[w * 512:(w + 1) * 512] if v]
     if not st:
-        print("wave %d: no stamps" % w); continue
-    print("---- wave %d: %d stamps, %d cycles from first to last (100 MHz s_memtime ticks are scaled by the clock the kernel saw)" % (w, len(st), st[-1][1] - st[0][1]))
+        print("wave %d: no stamps" % (4 * w)); continue
+    print("---- wave %d: %d stamps, %d s_memtime cycles from first to last" % (4 * w, len(st), st[-1][1] - st[0][1]))
     agg = {}
     for (t0, c0), (t1, c1) in zip(st[:-1], st[1:]):
         agg.setdefault(t1, []).append(c1 - c0)
