@@ -33,6 +33,14 @@ struct RgArgs {
 
 // In-kernel time stamps (as in srwn_group.hip / srwn_head.hip): lane 0 of waves 0 and 4 of workgroup 0 -- the two waves of
 // SIMD 0 -- 512 entries each (tools/rg_stamps.py).
+#ifndef SRWN_RG_PIPE
+#define SRWN_RG_PIPE 1
+#endif
+#ifndef SRWN_RG_PIPE_VALU
+#define SRWN_RG_PIPE_VALU 6
+#endif
+constexpr bool kRgPipe = SRWN_RG_PIPE != 0;        // the gated skip sum gates chunk c+1 between the MFMAs of chunk c
+constexpr int kRgPipeValu = SRWN_RG_PIPE_VALU;    // VALU instructions scheduled behind each of those MFMAs
 template <bool STAMP> struct RgStamper {
   unsigned long long* p; int n;
   __device__ __forceinline__ void operator()(int tag) {
@@ -138,6 +146,80 @@ __global__ __launch_bounds__(64 * rg_waves(EPI, NT), (EPI == SRWN_EPI_SOFTMAX_CE
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt][q] = bv;
     }
 
+  // ---- the gated skip sum (bf16): the gate of chunk c+1 runs BETWEEN the MFMAs of chunk c.  In the loop below a chunk's
+  // gate (VALU, ~250 instructions per wave) and its 32 MFMAs are a dependent chain inside a wave, so the two pipes only
+  // overlap across the two waves of a SIMD -- and there the older wave takes the issue slots: profiles/r03_o (stamps):
+  // wave 0 is through a chunk after 3 050 cycles and waits 1 900 at the barrier for wave 4, the matrix pipe busy 2 048 of
+  // 5 300.  Three register sets: the one being multiplied (gated a chunk ago), the one being gated (arrived), the one in
+  // flight.
+  constexpr bool PIPE = kRgPipe && PRO == SRWN_PRO_GATE && sizeof(T) == 2 && !TAPS && NT == 1;
+  if constexpr (PIPE) {
+    Frag<T> bX[KSC], bY[KSC], bZ[KSC];
+    const int64_t rbase = valid[0] ? rowv[0] : (a.rows - 1);
+    auto loadp = [&](int c, Frag<T> (&dst)[KSC]) {
+#pragma unroll
+      for (int ks = 0; ks < KSC; ++ks) {
+        const int kg = 16 * (c * KSC + ks);
+        const int chunk = kg / a.chunk_len, within = kg - chunk * a.chunk_len;
+        dst[ks] = load_nat(reinterpret_cast<const T*>(a.x) + (int64_t)chunk * a.x_chunk_stride + rbase * a.x_row_stride + within + 8 * half);
+      }
+    };
+    auto gate = [&](Frag<T>& f) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f.set(j, gate_of_z<T>(f.get(j)));
+    };
+    stage(0, 0);
+    loadp(0, bX);
+    loadp(nchunks > 1 ? 1 : 0, bY);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < KSC; ++ks) gate(bX[ks]);
+    auto chunkp = [&](int c, Frag<T> (&cur)[KSC], Frag<T> (&nxt)[KSC], Frag<T> (&ld)[KSC]) {
+      stamp(10);
+      // nxt (requested a chunk ago) has to be in before anything younger is issued: the compiler's counted wait for it
+      // would otherwise cover this chunk's DMA pieces as well (it does not count them)
+#pragma unroll
+      for (int ks = 0; ks < KSC; ++ks) asm volatile("" : "+v"(nxt[ks].v));
+      stamp(11);
+      if (c + 1 < nchunks) stage(c + 1, (c + 1) & 1);
+      loadp(c + 2 < nchunks ? c + 2 : nchunks - 1, ld);
+      stamp(12);
+      const Frag<T>* lw = reinterpret_cast<const Frag<T>*>(smem + (c & 1) * CHUNK_B) + lane;
+      Frag<T> af[2][MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) af[0][mt] = lw[(mt * KSC) * 64];
+#pragma unroll
+      for (int ks = 0; ks < KSC; ++ks) {
+        if (ks + 1 < KSC) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) af[(ks + 1) & 1][mt] = lw[(mt * KSC + ks + 1) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) mma(acc[mt][0], af[ks & 1][mt], cur[ks]);
+        gate(nxt[ks]);
+        asm volatile("" : "+v"(nxt[ks].v));    // (pins the gate HERE: left alone it sinks to its use, behind the barrier)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {      // one MFMA, then a slice of the next chunk's gate in its shadow
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, kRgPipeValu, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (STAMP) { asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[MT - 1][0][15])); stamp(13); }
+      if (a.safe_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KSC) : "memory");
+      stamp(14);
+      __syncthreads();
+      stamp(15);
+    };
+    for (int c = 0; c < nchunks; c += 3) {
+      chunkp(c, bX, bY, bZ);
+      if (c + 1 < nchunks) chunkp(c + 1, bY, bZ, bX);
+      if (c + 2 < nchunks) chunkp(c + 2, bZ, bX, bY);
+    }
+  } else {
   // Pipeline: weight chunk c+1 streams into the other LDS buffer (LDS-DMA from L2) while chunk c is consumed;
   // activation fragments are fetched from HBM TWO chunks ahead into a ring of two register sets -- one chunk of
   // MFMAs (~0.5 us) does not cover an HBM round trip under load, and with a one-chunk distance every chunk barrier
@@ -215,6 +297,7 @@ __global__ __launch_bounds__(64 * rg_waves(EPI, NT), (EPI == SRWN_EPI_SOFTMAX_CE
     }
     if (c < nchunks) chunk(c, bA, okA);
   }
+  }   // !PIPE
   // the weight buffers are free now: each wave takes a private row stage ([32][64 + pad]) from them
   T* rstage = reinterpret_cast<T*>(smem) + wave * (32 * RowStage<T>::stride(64));
 
