@@ -136,15 +136,29 @@ __global__ __launch_bounds__(64 * rg_waves(EPI, NT), (EPI == SRWN_EPI_SOFTMAX_CE
   };
 
   f32x16 acc[MT][NT];
+  const bool bias_al = (reinterpret_cast<size_t>(a.bias) & 15) == 0;
+  auto init_acc = [&]() {       // accumulators start at the bias (four consecutive channels per register group)
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int n = 32 * mt + crow(q, half);
-      const float bv = (a.bias && n < a.cout_valid) ? a.bias[n] : 0.0f;
+      for (int gq = 0; gq < 4; ++gq) {
+        const int n0 = 32 * mt + 8 * gq + 4 * half;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias) {
+          if (n0 + 3 < a.cout_valid && bias_al) bv = *reinterpret_cast<const f32x4*>(a.bias + n0);
+          else {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc[mt][nt][q] = bv;
-    }
+            for (int e = 0; e < 4; ++e) bv[e] = (n0 + e < a.cout_valid) ? a.bias[n0 + e] : 0.0f;
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt][4 * gq + e] = bv[e];
+      }
+  };
+  constexpr bool PIPE = kRgPipe && PRO == SRWN_PRO_GATE && sizeof(T) == 2 && !TAPS && NT == 1;
+  if (!PIPE) init_acc();
 
   // ---- the gated skip sum (bf16): the gate of chunk c+1 runs BETWEEN the MFMAs of chunk c.  In the loop below a chunk's
   // gate (VALU, ~250 instructions per wave) and its 32 MFMAs are a dependent chain inside a wave, so the two pipes only
@@ -152,7 +166,6 @@ __global__ __launch_bounds__(64 * rg_waves(EPI, NT), (EPI == SRWN_EPI_SOFTMAX_CE
   // wave 0 is through a chunk after 3 050 cycles and waits 1 900 at the barrier for wave 4, the matrix pipe busy 2 048 of
   // 5 300.  Three register sets: the one being multiplied (gated a chunk ago), the one being gated (arrived), the one in
   // flight.
-  constexpr bool PIPE = kRgPipe && PRO == SRWN_PRO_GATE && sizeof(T) == 2 && !TAPS && NT == 1;
   if constexpr (PIPE) {
     Frag<T> bX[KSC], bY[KSC], bZ[KSC];
     const int64_t rbase = valid[0] ? rowv[0] : (a.rows - 1);
@@ -171,6 +184,7 @@ __global__ __launch_bounds__(64 * rg_waves(EPI, NT), (EPI == SRWN_EPI_SOFTMAX_CE
     stage(0, 0);
     loadp(0, bX);
     loadp(nchunks > 1 ? 1 : 0, bY);
+    init_acc();                 // (behind the first requests: the bias comes from the L2 while they cross the HBM)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #pragma unroll
