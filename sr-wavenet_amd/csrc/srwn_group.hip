@@ -434,6 +434,7 @@ struct GroupBwdArgs {
   const void* xT; const void* cT; int64_t wt_stride; int KT;
   float* part_f; float* part_r; float* part_bf; float* part_br;
   int nslabs, write_all_g;
+  unsigned long long* stamps;     // diagnostic instantiation only (srwn_debug_stamp_buffer): waves 0 and 4 of workgroup 0
   int dbg;                        // timing experiments (SRWN_WT_DEBUG): 1 = skip the dWr contraction, 2 = skip the dWf one
 };
 
@@ -443,9 +444,12 @@ constexpr int kWtPadRows = 64;
 constexpr bool kWtStagger = false;   // half of the waves contract dWf before their taps, half after
 constexpr bool kWtEarlyC = false;    // the next layer's first c^T fragments requested a phase early   // finite (zero) rows behind the image: the shifted tap of the last weight-gradient tile reads past it
 
-template <typename T, int RT, bool DCS, int MAXT, int NWB, int NWV = 8, bool WT = false>
+template <typename T, int RT, bool DCS, int MAXT, int NWB, int NWV = 8, bool WT = false, bool STAMP = false>
 __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
   constexpr int R = 32 * RT, K = 2, KS = R / 16;
+  Stamper<STAMP> stamp{nullptr, 0};      // (tools/gb_stamps.py) lane 0 of waves 0 and 4 -- the two waves of SIMD 0 -- of workgroup 0
+  if (STAMP && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) & 3) == 0) stamp.p = a.stamps + (threadIdx.x >> 8) * 512;
+  stamp(1);
   constexpr int NCONV = RT * K * KS, NRES = RT * KS, NW = NCONV + NRES;
   constexpr int LS = RowStage<T>::stride(R), VEC = RowStage<T>::VEC;
   constexpr int LPR = R / VEC, RPI = 64 / LPR, NI = 32 / RPI;
@@ -548,6 +552,36 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
     raw4 G[MAXT][RT][4];
     Frag<T> acn[8];                 // (WT) c^T fragments of the next layer's dWr contraction, requested a phase early
     const int gtop = a.nl - 1;
+    // (WT) column sums of the image over the rows the segment owns -- the two bias gradients of a layer -- as products with
+    // a fragment of ones: wave w < R/16 sums the 16 columns 16 w.. with one MFMA and one transposing read per tile.  (They
+    // used to ride in the contraction loops as four v_dot2 per fragment on EVERY wave, a third of those loops'
+    // instructions; the loops are bound by the instructions a SIMD's two waves issue.)  rows >= Wseg of the last tile are
+    // masked in the ones (mask = true: the df image holds the halo's rows there; G is parked with them zeroed).
+    auto colsum = [&](float* pb_slab, int ntiles, bool mask) {
+      if (!WT || wave >= R / 16) return;
+      int lw = lane;
+      asm volatile("" : "+v"(lw));
+      const T* cb = LdT16p<T>::base(img, LS, lw) + 16 * wave;
+      Frag<T> ones;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ones.set(e, 1.0f);
+      f32x4 accb = {0.f, 0.f, 0.f, 0.f};
+      const int kfull = Wseg >> 5;
+#pragma unroll 2
+      for (int k = 0; k < ntiles; ++k) {
+        Frag<T> ok = ones;
+        if (mask && k >= kfull) {
+          const int hik = Wseg - 32 * k;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ok.set(e, kordW(lw >> 4, e) < hik ? 1.0f : 0.0f);
+        }
+        mma16(accb, ok, LdT16p<T>::template load<LS>(cb + (size_t)(32 * k) * LS, 0));
+      }
+      if (lw < 16) {      // (row 0 of the 16 x 16 result: every row holds the sums)
+        float* pb = pb_slab + 16 * wave + lw;
+        *pb = (sit > 0 ? *pb : 0.0f) + accb[0];
+      }
+    };
     if (WT) {
       // every row the time contractions may touch must be finite: rows a layer has not (re)written only ever meet the zeroed
       // (not owned) rows of the other operand, but 0 x NaN from stale LDS would poison a sum
@@ -621,9 +655,8 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
         const bool active = active2;
         const int ib = ib2, ob0 = ob2;
         f32x4 acc[NBW];
-        float bs[NBW];
 #pragma unroll
-        for (int bb = 0; bb < NBW; ++bb) { acc[bb] = f32x4{0.f, 0.f, 0.f, 0.f}; bs[bb] = 0.0f; }
+        for (int bb = 0; bb < NBW; ++bb) acc[bb] = f32x4{0.f, 0.f, 0.f, 0.f};
         int lw = lane;      // (opaque copy: keeps this block's lane-dependent addresses from being hoisted over the chain,
         asm volatile("" : "+v"(lw));   //  where every register counts)
         if (haveg) {
@@ -653,12 +686,12 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
               }
             }
           }
+          stamp(20);
           wg_barrier();
+          stamp(21);
+          colsum(a.part_br + pslab * R, ktn, false);      // dbr_g = colsum(G_{g+1}) (rows the segment does not own are zero here)
           if (active && !(a.dbg & 1)) {
             const T* ct = reinterpret_cast<const T*>(a.cT) + (size_t)g * a.wt_stride + (size_t)seg * a.KT * (R * 32);
-            Frag<T> ones;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) ones.set(j, 1.0f);
             // eight tiles' fragments requested at a time, the next eight before the first are used: one or two HBM round
             // trips per loop instead of one per tile (a chain of dependent round trips made this loop cost as much as the
             // whole chain).  No branches inside: tiles beyond the segment's contribute a zero fragment.
@@ -683,11 +716,14 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
                 const int k = k0 + j;
                 if (k < ktn) {     // (wave-uniform)
                   const T* pk = gbase + (size_t)(32 * k) * LS;
+                  Frag<T> bfv[NBW];
+#pragma unroll
+                  for (int bb = 0; bb < NBW; ++bb) bfv[bb] = LdT16p<T>::template load<LS>(pk, 16 * bb);
+                  __builtin_amdgcn_sched_group_barrier(0x100, 2 * NBW, 0);
+                  __builtin_amdgcn_sched_group_barrier(0x008 | 0x002, 64, 0);
 #pragma unroll
                   for (int bb = 0; bb < NBW; ++bb) {
-                    const Frag<T> bf = LdT16p<T>::template load<LS>(pk, 16 * bb);
-                    mma16(acc[bb], av[j], bf);
-                    if (ib == 0) bs[bb] = frag_dot(bs[bb], bf, ones);
+                    mma16(acc[bb], av[j], bfv[bb]);
                   }
                 }
                 __builtin_amdgcn_sched_barrier(0);   // (left alone, the scheduler hoists all the transposing reads of the chunk: spills)
@@ -696,12 +732,13 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
               for (int j = 0; j < 8; ++j) av[j] = bv[j];
             }
           }
+          stamp(22);
           wg_barrier();      // the image goes back to the chain
+          stamp(23);
         }
         if (active) {
           // one 16 x 16 block per accumulator: lane l holds rows 4 (l >> 4) + rr of column l & 15
           float* pl = a.part_r + pslab * (R * R) + (size_t)(16 * ib + 4 * (lw >> 4)) * R + 16 * ob0 + (lw & 15);
-          float* pb = a.part_br + pslab * R + 16 * ob0 + (lw & 15);
           if (sit > 0) {       // a later segment of this workgroup: its sums join the earlier ones (fixed order)
 #pragma unroll
             for (int bb = 0; bb < NBW; ++bb) {
@@ -715,16 +752,12 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) pl[rr * R + 16 * bb] = acc[bb][rr];
             }
-            if (ib == 0) {
-              float t = bs[bb];
-              t += __shfl_xor(t, 16, 64);
-              t += __shfl_xor(t, 32, 64);
-              if (lw < 16) pb[16 * bb] = (sit > 0 ? pb[16 * bb] : 0.0f) + t;
-            }
           }
         }
+        if (!haveg) colsum(a.part_br + pslab * R, 0, false);      // (no gradient from above: dbr = 0 is still written)
       }
 
+      stamp(24);      // (the wave's partial of dWr is written)
       // ---- phase A: df of every owned tile
 #pragma unroll
       for (int m = 0; m < MAXT; ++m) {
@@ -773,7 +806,9 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
         tile_store(trow, dfg, q, WT ? 0 : hi, dv);     // (WT: into the image only; its readers are all on the chip)
         __builtin_amdgcn_sched_barrier(0);   // keep the tile bodies apart: interleaving them only lengthens live ranges
       }
+      stamp(25);
       wg_barrier();
+      stamp(26);
 
       // (WT) the wave's share of dWf_g: output blocks (tap, 16 rows of x channels, NBF x 16 df channels)
       constexpr int NIB5 = R / 16, NBLK5 = NIB5 * NIB5;
@@ -836,21 +871,16 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
         // in the image since the barrier between the phases (its readers only read), x^T comes from the forward kernel's tiles
         const bool active = active5;
         const int tap = tap5, ib = ib5, ob0 = ob5;
+        colsum(a.part_bf + pslab * R, a.dbg & 2 ? 0 : ktn, true);      // dbf_g = colsum(df_g) over the rows the segment owns
         if (active) {
           const int lw = lw5;
           const int shift = tap == 0 ? d : 0;             // tap 0 multiplies x[t - d]: row s of x meets row s + d of df
-          const bool bias = tap == 1 && ib == 0;
           f32x4 acc[NBF];
-          float bs[NBF];
 #pragma unroll
-          for (int bb = 0; bb < NBF; ++bb) { acc[bb] = f32x4{0.f, 0.f, 0.f, 0.f}; bs[bb] = 0.0f; }
+          for (int bb = 0; bb < NBF; ++bb) acc[bb] = f32x4{0.f, 0.f, 0.f, 0.f};
           const T* xt = xt5;
           const int ibl = (a.dbg & 8) ? 0 : ib;     // (timing experiment: every wave loads the same quarter of each tile)
           const int ktl = (a.dbg & 2) ? 0 : ktn;
-          const int kfull = Wseg >> 5;                    // tiles the segment owns whole
-          Frag<T> ones5;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) ones5.set(e, 1.0f);
           const T* dbase = LdT16p<T>::base(img, LS, lw) + (size_t)shift * LS + 16 * ob0;
           Frag<T> av[8], bv[8];
 #pragma unroll
@@ -867,11 +897,16 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
               const int k = k0 + j;
               if (k < ktn) {       // (wave-uniform)
                 const T* pk = dbase + (size_t)(32 * k) * LS;
+                // (all of the tile's image fragments in ONE batch of transposing reads: read -> wait -> MFMA block by block
+                // is three LDS round trips per tile -- stamps: the loop was 15 600 cycles for 64 MFMAs)
+                Frag<T> bfv[NBF];
+#pragma unroll
+                for (int bb = 0; bb < NBF; ++bb) bfv[bb] = LdT16p<T>::template load<LS>(pk, 16 * bb);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * NBF, 0);      // the reads first ...
+                __builtin_amdgcn_sched_group_barrier(0x008 | 0x002, 64, 0);   // ... then the products and the column sums
 #pragma unroll
                 for (int bb = 0; bb < NBF; ++bb) {
-                  const Frag<T> bf = LdT16p<T>::template load<LS>(pk, 16 * bb);
-                  mma16(acc[bb], av[j], bf);
-                  if (bias && k < kfull) bs[bb] = frag_dot(bs[bb], bf, ones5);   // whole tiles; the ragged one below
+                  mma16(acc[bb], av[j], bfv[bb]);
                 }
               }
               __builtin_amdgcn_sched_barrier(0);
@@ -879,17 +914,7 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) av[j] = bv[j];
           }
-          if (bias && (Wseg & 31) && Wseg > 0 && !(a.dbg & 2)) {   // dbf: the rows of the last, ragged tile the segment owns
-            const int hik = Wseg - 32 * kfull;
-            Frag<T> mk;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) mk.set(e, kordW(lw >> 4, e) < hik ? 1.0f : 0.0f);
-#pragma unroll
-            for (int bb = 0; bb < NBF; ++bb)
-              bs[bb] = frag_dot(bs[bb], LdT16<T>::load(img, LS, 32 * kfull + shift, 16 * (ob0 + bb), lw), mk);
-          }
           float* pl = a.part_f + pslab * (2 * R * R) + (size_t)tap * R * R + (size_t)(16 * ib + 4 * (lw >> 4)) * R + 16 * ob0 + (lw & 15);
-          float* pb = a.part_bf + pslab * R + 16 * ob0 + (lw & 15);
           if (sit > 0) {
 #pragma unroll
             for (int bb = 0; bb < NBF; ++bb) {
@@ -903,12 +928,6 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) pl[rr * R + 16 * bb] = acc[bb][rr];
             }
-            if (bias) {
-              float t = bs[bb];
-              t += __shfl_xor(t, 16, 64);
-              t += __shfl_xor(t, 32, 64);
-              if (lw < 16) pb[16 * bb] = (sit > 0 ? pb[16 * bb] : 0.0f) + t;
-            }
           }
         }
       };   // dwf
@@ -917,9 +936,12 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
       // (Measured: the second copy of the two bodies and the longer live ranges cost 30-60 spilled registers in the R = 64
       // kernels, which are at 256 already -- 0.74 -> 0.98 ms per step; off.)
       if (kWtStagger && WT && wave < NWV / 2) { dwf(); phaseB(); }
-      else { phaseB(); if (WT) dwf(); }
+      else { phaseB(); stamp(27); if (WT) dwf(); }
+      stamp(28);
       if (NWB == 2 && g > 0) dma_wait();
+      stamp(29);
       wg_barrier();
+      stamp(30);
     }
     // ---- the group's bottom gradient
 #pragma unroll
@@ -1011,6 +1033,9 @@ int launch_group_bwd(GroupBwdArgs& a, int seg_rows, hipStream_t st) {
 #define SRWN_GB(D)                                                                                              \
   {                                                                                                             \
     auto kfn = two ? group_bwd_kernel<T, RT, D, MT2, NWB, NWV, WT> : group_bwd_kernel<T, RT, D, MAXT, NWB, NWV, WT>; \
+    if constexpr (WT && D && sizeof(T) == 2 && RT == 2) {                                                        \
+      if (g_stamps) { a.stamps = g_stamps; kfn = two ? group_bwd_kernel<T, RT, D, MT2, NWB, NWV, WT, true> : group_bwd_kernel<T, RT, D, MAXT, NWB, NWV, WT, true>; } \
+    }                                                                                                           \
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);  \
     if (e != hipSuccess) return set_error((int)e, "residual_group_bwd: LDS %zu: %s", sh, hipGetErrorString(e)); \
     hipLaunchKernelGGL(kfn, grid, block, sh, st, a);                                                            \
@@ -1051,6 +1076,7 @@ static int group_bwd_impl(const void* g_top, void* g_out, void* df_out, const vo
   a.xT = a.cT = nullptr; a.wt_stride = 0; a.KT = 0; a.part_f = a.part_r = a.part_bf = a.part_br = nullptr; a.nslabs = 0; a.write_all_g = 0;
   static const int wt_dbg = [] { const char* e = getenv("SRWN_WT_DEBUG"); return e ? atoi(e) : 0; }();
   a.dbg = wt_dbg;
+  a.stamps = nullptr;
   if (wt) {
     a.xT = wt->xT; a.cT = wt->cT; a.wt_stride = wt->wt_stride; a.part_f = wt->part_f; a.part_r = wt->part_r;
     a.part_bf = wt->part_bf; a.part_br = wt->part_br; a.nslabs = wt->nslabs; a.write_all_g = wt->write_all_g ? 1 : 0;
