@@ -603,6 +603,12 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
         rows_load(reinterpret_cast<const T*>(a.g_top), q, v);
         rows_put(trow, v);
         acc_get(trow, G[m]);
+        if (WT && !((jbase + 32 * q + col) < Jr)) {      // rows beyond the clip are clamped re-reads: G = 0 there from here on
+#pragma unroll
+          for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) G[m][mt][gq] = Raw4g<T>::zero();
+        }
       }
     }
     dma_wait();
@@ -790,7 +796,7 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
             Frag<T> bfr;
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj)
-              bfr.set(jj, (ok ? Raw4g<T>::get(G[m][s >> 1][2 * (s & 1) + (jj >> 2)], jj & 3) : 0.0f) * kSqrtHalf);
+              bfr.set(jj, ((WT || ok) ? Raw4g<T>::get(G[m][s >> 1][2 * (s & 1) + (jj >> 2)], jj & 3) : 0.0f) * kSqrtHalf);   // (WT: G is 0 beyond the clip, see phase B)
 #pragma unroll
             for (int mt = 0; mt < RT; ++mt) mma(accC[mt], lds_res[(mt * KS + s) * 64 + lane], bfr);
           }
@@ -843,18 +849,21 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
         for (int mt = 0; mt < RT; ++mt)
 #pragma unroll
           for (int e = 0; e < 16; ++e)
-            accG[mt][e] = (haveg && ok) ? Raw4g<T>::get(G[m][mt][e >> 2], e & 3) * kSqrtHalf : 0.0f;
+            accG[mt][e] = (haveg && (WT || ok)) ? Raw4g<T>::get(G[m][mt][e >> 2], e & 3) * kSqrtHalf : 0.0f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const Frag<T> f0 = load_nat(img + (size_t)src * LS + 16 * ks + 8 * half);
-          const Frag<T> bfr = ok_d ? f0 : zero_frag<T>();
+          // (WT: no selects -- the image is zeroed per segment and df of a row beyond the clip is computed as 0 (its dcs is
+          // masked, its G is 0), so G stays 0 there layer after layer; without the zeroed image a previous segment's rows
+          // may lie behind the clip's end)
+          const Frag<T> bfr = (WT || ok_d) ? f0 : zero_frag<T>();
 #pragma unroll
           for (int mt = 0; mt < RT; ++mt) mma(accG[mt], lds_conv[(mt * (K * KS) + ks) * 64 + lane], bfr);
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const Frag<T> f1 = load_nat(img + (size_t)i0 * LS + 16 * ks + 8 * half);
-          const Frag<T> bfr = ok ? f1 : zero_frag<T>();
+          const Frag<T> bfr = (WT || ok) ? f1 : zero_frag<T>();
 #pragma unroll
           for (int mt = 0; mt < RT; ++mt) mma(accG[mt], lds_conv[(mt * (K * KS) + KS + ks) * 64 + lane], bfr);
         }
