@@ -843,7 +843,9 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
         const bool ok = j < Jr;
         const bool ok_d = (j + d) < Jr;                 // the shifted tap stays inside the clip (zero beyond it)
         int src = i0 + d;
-        src = src < a.NT * 32 ? src : a.NT * 32 - 1;
+        if (!WT) src = src < a.NT * 32 ? src : a.NT * 32 - 1;      // (WT: kWtPadRows zeroed rows lie behind the image, d < 64: a tap
+                                                                    // past the image reads zeros -- clamped it would read the last row,
+                                                                    // which only the select on ok_d kept out)
         f32x16 accG[RT];
 #pragma unroll
         for (int mt = 0; mt < RT; ++mt)
