@@ -567,15 +567,27 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
       for (int e = 0; e < 8; ++e) ones.set(e, 1.0f);
       f32x4 accb = {0.f, 0.f, 0.f, 0.f};
       const int kfull = Wseg >> 5;
-#pragma unroll 2
-      for (int k = 0; k < ntiles; ++k) {
-        Frag<T> ok = ones;
-        if (mask && k >= kfull) {
-          const int hik = Wseg - 32 * k;
+      constexpr int CU = 4;      // tiles per batch of transposing reads (one LDS round trip per batch, not per tile)
+#pragma unroll 1
+      for (int k0 = 0; k0 < ntiles; k0 += CU) {
+        Frag<T> bf[CU];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) ok.set(e, kordW(lw >> 4, e) < hik ? 1.0f : 0.0f);
+        for (int u = 0; u < CU; ++u) {
+          const int k = k0 + u < ntiles ? k0 + u : ntiles - 1;
+          bf[u] = LdT16p<T>::template load<LS>(cb + (size_t)(32 * k) * LS, 0);
         }
-        mma16(accb, ok, LdT16p<T>::template load<LS>(cb + (size_t)(32 * k) * LS, 0));
+#pragma unroll
+        for (int u = 0; u < CU; ++u) {
+          const int k = k0 + u;
+          Frag<T> ok = ones;
+          if (k >= ntiles) ok = zero_frag<T>();
+          else if (mask && k >= kfull) {
+            const int hik = Wseg - 32 * k;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ok.set(e, kordW(lw >> 4, e) < hik ? 1.0f : 0.0f);
+          }
+          mma16(accb, ok, bf[u]);
+        }
       }
       if (lw < 16) {      // (row 0 of the 16 x 16 result: every row holds the sums)
         float* pb = pb_slab + 16 * wave + lw;
