@@ -1209,6 +1209,7 @@ static int group_fwd_impl(const void* x0, void* x_out, void* z_out, int64_t laye
       if (R == 32) return launch_group_fwd<bf16_t, 1, 3, 2, 8, true, false, true>(a, any_cond, seg_rows, st);
       // (eight waves of three tiles: twelve waves of 168 registers, the plain kernel's choice, spill 30-47 registers once the
       // tile stores are in the body: 0.43 vs 0.38 ms per step)
+      if (g_stamps) { a.stamps = g_stamps; return launch_group_fwd<bf16_t, 2, 3, 2, 8, true, true, true>(a, any_cond, seg_rows, st); }   // (tools/stamp_probe.py)
       return launch_group_fwd<bf16_t, 2, 3, 2, 8, true, false, true>(a, any_cond, seg_rows, st);
     } else if (dtype == SRWN_F32) {
       if (R == 32) return launch_group_fwd<float, 1, 1, 1, 8, true, false, true>(a, any_cond, seg_rows, st);
