@@ -84,7 +84,7 @@ __global__ __launch_bounds__(64 * NWV) void group_fwd_kernel(GroupFwdArgs a) {
   const int col = lane & 31, half = lane >> 5;
   const int rsub = lane / LPR, piece = lane % LPR;
   Stamper<STAMP> stamp{nullptr, 0};
-  if (STAMP && blockIdx.x == 0 && lane == 0 && wave < 2) stamp.p = a.stamps + wave * 512;
+  if (STAMP && blockIdx.x == 0 && lane == 0 && (wave & 3) == 0 && wave < 8) stamp.p = a.stamps + (wave >> 2) * 512;   // waves 0 and 4: the two waves of SIMD 0
   stamp(1);
 
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""In-kernel phase timing of the fused forward kernel (workgroup 0, waves 0 and 1): prints cycles between stamps."""
+"""In-kernel phase timing of the fused forward kernel (workgroup 0, waves 0 and 4 = the two waves of SIMD 0): prints cycles between stamps."""
 import importlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -28,7 +28,7 @@ for which in (0, 1):
     h = buf.cpu().numpy().astype("uint64")
     for w in (0, 1):
         st = [(int(v) >> 48, int(v) & 0xffffffffffff) for v in h[w * 512:(w + 1) * 512] if v]
-        print("---- group dil %d.., wave %d: %d stamps, total %d cycles" % (eng.dil[g[0]], w, len(st), st[-1][1] - st[0][1]))
+        print("---- group dil %d.., wave %d: %d stamps, total %d cycles" % (eng.dil[g[0]], 4 * w, len(st), st[-1][1] - st[0][1]))
         agg = {}
         for (t0, c0), (t1, c1) in zip(st[:-1], st[1:]):
             agg.setdefault(t1, []).append(c1 - c0)
