@@ -466,7 +466,18 @@ __global__ __launch_bounds__(256 * NG) void wgrad_layer_kernel(WgLArgs a) {
     for (int n = 0; n < CT; ++n) accF[n][q] = 0.0f;
     accR[q] = 0.0f;
   }
-  float bsum = 0.0f;   // threads 0..RC-1: colsum(df); RC..2RC-1: colsum(G)
+  // Column sums of the D tile [df | G] (the two bias gradients): wave w < 2 CT sums 32-column tile w with one MFMA per
+  // k-step against a fragment of ONES (every row of the 32 x 32 result holds the sums).  Before, threads 0..2RC-1 -- two of a
+  // group's four waves -- walked the tile's 32 rows per chunk (~100 instructions against the ~30 of the products) and the
+  // other two waited at the chunk's barrier.
+  f32x16 accB;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) accB[q] = 0.0f;
+  Frag<T> ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones.set(e, 1.0f);
+  const bool has_bias = wave < 2 * CT;
+  const int bias_col = wave < CT ? 32 * wave : RC + 32 * (wave - CT);
 
   f32x4 rxd[NV], rxc[NV], rz[NV], rf[NV], rg[NV];
   f32x4 rcd[COND ? NV : 1], rcc[COND ? NV : 1];
@@ -595,12 +606,9 @@ __global__ __launch_bounds__(256 * NG) void wgrad_layer_kernel(WgLArgs a) {
     };
     auto multiply = [&](int buf) {
       const T* ta = tileA(buf); const T* td = tileD(buf);
-      if (tid < 2 * RC) {
-#pragma unroll 8
-        for (int rr = 0; rr < KR; ++rr) bsum += (float)td[rr * LD + tid];
-      }
 #pragma unroll
       for (int ks = 0; ks < KR / 16; ++ks) {
+        if (has_bias) mma(accB, ones, Ld2<T>::load(td, LD, 16 * ks, bias_col, lane));
         if (has_conv) {
           const Frag<T> a_conv = Ld2<T>::load(ta, LA, 16 * ks, 32 * wave, lane);
 #pragma unroll
@@ -640,12 +648,9 @@ __global__ __launch_bounds__(256 * NG) void wgrad_layer_kernel(WgLArgs a) {
     const int buf = it & 1;
     if (it + 1 < nit) gload(it + 1);
     const T* ta = tileA(buf); const T* td = tileD(buf);
-    if (tid < 2 * RC) {
-#pragma unroll 8
-      for (int rr = 0; rr < KR; ++rr) bsum += (float)td[rr * LD + tid];
-    }
 #pragma unroll
     for (int ks = 0; ks < KR / 16; ++ks) {
+      if (has_bias) mma(accB, ones, Ld2<T>::load(td, LD, 16 * ks, bias_col, lane));
       if (has_conv) {
         const Frag<T> a_conv = Ld2<T>::load(ta, LA, 16 * ks, 32 * wave, lane);          // rows 32w.. of [xd|xc]
 #pragma unroll
@@ -675,7 +680,7 @@ __global__ __launch_bounds__(256 * NG) void wgrad_layer_kernel(WgLArgs a) {
         for (int q = 0; q < 16; ++q) r[(16 * n + q) * 256] = accF[n][q];
 #pragma unroll
       for (int q = 0; q < 16; ++q) r[(16 * CT + q) * 256] = accR[q];
-      r[(16 * (CT + 1)) * 256] = bsum;
+      r[(16 * (CT + 1)) * 256] = accB[0];
     }
     __syncthreads();
     if (grp > 0) return;
@@ -687,7 +692,7 @@ __global__ __launch_bounds__(256 * NG) void wgrad_layer_kernel(WgLArgs a) {
         for (int q = 0; q < 16; ++q) accF[n][q] += r[(16 * n + q) * 256];
 #pragma unroll
       for (int q = 0; q < 16; ++q) accR[q] += r[(16 * CT + q) * 256];
-      bsum += r[(16 * (CT + 1)) * 256];
+      accB[0] += r[(16 * (CT + 1)) * 256];
     }
   }
   const int col = lane & 31, half = lane >> 5;
@@ -704,8 +709,10 @@ __global__ __launch_bounds__(256 * NG) void wgrad_layer_kernel(WgLArgs a) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) pr[(int64_t)(32 * res_rt + crow(q, half)) * RC + 32 * res_ct + col] = accR[q];
   }
-  if (tid < RC) a.part_bf[ls * RC + tid] = bsum;
-  else if (tid < 2 * RC) a.part_br[ls * RC + (tid - RC)] = bsum;
+  if (has_bias && lane < 32) {      // row 0 of the result: lanes 0..31, register 0
+    if (wave < CT) a.part_bf[ls * RC + 32 * wave + lane] = accB[0];
+    else a.part_br[ls * RC + 32 * (wave - CT) + lane] = accB[0];
+  }
 }
 
 }  // namespace
@@ -817,7 +824,13 @@ __global__ __launch_bounds__(512) void wgrad_nc_kernel(WgNcArgs a) {
     for (int n = 0; n < 4; ++n) accW[n][q] = 0.0f;
     accR[0][q] = 0.0f; accR[1][q] = 0.0f;
   }
-  float bsum = 0.0f;   // threads 0..127: colsum(dpre); 128..255: colsum(dh)
+  // column sums of [dpre | dh] (the two bias gradients) as ones-MFMAs: wave w sums 32-column tile w (see wgrad_layer_kernel)
+  f32x16 accB;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) accB[q] = 0.0f;
+  Frag<T> ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones.set(e, 1.0f);
 
   f32x4 r0v[NV], r1v[NV], av[NV], pv[NV], hv[NV];
   auto gload = [&](int it) {
@@ -857,12 +870,9 @@ __global__ __launch_bounds__(512) void wgrad_nc_kernel(WgNcArgs a) {
 
   auto multiply = [&](int buf) {
     const T* ta = tileA(buf); const T* td = tileD(buf);
-    if (tid < 2 * C) {
-#pragma unroll 8
-      for (int rr = 0; rr < KR; ++rr) bsum += (float)td[rr * LD + tid];
-    }
 #pragma unroll
     for (int ks = 0; ks < KR / 16; ++ks) {
+      mma(accB, ones, Ld2<T>::load(td, LD, 16 * ks, 32 * wave, lane));                        // columns 32w.. of [dpre | dh]
       const Frag<T> a_conv = Ld2<T>::load(ta, LA, 16 * ks, 32 * wave, lane);                  // rows 32w.. of [r(t)|r(t+1)]
       const Frag<T> a_res = Ld2<T>::load(ta, LA, 16 * ks, 2 * C + 32 * (wave >> 1), lane);    // a row tile
 #pragma unroll
@@ -957,8 +967,10 @@ __global__ __launch_bounds__(512) void wgrad_nc_kernel(WgNcArgs a) {
 #pragma unroll
     for (int q = 0; q < 16; ++q)
       pr[(int64_t)(32 * (wave >> 1) + crow(q, half)) * C + 32 * (2 * (wave & 1) + n) + col] = accR[n][q];
-  if (tid < C) a.part_b[ls * C + tid] = bsum;
-  else if (tid < 2 * C) a.part_br[ls * C + (tid - C)] = bsum;
+  if (lane < 32) {      // row 0 of the result: lanes 0..31, register 0; tiles 0..3 = dpre, 4..7 = dh
+    if (wave < 4) a.part_b[ls * C + 32 * wave + lane] = accB[0];
+    else a.part_br[ls * C + 32 * (wave - 4) + lane] = accB[0];
+  }
 }
 
 }  // namespace
