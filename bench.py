@@ -92,7 +92,7 @@ def student_leg(steps=10, warmup=3, B=8, T=16000):
     dt = torch.bfloat16
     tcfg = EG.StackConfig(dilations=dil, dilation_channels=64, skip_channels=256, output_channels=4 * M, cond_channels=lat,
                           pool_stride=pool, shift_input=True, dtype=dt, head_mode="mol")
-    teacher = EG.WaveNetEngine(tcfg, B, T, "cuda")
+    teacher = EG.WaveNetEngine(tcfg, B, T, "cuda", frozen=True)   # never trained here: no tiles / partial slabs allocated
     fcfg = EG.StackConfig(dilations=dil, dilation_channels=64, skip_channels=256, cond_channels=lat, pool_stride=pool, dtype=dt)
     stu = ST.StudentEngine(teacher, fcfg, 4, alpha=1.0, beta=1.0, gamma=1e-3, learning_rate=1e-4)
     rng = np.random.default_rng(0)

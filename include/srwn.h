@@ -4,7 +4,8 @@
  * seam is the Python call surface of ops.py / model.py.  Each entry point below names the
  * reference function (file:line under /root/reference) whose arithmetic it replaces; the host
  * mirror of that Python surface lives in sr-wavenet_amd/{ops,model}.py and binds this header
- * with ctypes.
+ * through the pybind11 module build.py generates from it (_srwn_pyb; ctypes on request:
+ * SRWN_BINDING=ctypes) -- see INTEGRATION.md.
  *
  * Conventions
  *  - every pointer is a DEVICE pointer owned by the caller; nothing is allocated or freed here;
@@ -122,23 +123,6 @@ int srwn_residual_group_bwd(const void* g_top, void* g_out, void* df_out, const 
                             int64_t layer_stride, const void* const* wconvT, const void* const* wresT,
                             const int32_t* dilations, int32_t nlayers, int32_t B, int32_t T, int32_t R, int32_t K,
                             int32_t seg_rows, int32_t dtype, void* stream);
-/* the backward chain of a group AND the group's layer weight gradients in one launch: the chain of
- * srwn_residual_group_bwd plus, from df_g and G_{g+1} while they are on the chip, the sums srwn_wgrad_layers makes from
- * their HBM copies (tf.gradients of ops.py:27,39):
- *   part_f [g][slab][k*R+i][o] = sum x_g[t-(1-k)*d_g, i] * df_g[t, o]      part_bf[g][slab][o] = sum df_g[t, o]
- *   part_r [g][slab][i][o]     = sum c_g[t, i] * G_{g+1}[t, o]             part_br[g][slab][o] = sum G_{g+1}[t, o]
- * (c = z sigmoid z; one slab per workgroup, `nslabs` >= srwn_group_wgrad_slabs() slabs per layer of which the launch
- * writes the first <number of workgroups> -- keep the rest zero; finish with srwn_reduce_partials, sqrt(.5) on the
- * residual pair, exactly as after srwn_wgrad_layers).  df is not written at all; g_out receives the group's bottom
- * gradient (layer 0's input gradient) and, with write_all_g != 0, layer g's at g_out + g*layer_stride (the conditioned
- * decoders sum them per frame, model.py:180).  x: layer g's complete input at x + g*layer_stride.  Halo
- * (sum(dilations)/gcd) <= 31.  fp32 runs the launch once per sum (the chain repeats identically). */
-int32_t srwn_group_wgrad_slabs(void);
-int srwn_residual_group_bwd_wgrad(const void* g_top, void* g_out, int32_t write_all_g, const void* x, const void* z,
-                                  const void* dcs, int64_t layer_stride, const void* const* wconvT,
-                                  const void* const* wresT, const int32_t* dilations, int32_t nlayers, float* part_f,
-                                  float* part_r, float* part_bf, float* part_br, int32_t nslabs, int32_t B, int32_t T,
-                                  int32_t R, int32_t K, int32_t seg_rows, int32_t dtype, void* stream);
 /* ---- layer weight gradients summed inside the backward group kernel, 8 waves, output-split ("wt" mode).
  * The two kernels of a group are given the SAME segment cut (srwn_group_wt_geometry).  srwn_residual_group_fwd_wt is
  * srwn_residual_group_fwd that also writes, per layer g of the group and per 32-step tile of every segment, the
@@ -195,8 +179,11 @@ int srwn_relu(const float* x, float* y, int64_t n, void* stream);
 int srwn_mol_nll_rows(const float* logits, int64_t ldl, const float* x, int32_t M, float* out, int64_t rows,
                       void* stream);
 
-/* diagnostic hook for profiling builds (no reference counterpart): while a device buffer of 1024 uint64 is registered
- * the bf16 forward group kernel appends in-kernel clock stamps of workgroup 0 to it; NULL restores production code. */
+/* diagnostic hook (no reference counterpart).  Only the -DSRWN_DIAG build of this library (libsrwn_diag.so:
+ * `python sr-wavenet_amd/build.py --diag`, loaded with SRWN_LIB_PATH) holds the stamped kernel instantiations: there,
+ * while a device buffer of 1024 uint64 is registered, the bf16 group kernels, the skip sum and the one-launch head append
+ * in-kernel clock stamps of workgroup 0 to it; NULL restores production code.  The shipped libsrwn.so accepts NULL and
+ * returns SRWN_E_UNSUPPORTED for a buffer. */
 int srwn_debug_stamp_buffer(void* device_buffer);
 /* greedy cut of a stack's dilation list (model.py:9, teacher.py:57) into such groups: starts[0..n] (starts[n] = nlayers),
  * returns n.  `starts` needs nlayers + 1 entries. */

@@ -43,9 +43,6 @@ SIGNATURES = {
     "srwn_residual_group_fwd": (C.c_int, [_p, _p, _p, _i64, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _i32, _i32, _i32,
                                           _i32, _i32, _i32, _i32, _p]),
     "srwn_residual_group_bwd": (C.c_int, [_p, _p, _p, _p, _p, _i64, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
-    "srwn_group_wgrad_slabs": (_i32, []),
-    "srwn_residual_group_bwd_wgrad": (C.c_int, [_p, _p, _i32, _p, _p, _p, _i64, _p, _p, _p, _i32, _p, _p, _p, _p, _i32,
-                                                _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "srwn_group_wt_geometry": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p]),
     "srwn_residual_group_fwd_wt": (C.c_int, [_p, _p, _p, _i64, _p, _p, _i64, _i32, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p,
                                              _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),

@@ -19,7 +19,7 @@ PYB_SRC = os.path.join(CSRC, "srwn_pybind.cpp")   # generated from _lib.SIGNATUR
 PYB_NAME = "_srwn_pyb"
 IO_SOURCES = ["srwn_tfrecord.cpp"]
 CXX = os.environ.get("CXX", "g++")
-SOURCES = ["srwn_util.hip", "srwn_fwd.hip", "srwn_bwd.hip", "srwn_opt.hip", "srwn_pool.hip", "srwn_gemm.hip", "srwn_wgrad2.hip", "srwn_gen.hip", "srwn_gen16.hip", "srwn_flow.hip", "srwn_enc.hip", "srwn_nc.hip", "srwn_group.hip", "srwn_groupw.hip", "srwn_wgradt.hip", "srwn_ops.hip", "srwn_head.hip"]
+SOURCES = ["srwn_util.hip", "srwn_fwd.hip", "srwn_bwd.hip", "srwn_opt.hip", "srwn_pool.hip", "srwn_gemm.hip", "srwn_wgrad2.hip", "srwn_gen.hip", "srwn_gen16.hip", "srwn_flow.hip", "srwn_enc.hip", "srwn_nc.hip", "srwn_group.hip", "srwn_wgradt.hip", "srwn_ops.hip", "srwn_head.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-pass-failed", "-ffp-contract=on"]
 # Kernels that fetch REGISTER operands with loads the compiler does not see (inline asm, hand-counted waits) must not
@@ -55,6 +55,14 @@ def _stale(target, srcs):
     return any(os.path.getmtime(s) > t for s in srcs)
 
 
+def _sha(paths, extra=""):
+    import hashlib
+    h = hashlib.sha256(extra.encode())
+    for f in paths:
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def _check_no_spill(src, obj, remarks, kernels):
     """Parses hipcc's kernel-resource-usage remarks: every kernel of `kernels` must report `VGPRs Spill: 0`."""
     import re
@@ -75,16 +83,57 @@ def _check_no_spill(src, obj, remarks, kernels):
             raise RuntimeError("%s: kernel %s must not spill registers (untracked register loads): %s" % (src, k, hit or "not found"))
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def _check_inflight(src, obj, flags, kernels):
+    """The structural half of the guard: the kernel's gfx950 assembly (a device-only -S compile with the same flags) is
+    walked by asmcheck.check_inflight_loads -- no instruction may read or overwrite the destination of a global_load
+    while that load can still be in flight under the s_waitcnt vmcnt(N) the code actually executes.  A spill-free build
+    can still copy or re-coalesce such a register before the hand-counted wait; this refuses it."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_srwn_asmcheck", os.path.join(HERE, "asmcheck.py"))
+    ac = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ac)
+    cmd = [HIPCC] + flags + ["--cuda-device-only", "-S", src, "-o", "-"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc -S failed for %s:\n%s" % (src, r.stderr[-4000:]))
+    for k in kernels:
+        bad = ac.check_inflight_loads(r.stdout, k)
+        if bad:
+            if os.path.exists(obj):
+                os.remove(obj)
+            raise RuntimeError("%s: kernel %s touches the destination of a load that may still be in flight:\n  %s"
+                               % (src, k, "\n  ".join(bad[:8])))
+
+
+def build(force: bool = False, verbose: bool = False, diag: bool = False) -> str:
+    """diag=False: libsrwn.so (+ libsrwn_io.so, the pybind11 module, the manifest).  diag=True: libsrwn_diag.so, the same
+    sources with -DSRWN_DIAG (stamped kernel instantiations, SRWN_WT_DEBUG), objects under csrc/diag/; load it with
+    SRWN_LIB_PATH (ctypes binding, no manifest)."""
+    import json
+    flags = FLAGS + (["-DSRWN_DIAG"] if diag else [])
+    odir = os.path.join(CSRC, "diag") if diag else CSRC
+    os.makedirs(odir, exist_ok=True)
+    lib = os.path.join(HERE, "libsrwn_diag.so") if diag else LIB
+    man_path = os.path.join(odir, "objects.manifest.json") if diag else MANIFEST
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    objs = [os.path.join(CSRC, os.path.splitext(os.path.basename(s))[0] + ".o") for s in srcs]
-    deps = _deps()
+    objs = [os.path.join(odir, os.path.splitext(os.path.basename(s))[0] + ".o") for s in srcs]
+    deps = sorted(_deps())
+    # Staleness is decided from what each object was COMPILED from (recorded sha256 of source + headers + flags), not
+    # from mtimes: a tree whose sources changed but carry older mtimes than the travelling .o files (rsync -t, a
+    # snapshot restore) would otherwise have its stale library blessed by a fresh manifest.
+    try:
+        old = json.load(open(man_path)).get("objects", {})
+    except (OSError, ValueError):
+        old = {}
+    keys = {}
 
     def cc(pair):
         src, obj = pair
-        if force or _stale(obj, [src] + deps):
-            guarded = NO_SPILL.get(os.path.basename(src), [])
-            cmd = [HIPCC] + FLAGS + (["-Rpass-analysis=kernel-resource-usage"] if guarded else []) + ["-c", src, "-o", obj]
+        rel = os.path.basename(src)
+        key = _sha([src] + deps, " ".join(flags))
+        if force or not os.path.exists(obj) or old.get(rel) != key:
+            guarded = NO_SPILL.get(rel, [])
+            cmd = [HIPCC] + flags + (["-Rpass-analysis=kernel-resource-usage"] if guarded else []) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             r = subprocess.run(cmd, capture_output=True, text=True)
@@ -92,21 +141,28 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-8000:]))
             if guarded:
                 _check_no_spill(src, obj, r.stderr, guarded)
+                _check_inflight(src, obj, flags, guarded)
+        keys[rel] = key
         return obj
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(cc, zip(srcs, objs)))
-    if force or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    relink = force or not os.path.exists(lib) or old != keys
+    if relink:
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s" % r.stderr[-8000:])
+    if diag:
+        with open(man_path, "w") as f:
+            json.dump({"flags": flags, "objects": keys}, f, indent=1, sort_keys=True)
+        return lib
     build_io(force)
-    build_pybind(force)
-    import json
-    with open(MANIFEST, "w") as f:      # which sources this library came from: _lib.load() refuses a stale one
-        json.dump({"flags": FLAGS, "sources": source_hashes()}, f, indent=1, sort_keys=True)
-    return LIB
+    build_pybind(force or relink)
+    with open(MANIFEST, "w") as f:      # which sources this library came from: _lib.load() refuses a stale one.  Written
+        # only here, after every object has been compiled from (or verified against) the hashes it records
+        json.dump({"flags": flags, "objects": keys, "sources": source_hashes()}, f, indent=1, sort_keys=True)
+    return lib
 
 
 def _signatures():
@@ -154,7 +210,13 @@ def pybind_path() -> str:
 def build_pybind(force: bool = False) -> str:
     """The pybind11 module (the binding north_star names): g++, linked against libsrwn.so next to it ($ORIGIN rpath)."""
     import sysconfig
-    import pybind11
+    try:
+        import pybind11
+    except ImportError:
+        if os.environ.get("SRWN_BINDING") == "ctypes":      # the ctypes binding of the same library needs no module
+            print("pybind11 not importable: skipping the _srwn_pyb module (SRWN_BINDING=ctypes)", file=sys.stderr)
+            return ""
+        raise RuntimeError("pybind11 is not importable: install it, or set SRWN_BINDING=ctypes to bind libsrwn.so with ctypes")
     src = pybind_source()
     if not os.path.exists(PYB_SRC) or open(PYB_SRC).read() != src:
         with open(PYB_SRC, "w") as f:
@@ -180,4 +242,4 @@ def build_io(force: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, diag="--diag" in sys.argv))

@@ -596,7 +596,7 @@ static int launch_rg(const RgArgs& a, int pro, int epi, hipStream_t st) {
   if (pro == P && epi == E) {                                                                                \
     auto kfn = rowgemm_kernel<T, MT, KSC, P, E, (E == SRWN_EPI_SOFTMAX_CE) ? 1 : NT>;                        \
     if constexpr (sizeof(T) == 2 && P == SRWN_PRO_GATE && E == SRWN_EPI_RELU && NT == 1 && MT == 8) {         \
-      if (a.stamps) kfn = rowgemm_kernel<T, MT, KSC, P, E, NT, false, true>;   /* diagnostic: the skip sum */ \
+      SRWN_DIAG_ONLY(if (a.stamps) kfn = rowgemm_kernel<T, MT, KSC, P, E, NT, false, true>;)   /* diagnostic build: the skip sum */ \
     }                                                                                                        \
     if (sh > 32768) {                                                                                        \
       hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \

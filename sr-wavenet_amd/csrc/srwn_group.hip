@@ -435,8 +435,13 @@ struct GroupBwdArgs {
   float* part_f; float* part_r; float* part_bf; float* part_br;
   int nslabs, write_all_g;
   unsigned long long* stamps;     // diagnostic instantiation only (srwn_debug_stamp_buffer): waves 0 and 4 of workgroup 0
-  int dbg;                        // timing experiments (SRWN_WT_DEBUG): 1 = skip the dWr contraction, 2 = skip the dWf one
+  int dbg;                        // diagnostic build only (SRWN_WT_DEBUG): 1 = skip the dWr contraction, 2 = skip the dWf one
 };
+#ifdef SRWN_DIAG
+#define WT_DBG(a) ((a).dbg)
+#else
+#define WT_DBG(a) 0      // the shipped kernels carry no wrong-answer switches (and no registers for them)
+#endif
 
 constexpr int kWtPadRows = 64;
 // Two ways of hiding the weight-gradient fragment loads behind the chain, both built and measured, both off: they need
@@ -708,7 +713,7 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
           wg_barrier();
           stamp(21);
           colsum(a.part_br + pslab * R, ktn, false);      // dbr_g = colsum(G_{g+1}) (rows the segment does not own are zero here)
-          if (active && !(a.dbg & 1)) {
+          if (active && !(WT_DBG(a) & 1)) {
             const T* ct = reinterpret_cast<const T*>(a.cT) + (size_t)g * a.wt_stride + (size_t)seg * a.KT * (R * 32);
             // eight tiles' fragments requested at a time, the next eight before the first are used: one or two HBM round
             // trips per loop instead of one per tile (a chain of dependent round trips made this loop cost as much as the
@@ -766,7 +771,7 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
           }
 #pragma unroll
           for (int bb = 0; bb < NBW; ++bb) {
-            if (!(a.dbg & 16)) {
+            if (!(WT_DBG(a) & 16)) {
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) pl[rr * R + 16 * bb] = acc[bb][rr];
             }
@@ -894,7 +899,7 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
         // in the image since the barrier between the phases (its readers only read), x^T comes from the forward kernel's tiles
         const bool active = active5;
         const int tap = tap5, ib = ib5, ob0 = ob5;
-        colsum(a.part_bf + pslab * R, a.dbg & 2 ? 0 : ktn, true);      // dbf_g = colsum(df_g) over the rows the segment owns
+        colsum(a.part_bf + pslab * R, WT_DBG(a) & 2 ? 0 : ktn, true);      // dbf_g = colsum(df_g) over the rows the segment owns
         if (active) {
           const int lw = lw5;
           const int shift = tap == 0 ? d : 0;             // tap 0 multiplies x[t - d]: row s of x meets row s + d of df
@@ -902,8 +907,8 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
 #pragma unroll
           for (int bb = 0; bb < NBF; ++bb) acc[bb] = f32x4{0.f, 0.f, 0.f, 0.f};
           const T* xt = xt5;
-          const int ibl = (a.dbg & 8) ? 0 : ib;     // (timing experiment: every wave loads the same quarter of each tile)
-          const int ktl = (a.dbg & 2) ? 0 : ktn;
+          const int ibl = (WT_DBG(a) & 8) ? 0 : ib;     // (timing experiment: every wave loads the same quarter of each tile)
+          const int ktl = (WT_DBG(a) & 2) ? 0 : ktn;
           const T* dbase = LdT16p<T>::base(img, LS, lw) + (size_t)shift * LS + 16 * ob0;
           Frag<T> av[8], bv[8];
 #pragma unroll
@@ -947,7 +952,7 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
           }
 #pragma unroll
           for (int bb = 0; bb < NBF; ++bb) {
-            if (!(a.dbg & 16)) {
+            if (!(WT_DBG(a) & 16)) {
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) pl[rr * R + 16 * bb] = acc[bb][rr];
             }
@@ -1057,7 +1062,7 @@ int launch_group_bwd(GroupBwdArgs& a, int seg_rows, hipStream_t st) {
   {                                                                                                             \
     auto kfn = two ? group_bwd_kernel<T, RT, D, MT2, NWB, NWV, WT> : group_bwd_kernel<T, RT, D, MAXT, NWB, NWV, WT>; \
     if constexpr (WT && D && sizeof(T) == 2 && RT == 2) {                                                        \
-      if (g_stamps) { a.stamps = g_stamps; kfn = two ? group_bwd_kernel<T, RT, D, MT2, NWB, NWV, WT, true> : group_bwd_kernel<T, RT, D, MAXT, NWB, NWV, WT, true>; } \
+      SRWN_DIAG_ONLY(if (g_stamps) { a.stamps = g_stamps; kfn = two ? group_bwd_kernel<T, RT, D, MT2, NWB, NWV, WT, true> : group_bwd_kernel<T, RT, D, MAXT, NWB, NWV, WT, true>; }) \
     }                                                                                                           \
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);  \
     if (e != hipSuccess) return set_error((int)e, "residual_group_bwd: LDS %zu: %s", sh, hipGetErrorString(e)); \
@@ -1097,8 +1102,8 @@ static int group_bwd_impl(const void* g_top, void* g_out, void* df_out, const vo
   GroupBwdArgs a;
   a.g_top = g_top; a.g_out = g_out; a.df_out = df_out; a.z = z; a.dcs = dcs; a.layer_stride = layer_stride;
   a.xT = a.cT = nullptr; a.wt_stride = 0; a.KT = 0; a.part_f = a.part_r = a.part_bf = a.part_br = nullptr; a.nslabs = 0; a.write_all_g = 0;
-  static const int wt_dbg = [] { const char* e = getenv("SRWN_WT_DEBUG"); return e ? atoi(e) : 0; }();
-  a.dbg = wt_dbg;
+  a.dbg = 0;
+  SRWN_DIAG_ONLY(static const int wt_dbg = [] { const char* e = getenv("SRWN_WT_DEBUG"); return e ? atoi(e) : 0; }(); a.dbg = wt_dbg;)
   a.stamps = nullptr;
   if (wt) {
     a.xT = wt->xT; a.cT = wt->cT; a.wt_stride = wt->wt_stride; a.part_f = wt->part_f; a.part_r = wt->part_r;
@@ -1209,7 +1214,7 @@ static int group_fwd_impl(const void* x0, void* x_out, void* z_out, int64_t laye
       if (R == 32) return launch_group_fwd<bf16_t, 1, 3, 2, 8, true, false, true>(a, any_cond, seg_rows, st);
       // (eight waves of three tiles: twelve waves of 168 registers, the plain kernel's choice, spill 30-47 registers once the
       // tile stores are in the body: 0.43 vs 0.38 ms per step)
-      if (g_stamps) { a.stamps = g_stamps; return launch_group_fwd<bf16_t, 2, 3, 2, 8, true, true, true>(a, any_cond, seg_rows, st); }   // (tools/stamp_probe.py)
+      SRWN_DIAG_ONLY(if (g_stamps) { a.stamps = g_stamps; return launch_group_fwd<bf16_t, 2, 3, 2, 8, true, true, true>(a, any_cond, seg_rows, st); })   // (tools/stamp_probe.py)
       return launch_group_fwd<bf16_t, 2, 3, 2, 8, true, false, true>(a, any_cond, seg_rows, st);
     } else if (dtype == SRWN_F32) {
       if (R == 32) return launch_group_fwd<float, 1, 1, 1, 8, true, false, true>(a, any_cond, seg_rows, st);
@@ -1219,7 +1224,7 @@ static int group_fwd_impl(const void* x0, void* x_out, void* z_out, int64_t laye
   }
   if (dtype == SRWN_BF16) {
     if (R == 32) return launch_group_fwd<bf16_t, 1, 3, 2>(a, any_cond, seg_rows, st);
-    if (g_stamps) { a.stamps = g_stamps; return launch_group_fwd<bf16_t, 2, 3, 2, 8, true, true>(a, any_cond, seg_rows, st); }
+    SRWN_DIAG_ONLY(if (g_stamps) { a.stamps = g_stamps; return launch_group_fwd<bf16_t, 2, 3, 2, 8, true, true>(a, any_cond, seg_rows, st); })
     // (the conditioned body needs 30 registers more than twelve waves leave it -- it spills them -- so it keeps eight
     // waves: the student's step 6.88 -> 6.77 ms)
     if (waves12 && !any_cond) return launch_group_fwd<bf16_t, 2, 2, 2, 12>(a, any_cond, seg_rows, st);
@@ -1320,9 +1325,11 @@ extern "C" int32_t srwn_group_plan(const int32_t* dilations, int32_t nlayers, in
   return n;
 }
 
-// Diagnostic hook (no reference counterpart): registers a device buffer of 1024 uint64; while one is registered, the
-// bf16 R = 64 forward group kernel runs in its stamped instantiation and workgroup 0 appends (tag << 48 | shader clock)
-// at its phase boundaries (tools/stamp_probe.py).  Pass NULL to return to the production instantiation.
+// Diagnostic hook (no reference counterpart), live in the -DSRWN_DIAG build only (libsrwn_diag.so, build.py --diag):
+// registers a device buffer of 1024 uint64; while one is registered, the bf16 R = 64 group kernels, the skip sum and the
+// one-launch head run in their stamped instantiations and workgroup 0 appends (tag << 48 | shader clock) at its phase
+// boundaries (tools/stamp_probe.py).  Pass NULL to return to the production instantiation.  The shipped library holds
+// no stamped instantiation: it accepts NULL and refuses a buffer.
 namespace srwn {
 unsigned long long* debug_stamps() { return g_stamps; }
 int safe_wait() {
@@ -1331,6 +1338,9 @@ int safe_wait() {
 }
 }  // namespace srwn
 extern "C" int srwn_debug_stamp_buffer(void* device_buffer) {
+#ifndef SRWN_DIAG
+  if (device_buffer) return set_error(SRWN_E_UNSUPPORTED, "debug_stamp_buffer: this is the shipped library; build the diagnostic one (build.py --diag) and load it with SRWN_LIB_PATH");
+#endif
   g_stamps = reinterpret_cast<unsigned long long*>(device_buffer);
   return 0;
 }

@@ -314,7 +314,8 @@ extern "C" int srwn_head_chain(const void* r0, const void* w1, const void* w2_pe
            r1, dlogits, da1, dtotal, rows, debug_stamps(), safe_wait()};
   const int64_t tiles = (rows + 31) / 32;
   const size_t sh = kHcBufs * (size_t)(8 * 4 * 1024) + (size_t)kHcWaves * 32 * RowStage<bf16_t>::stride(64) * sizeof(bf16_t) + 2 * 256 * sizeof(float) + (size_t)kHcWaves * 32 * 33;
-  auto kfn = a.stamps ? headchain_kernel<bf16_t, true> : headchain_kernel<bf16_t, false>;
+  auto kfn = headchain_kernel<bf16_t, false>;
+  SRWN_DIAG_ONLY(if (a.stamps) kfn = headchain_kernel<bf16_t, true>;)
   hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
   if (e != hipSuccess) return set_error((int)e, "head_chain: LDS %zu: %s", sh, hipGetErrorString(e));
   hipLaunchKernelGGL(kfn, dim3((unsigned)((tiles + kHcWaves - 1) / kHcWaves)), dim3(64 * kHcWaves), sh,

@@ -16,6 +16,15 @@ int rowgemm_dispatch(const void* x, int64_t x_row_stride, int64_t x_chunk_stride
                      hipStream_t st, int* rc);
 // srwn_group.hip: the buffer registered with srwn_debug_stamp_buffer (nullptr = production kernels)
 unsigned long long* debug_stamps();
+// Diagnostic build: `python sr-wavenet_amd/build.py --diag` compiles every source with -DSRWN_DIAG into libsrwn_diag.so
+// (loaded with SRWN_LIB_PATH).  Only that library holds the stamped kernel instantiations and the timing-ablation switch
+// SRWN_WT_DEBUG (under which results are wrong by design); the shipped libsrwn.so has neither, and its
+// srwn_debug_stamp_buffer refuses a buffer.
+#ifdef SRWN_DIAG
+#define SRWN_DIAG_ONLY(...) __VA_ARGS__
+#else
+#define SRWN_DIAG_ONLY(...)
+#endif
 // SRWN_SAFE_WAIT=1: every hand-counted s_waitcnt vmcnt(N) of the kernels becomes vmcnt(0) (a test runs both and compares
 // bits: a count that a compiler change had made too large would show there)
 int safe_wait();

@@ -192,8 +192,11 @@ __global__ __launch_bounds__(512) void wgrad_skip_wt_kernel(WtSkipArgs a) {
   // the barrier publishes that tile and frees the one read an iteration ago
 #define SRWN_WT_ITER(IT, ACUR, ANEW)                                                                            \
   {                                                                                                             \
+    /* ONE statement defines the landed fragments on every path: two alternative ones (a full drain under SRWN_SAFE_WAIT) \
+       made the compiler place the copies that reconcile them BEFORE the wait of one branch -- reads of registers whose  \
+       load was still in flight (found by build.py's asmcheck).  The full drain follows the counted wait instead. */    \
+    asm volatile("s_waitcnt vmcnt(6)" : "+v"(ACUR[0]), "+v"(ACUR[1]), "+v"(ACUR[2]), "+v"(ACUR[3])::"memory");       \
     if (a.safe_wait) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ACUR[0]), "+v"(ACUR[1]), "+v"(ACUR[2]), "+v"(ACUR[3])::"memory"); \
-    else asm volatile("s_waitcnt vmcnt(6)" : "+v"(ACUR[0]), "+v"(ACUR[1]), "+v"(ACUR[2]), "+v"(ACUR[3])::"memory"); \
     wg_barrier();                                                                                               \
     load_a(ca, ANEW); advance(ca);                                                                              \
     dma_tile(cd, ((IT) + 3) & (kNB - 1)); advance(cd);                                                          \

@@ -87,7 +87,7 @@ class _Span:
 
 class WaveNetEngine:
     def __init__(self, cfg: StackConfig, batch: int, length: int, device="cuda", seed: int = 0,
-                 process_group=None, share_from: Optional["WaveNetEngine"] = None):
+                 process_group=None, share_from: Optional["WaveNetEngine"] = None, frozen: bool = False):
         if cfg.filter_width != 2:
             raise NotImplementedError("filter_width %d: only 2 is built (reference default, model.py:9)" % cfg.filter_width)
         if cfg.dilation_channels not in (32, 64):
@@ -111,16 +111,16 @@ class WaveNetEngine:
         fuse = _os.environ.get("SRWN_FUSE", "1")
         self.fuse_fwd = fuse not in ("0", "bwd")
         self.fuse_bwd = fuse not in ("0", "fwd")
-        # SRWN_FUSE_WG=1: layer weight gradients inside a one-wave-per-SIMD backward group kernel (csrc/srwn_groupw.hip):
-        # df and G never reach HBM (-1.9 GB per step), but the kernel is slower than the chain kernel + the separate
-        # weight-gradient pass it replaces (182 vs 83 + 77 us per group) -> off by default
-        self.fuse_wg = _os.environ.get("SRWN_FUSE_WG", "0") != "0"
         # SRWN_FUSE_WT=1 (default): layer weight gradients inside the 8-wave backward group kernel, split by output over
         # the waves; the forward group kernel writes the transposed operands ("weight-gradient tiles") they need
         # (csrc/srwn_group.hip, _wt entry points).  0: chain kernel + separate weight-gradient pass (the parity twin)
         self.fuse_wt = _os.environ.get("SRWN_FUSE_WT", "1") != "0"
         self.wt_store_x = _os.environ.get("SRWN_WT_STORE_X", "0") != "0"
-        self.frozen = False   # forward-only use (set by StudentEngine for its teacher): no weight-gradient tiles written
+        # frozen: a stack that is never trained (a distillation teacher, model.py:334): fixed before allocation, so no
+        # weight-gradient tiles / per-workgroup partial slabs are allocated for it and backward() refuses to run.  A
+        # trainable stack can still be run forward-only (forward(train=False): the student does that to its teacher).
+        self.frozen = bool(frozen)
+        self._tiles_valid = False
         # weight-gradient passes on a side stream beside the data-gradient chain: worth 11 % with one launch per layer
         # (short latency-bound chain kernels), but with the group kernels every kernel of the backward phase is
         # bandwidth-bound and running two at once is slower than one after the other (2.15 vs 2.13 ms; the skip data
@@ -414,6 +414,9 @@ class WaveNetEngine:
         self.use_wl = (R in (32, 64) and self.Kw == 2)
         self.use_dcs = (R, self.S) in ((64, 256), (32, 128))
         import os as _os
+        # decided ONCE, before anything is sized (the tiles, the partial slabs and the skip weight-gradient path follow it)
+        self._fused_wt = (self.fuse_wt and self.fuse_fwd and self.fused_bwd and self.cfg.head_mode != "flow"
+                          and not self.frozen)
         if self.fused_wt:
             # weight-gradient tiles of every layer (written by the forward group kernels, read by the backward ones) and one
             # partial slab per workgroup of the backward kernels (slabs a group does not reach stay zero)
@@ -426,9 +429,6 @@ class WaveNetEngine:
             # per layer: the stride and segment length of its group (what fixes the positions its tiles hold)
             self.wt_layer_st = [math.gcd(*self.dil[l0:l1]) for l0, l1 in self.groups for _ in range(l0, l1)]
             self.wt_layer_seg = [self.wt_seg_rows[i] for i, (l0, l1) in enumerate(self.groups) for _ in range(l0, l1)]
-        elif self.fused_wg:
-            # one partial per workgroup of the fused backward kernel (slabs it does not reach stay zero)
-            self.nslabs = K.group_wgrad_slabs()
         elif self.use_wl and self.fuse_bwd and "SRWN_WG_SLAB_ROWS" not in _os.environ and self.groups:
             # the layer weight-gradient pass is launched per layer group with one workgroup per (layer, slab): cut the
             # rows so that the widest group's launch is one workgroup per CU (5-layer groups at 3072 rows per slab left
@@ -513,9 +513,10 @@ class WaveNetEngine:
             self.cond_in.zero_()
             self.cond_in[:, :self.E].copy_(cond.reshape(self.B * self.frames, self.E))
 
-    def forward(self, want_logits: bool = False, with_loss: bool = True) -> Optional[torch.Tensor]:
+    def forward(self, want_logits: bool = False, with_loss: bool = True, train: bool = True) -> Optional[torch.Tensor]:
         """Runs the stack on the staged inputs; leaves loss in self.loss and dlogits for backward.
-        Returns fp32 per-time-step logits [B,T,C] when want_logits."""
+        Returns fp32 per-time-step logits [B,T,C] when want_logits.  train=False: forward only (no weight-gradient tiles
+        are written; backward() refuses to follow such a pass)."""
         B, T, N, L, R, S = self.B, self.T, self.N, self.L, self.R, self.S
         es = self.packed.element_size()
         v = self.view
@@ -524,8 +525,9 @@ class WaveNetEngine:
                             1 if self.cfg.shift_input else 0, out=self.xs[0])
         if self.E:
             self._cond_bias_to_input()
+        self._tiles_valid = bool(train) and self.fused_wt
         with _Span(self, "fwd_layers"):
-            self._stack_fwd(self.cond_all if self.E else None)
+            self._stack_fwd(self.cond_all if self.E else None, wt=self._tiles_valid)
         K.reduce_partials(v("BS").reshape(-1), L, S, 1, True, 1.0, self.bs_sum.data_ptr(), 0)
         with _Span(self, "skip_sum"):
             K.pw_linear(self.zs.data_ptr(), R, N * R, R, L * R, self.wptr(self.o_skip), self.bs_sum, self.r0, S, S,
@@ -594,26 +596,29 @@ class WaveNetEngine:
         call("srwn_add_frame_bias", self.xs[0].data_ptr(), self.cond_all.data_ptr(), R, self.B, self.T, R,
              self.frames, self.cfg.pool_stride, K.abi_dtype(self.dt), st)
 
-    def _stack_fwd(self, cond_all: Optional[torch.Tensor]):
-        """The residual layers (model.py:42-47 / 176-189 / 428-453): xs[0] -> xs[1..L], zs[0..L-1]."""
+    def _stack_fwd(self, cond_all: Optional[torch.Tensor], wt: Optional[bool] = None):
+        """The residual layers (model.py:42-47 / 176-189 / 428-453): xs[0] -> xs[1..L], zs[0..L-1].
+        wt: also write the weight-gradient tiles (default: whenever the backward pass reads them)."""
+        wt = self.fused_wt if wt is None else (wt and self.fused_wt)
         if self.fuse_fwd:
             for l0, l1 in self.groups:      # runs of layers whose outputs travel between layers in LDS
-                if l1 - l0 >= 2 or self.fused_wt:
-                    self._group_fwd(l0, l1, cond_all)
+                if l1 - l0 >= 2 or wt:
+                    self._group_fwd(l0, l1, cond_all, wt)
                 else:
                     self._layer_fwd(l0, cond_all)
         else:
             for l in range(self.L):
                 self._layer_fwd(l, cond_all)
 
-    def _group_fwd(self, l0: int, l1: int, cond_all: Optional[torch.Tensor]):
+    def _group_fwd(self, l0: int, l1: int, cond_all: Optional[torch.Tensor], use_wt: bool = True):
         """Layers [l0, l1) in one launch (srwn_residual_group_fwd); same stored xs / zs as the per-layer path."""
         v = self.view
         cond3 = None
         if cond_all is not None:      # layer l adds the bias of layer l + 1 onto its output
             cond3 = [cond_all[l + 1].view(self.B, self.frames, self.R) if l + 1 < self.L else None for l in range(l0, l1)]
         wt = {}
-        if self.fused_wt:
+        use_wt = use_wt and self.fused_wt
+        if use_wt:
             # (xs of the layers inside a group is NOT written in this mode: only the weight gradients would read it, and they
             # take the transposed tiles; SRWN_WT_STORE_X=1 keeps it for inspection)
             wt = dict(xT=self.xTs[l0:l1], cT=self.cTs[l0:l1], store_inner_x=self.wt_store_x)
@@ -623,7 +628,7 @@ class WaveNetEngine:
                              [v("BF")[l] for l in range(l0, l1)], [v("BR")[l] for l in range(l0, l1)],
                              self.dil[l0:l1], self.Kw, cond=cond3,
                              pool_stride=self.cfg.pool_stride,
-                             seg_rows=self.wt_seg_rows[self.groups.index((l0, l1))] if self.fused_wt else self.seg_rows, **wt)
+                             seg_rows=self.wt_seg_rows[self.groups.index((l0, l1))] if use_wt else self.seg_rows, **wt)
 
     def _layer_fwd(self, l: int, cond_all: Optional[torch.Tensor]):
         v = self.view
@@ -647,6 +652,10 @@ class WaveNetEngine:
         short per-layer dgrad kernels.  Joined before the optimizer.  SRWN_OVERLAP=0 serialises everything."""
         B, T, N, L, R, S, Kw = self.B, self.T, self.N, self.L, self.R, self.S, self.Kw
         dt = self.dt
+        if self.frozen:
+            raise RuntimeError("backward: this stack was built frozen (forward only)")
+        if self.fused_wt and not self._tiles_valid:
+            raise RuntimeError("backward: the last forward pass ran with train=False and wrote no weight-gradient tiles")
         main = torch.cuda.current_stream()
         overlap = self.overlap and not self.timing
         side = self.side if overlap else main
@@ -674,9 +683,6 @@ class WaveNetEngine:
                 if self.fused_wt:
                     self._group_bwd_wt(l0, l1)
                     continue
-                if self.fused_wg:
-                    self._group_bwd_wg(l0, l1)
-                    continue
                 self._group_bwd(l0, l1)
                 if not self.timing:
                     if overlap:
@@ -690,7 +696,7 @@ class WaveNetEngine:
                 if overlap:
                     main.wait_stream(side)
                 return
-            if self.timing and not (self.fused_wg or self.fused_wt):
+            if self.timing and not self.fused_wt:
                 for g in groups:
                     self._wgrad_layers_group(*g)
             with torch.cuda.stream(side):
@@ -745,18 +751,13 @@ class WaveNetEngine:
         return self.fuse_bwd and self.use_wl and (getattr(self, "use_dcs", False) or self.cfg.head_mode == "flow")
 
     @property
-    def fused_wg(self) -> bool:
-        """The layer weight gradients are summed inside the one-wave-per-SIMD backward group kernel (srwn_groupw.hip)."""
-        return self.fuse_wg and self.fused_bwd and not self.fused_wt
-
-    @property
     def fused_wt(self) -> bool:
         """The layer weight gradients are summed inside the backward group kernel from the forward kernel's weight-gradient
         tiles (no df / G round trip through HBM, no separate weight-gradient pass)."""
         # (not for the flows of the student: they carry no skip path and write every layer's input gradient for the
         # conditioning 1x1 anyway -- measured: their backward gains nothing and their forward pays for the tiles,
         # 7.09 vs 6.77 ms per distillation step -- and not for a stack that is never trained: StudentEngine's teacher)
-        return self.fuse_wt and self.fuse_fwd and self.fused_bwd and self.cfg.head_mode != "flow" and not self.frozen
+        return self._fused_wt
 
     def _group_bwd_wt(self, l0: int, l1: int):
         """Chain + weight-gradient partials of layers [l0, l1) in one launch (srwn_residual_group_bwd_wt)."""
@@ -771,20 +772,6 @@ class WaveNetEngine:
                                     self.pl_f[l0 * ns * 2 * R * R:], self.pl_r[l0 * ns * R * R:],
                                     self.pl_bf[l0 * ns * R:], self.pl_br[l0 * ns * R:], ns,
                                     self.wt_seg_rows[self.groups.index((l0, l1))], self.Kw, write_all_g=bool(self.E))
-
-    def _group_bwd_wg(self, l0: int, l1: int):
-        """Chain + weight-gradient partials of layers [l0, l1) in one launch (srwn_residual_group_bwd_wgrad)."""
-        flow = self.cfg.head_mode == "flow"
-        R, ns = self.R, self.nslabs
-        g_top = self.gs[l1] if (flow or l1 < self.L) else None
-        with _Span(self, "group_bwd_wg"):
-            K.residual_group_bwd_wgrad(g_top, self.gs[l0:l1], self.xs[l0:l1], self.zs[l0:l1],
-                                       None if flow else self.dcs[l0:l1],
-                                       [self.wptr(self.o_convT[l]) for l in range(l0, l1)],
-                                       [self.wptr(self.o_resT[l]) for l in range(l0, l1)], self.dil[l0:l1],
-                                       self.pl_f[l0 * ns * 2 * R * R:], self.pl_r[l0 * ns * R * R:],
-                                       self.pl_bf[l0 * ns * R:], self.pl_br[l0 * ns * R:], ns, self.Kw,
-                                       seg_rows=self.seg_rows, write_all_g=bool(self.E))
 
     def _group_bwd(self, l0: int, l1: int):
         flow = self.cfg.head_mode == "flow"

@@ -342,45 +342,6 @@ def residual_group_bwd(g_top: Optional[torch.Tensor], g_out: torch.Tensor, df_ou
          R, int(K), int(seg_rows), dt, _stream())
 
 
-def group_wgrad_slabs() -> int:
-    """Partial slabs per layer a `residual_group_bwd_wgrad` launch may write (one per workgroup it starts)."""
-    from ._lib import load
-    return int(load().srwn_group_wgrad_slabs())
-
-
-def residual_group_bwd_wgrad(g_top: Optional[torch.Tensor], g_out: torch.Tensor, x: torch.Tensor, z: torch.Tensor,
-                             dcs: Optional[torch.Tensor], wconvT_ptrs, wresT_ptrs, dilations, part_f: torch.Tensor,
-                             part_r: torch.Tensor, part_bf: torch.Tensor, part_br: torch.Tensor, nslabs: int,
-                             K: int = 2, seg_rows: int = 0, write_all_g: bool = False):
-    """Backward chain of a layer group + its layer weight-gradient partials in one launch.
-    g_out / x / z / dcs: [n,B,T,R] stacks (views of the engine's gs[l0:], xs[l0:], zs[l0:], dcs[l0:]); part_*: fp32 partial
-    buffers starting at the group's first layer, [n][nslabs][2RR | RR | R | R]."""
-    import ctypes as C
-    n = len(dilations)
-    _, B, T, R = z.shape
-    if not (len(wconvT_ptrs) == len(wresT_ptrs) == n):
-        raise ValueError("residual_group_bwd_wgrad: per-layer argument lists differ in length")
-    dt = abi_dtype(z.dtype)
-    for name, t in (("x", x), ("z", z)) + ((("dcs", dcs),) if dcs is not None else ()):
-        _chk(t, name, z.dtype)
-        if t.dim() != 4 or t.shape[0] < n or tuple(t.shape[1:]) != (B, T, R):
-            raise ValueError("%s: shape %s, expected [>=%d,%d,%d,%d]" % (name, tuple(t.shape), n, B, T, R))
-    _chk(g_out, "g_out", z.dtype)
-    if g_out.dim() != 4 or g_out.shape[0] < (n if write_all_g else 1) or tuple(g_out.shape[1:]) != (B, T, R):
-        raise ValueError("g_out: shape %s" % (tuple(g_out.shape),))
-    for name, t, per in (("part_f", part_f, 2 * R * R), ("part_r", part_r, R * R), ("part_bf", part_bf, R),
-                         ("part_br", part_br, R)):
-        _chk(t, name, torch.float32)
-        if t.numel() < n * nslabs * per:
-            raise ValueError("%s: %d floats, needs %d" % (name, t.numel(), n * nslabs * per))
-    pg = _opt(g_top, "g_top", z.dtype, (B, T, R))
-    dl = (C.c_int32 * n)(*[int(d) for d in dilations])
-    call("srwn_residual_group_bwd_wgrad", pg, g_out.data_ptr(), 1 if write_all_g else 0, x.data_ptr(), z.data_ptr(),
-         None if dcs is None else dcs.data_ptr(), B * T * R, _ptr_array(wconvT_ptrs), _ptr_array(wresT_ptrs), dl, n,
-         part_f.data_ptr(), part_r.data_ptr(), part_bf.data_ptr(), part_br.data_ptr(), int(nslabs), B, T, R, int(K),
-         int(seg_rows), dt, _stream())
-
-
 # ----------------------------------------------------------------------------------------------
 # pointwise linear and the fused softmax head
 # ----------------------------------------------------------------------------------------------

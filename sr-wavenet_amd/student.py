@@ -209,9 +209,6 @@ class FlowStack(WaveNetEngine):
                 if self.fused_wt:       # ... that also sums the group's weight gradients (srwn_residual_group_bwd_wt)
                     self._group_bwd_wt(l0, l1)
                     continue
-                if self.fused_wg:
-                    self._group_bwd_wg(l0, l1)
-                    continue
                 self._group_bwd(l0, l1)
                 if overlap:
                     ev = torch.cuda.Event()
@@ -314,14 +311,12 @@ class StudentEngine:
         B, T, N = self.B, self.T, self.N
         tch = self.teacher
         main = torch.cuda.current_stream()
-        was_frozen, tch.frozen = tch.frozen, True   # forward only (stop_gradient, model.py:334): no weight-gradient tiles
         if self.tstream is not None:   # the frozen teacher depends on (truth, encoding) only: run it beside the flows
             self.tstream.wait_stream(main)
             with torch.cuda.stream(self.tstream):
-                tch.forward(with_loss=False)                           # logits32 [N, 4M] on RightShift(truth)
-        else:
-            tch.forward(with_loss=False)
-        tch.frozen = was_frozen
+                tch.forward(with_loss=False, train=False)              # logits32 [N, 4M] on RightShift(truth); forward only
+        else:                                                          # (stop_gradient, model.py:334): no weight-gradient tiles
+            tch.forward(with_loss=False, train=False)
         self.forward_flows()
         K.stft_power(self.truth, None, self.fpow, self.pow_truth)      # model.py:360,367
         K.stft_power(self.out.view(B, T), self.spec, self.fpow, self.pow_out)

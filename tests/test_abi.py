@@ -120,3 +120,33 @@ def test_product_does_not_import_the_oracle():
         if "from oracle" in chunk or "import oracle" in chunk:
             assert chunk.startswith("cpu_baseline("), "bench.py imports the oracle outside cpu_baseline: def " + chunk[:40]
     assert "oracle" not in bench.split("\ndef ")[0].replace("oracle ii", "").replace("(oracle", ""), "bench.py: module-level oracle import"
+
+
+def test_shipped_library_has_no_wrong_answer_switches():
+    """The timing-ablation switch of the backward group kernel (SRWN_WT_DEBUG: skips a contraction loop or a partial
+    store -- results are wrong by design) and the stamped kernel instantiations live in the -DSRWN_DIAG build only
+    (libsrwn_diag.so): the shipped library neither reads that variable nor accepts a stamp buffer."""
+    L = sub("_lib")
+    blob = open(os.path.join(ROOT, "sr-wavenet_amd", "libsrwn.so"), "rb").read()
+    for name in (b"SRWN_WT_DEBUG", b"SRWN_GW_MASK", b"SRWN_FUSE_WG"):
+        assert name not in blob, name
+    lib = L.bind("ctypes")
+    assert lib.srwn_debug_stamp_buffer(None) == 0
+    assert lib.srwn_debug_stamp_buffer(4096) == -4 and b"diagnostic" in lib.srwn_last_error()
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "sr-wavenet_amd")):
+        for fn in files:
+            if fn.endswith(".py") and fn != "build.py":      # (build.py's docstring names what the --diag build holds)
+                assert "SRWN_WT_DEBUG" not in open(os.path.join(dirpath, fn)).read(), fn
+
+
+def test_build_decides_staleness_from_recorded_hashes(tmp_path):
+    """build.py recompiles a source when the sha256 of (source + headers + flags) differs from the one its object was
+    compiled from -- not when an mtime is newer -- and records a hash per object only after compiling it."""
+    import json
+    B = sub("build")
+    man = json.load(open(B.MANIFEST))
+    assert set(man["objects"]) == {s for s in B.SOURCES}
+    deps = sorted(B._deps())
+    for s in B.SOURCES:
+        assert man["objects"][s] == B._sha([os.path.join(B.CSRC, s)] + deps, " ".join(B.FLAGS)), s
+    assert man["sources"] == B.source_hashes()

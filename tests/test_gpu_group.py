@@ -13,27 +13,24 @@ from tests.test_gpu_kernels import DEV
 pytestmark = pytest.mark.gpu
 
 
-def _pair(monkeypatch, dil, B, T, R, S, C, dt, E=0, pool=1, seg_rows=0, seed=3, fuse_wg="0", ref_fuse="0", fuse_wt="0"):
-    """The same model twice: one launch per layer (SRWN_FUSE=0) and the multi-layer kernels.  fuse_wg = "1": the
-    second model also sums the layer weight gradients inside its backward group kernel (srwn_groupw.hip); fuse_wt =
-    "1": the same inside the 8-wave backward group kernel from the forward kernel's weight-gradient tiles (the default
-    path of the engine); ref_fuse = "1" makes the first model the group kernels + the separate weight-gradient pass
-    (those kernels' direct twin)."""
+def _pair(monkeypatch, dil, B, T, R, S, C, dt, E=0, pool=1, seg_rows=0, seed=3, ref_fuse="0", fuse_wt="0"):
+    """The same model twice: one launch per layer (SRWN_FUSE=0) and the multi-layer kernels.  fuse_wt = "1": the second
+    model also sums the layer weight gradients inside its 8-wave backward group kernel from the forward kernel's
+    weight-gradient tiles (the default path of the engine); ref_fuse = "1" makes the first model the group kernels + the
+    separate weight-gradient pass (those kernels' direct twin)."""
     EG = sub("engine")
     cfg = EG.StackConfig(dilations=list(dil), dilation_channels=R, skip_channels=S, output_channels=C,
                          cond_channels=E, pool_stride=pool, shift_input=True, dtype=dt)
     monkeypatch.setenv("SRWN_WG_SLAB_ROWS", "3072")   # the same partial-sum slabs on both sides (the fused path sizes its own)
     monkeypatch.setenv("SRWN_FUSE", ref_fuse)
-    monkeypatch.setenv("SRWN_FUSE_WG", "0")
     monkeypatch.setenv("SRWN_FUSE_WT", "0")
     monkeypatch.setenv("SRWN_SEG_ROWS", str(seg_rows))
     ref = EG.WaveNetEngine(cfg, B, T, DEV, seed=seed)
     monkeypatch.setenv("SRWN_FUSE", "1")
-    monkeypatch.setenv("SRWN_FUSE_WG", fuse_wg)
     monkeypatch.setenv("SRWN_FUSE_WT", fuse_wt)
     monkeypatch.setenv("SRWN_WT_STORE_X", "0")     # (the production setting: inner layers' input rows are not stored)
     fus = EG.WaveNetEngine(cfg, B, T, DEV, seed=seed)
-    assert ref.fuse_fwd == (ref_fuse == "1") and fus.fuse_fwd and not ref.fused_wg
+    assert ref.fuse_fwd == (ref_fuse == "1") and fus.fuse_fwd
     # biases are zero at init (tf.layers.conv1d defaults): make every one of them count
     g = torch.Generator(device="cpu").manual_seed(seed)
     for name in ("BF", "BR", "BS", "init_b", "head_b1"):
@@ -283,44 +280,6 @@ def test_group_wt_conditioned(monkeypatch, dt):
     dil = [1, 2, 4, 8, 16, 32, 64]
     ref, fus = _pair(monkeypatch, dil, 2, 400, 64, 256, 64, dt, E=16, pool=8, seg_rows=128, fuse_wt="1", ref_fuse="1")
     assert fus.fused_wt
-    for e in (ref, fus):
-        e.forward(); e.backward()
-    torch.cuda.synchronize()
-    for l in range(len(dil)):
-        assert torch.equal(ref.gs[l], fus.gs[l]), "G of layer %d" % l
-    gr, gf = ref.named_tensors(ref.grads), fus.named_tensors(fus.grads)
-    tol = 2e-5 if dt == torch.float32 else 4e-3
-    for n in gr:
-        assert _rel(gf[n], gr[n]) < tol, "%s: %g" % (n, _rel(gf[n], gr[n]))
-
-
-@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("dil,B,T,R,S,seg", SHAPES)
-def test_group_backward_with_weight_gradients_equals_twin(monkeypatch, dt, dil, B, T, R, S, seg):
-    """srwn_residual_group_bwd_wgrad (chain + layer weight gradients in one launch, df / G never stored) against the
-    chain kernel followed by srwn_wgrad_layers: the chain is the same arithmetic (the groups' bottom gradients agree bit
-    for bit), the weight gradients are the same products summed per segment instead of per slab of rows."""
-    ref, fus = _pair(monkeypatch, dil, B, T, R, S, 64, dt, seg_rows=seg, fuse_wg="1", ref_fuse="1")
-    assert fus.fused_wg and ref.fused_bwd and not ref.fused_wg
-    for e in (ref, fus):
-        e.forward(); e.backward()
-    torch.cuda.synchronize()
-    for l0, _ in fus.groups:
-        assert torch.equal(ref.gs[l0], fus.gs[l0]), "bottom gradient of the group at layer %d" % l0
-    gr, gf = ref.named_tensors(ref.grads), fus.named_tensors(fus.grads)
-    tol = 2e-5 if dt == torch.float32 else 4e-3      # same operands; only the order of the fp32 sums differs
-    for n in gr:
-        assert torch.isfinite(gf[n]).all(), n
-        assert _rel(gf[n], gr[n]) < tol, "%s: %g" % (n, _rel(gf[n], gr[n]))
-
-
-@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-def test_group_backward_with_weight_gradients_conditioned(monkeypatch, dt):
-    """Conditioned decoder (model.py:176-189): the fused kernel also writes every layer's input gradient (the
-    conditioning 1x1's gradient is their per-frame sum)."""
-    dil = [1, 2, 4, 8, 16, 32, 64]
-    ref, fus = _pair(monkeypatch, dil, 2, 400, 64, 256, 64, dt, E=16, pool=8, seg_rows=128, fuse_wg="1", ref_fuse="1")
-    assert fus.fused_wg
     for e in (ref, fus):
         e.forward(); e.backward()
     torch.cuda.synchronize()

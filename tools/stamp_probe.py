@@ -3,6 +3,8 @@
 import importlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# the stamped kernel instantiations live in the diagnostic build only (python sr-wavenet_amd/build.py --diag)
+os.environ.setdefault("SRWN_LIB_PATH", os.path.join(ROOT, "sr-wavenet_amd", "libsrwn_diag.so"))
 import torch
 EG = importlib.import_module("sr-wavenet_amd.engine")
 KN = importlib.import_module("sr-wavenet_amd.kernels")
