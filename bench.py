@@ -124,10 +124,14 @@ def generation_leg(nsteps=256):
     for name, B in (("1wg", 32), ("2048", 2048)):
         eng.generate(64, batch=B)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        eng.generate(nsteps, mode="sample", seed=1, batch=B)
-        torch.cuda.synchronize()
-        out[name] = (time.perf_counter() - t0) / nsteps * 1e6
+        best = None
+        for _ in range(3):      # (the call allocates its rings -- 0.8 GB for 2048 streams -- on the way: a pass that misses the
+            t0 = time.perf_counter()      # caching allocator pays a hipMalloc of that size; the fastest of three is the kernel)
+            eng.generate(nsteps, mode="sample", seed=1, batch=B)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / nsteps * 1e6
+            best = dt if best is None else min(best, dt)
+        out[name] = best
     return out
 
 
@@ -152,6 +156,9 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     ndev = torch.cuda.device_count()
+    backend = os.environ.get("SRWN_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+    if world > 1 and backend == "nccl" and local >= ndev:
+        raise SystemExit("LOCAL_RANK %d but %d visible GPUs: RCCL needs one distinct device per local rank" % (local, ndev))
     local = local % max(ndev, 1)   # (rehearsal: several ranks may share one GPU with SRWN_DIST_BACKEND=gloo)
     torch.cuda.set_device(local)
     dist = None
@@ -160,9 +167,18 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = os.environ.get("SRWN_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
         kw = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+        # what the line below reports is only a scaling figure if the job is what --gpus says it is
+        if dist.get_world_size() != max(args.gpus, 1) and world > 1:
+            raise SystemExit("process group has %d ranks but --gpus %d" % (dist.get_world_size(), args.gpus))
+        if backend == "nccl" and world > 1:     # one distinct device per rank of this node (a wrapped LOCAL_RANK would
+            mine = torch.tensor([local], device="cuda", dtype=torch.int64)      # put two ranks on one card)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            ids = [int(t.item()) for t in every]
+            if len(set(ids)) != world:
+                raise SystemExit("ranks share devices: %s" % ids)
 
     EG = importlib.import_module("sr-wavenet_amd.engine")
     KN = importlib.import_module("sr-wavenet_amd.kernels")
@@ -209,6 +225,37 @@ def main():
         dt_s = float(tt.item())
     loss = float(eng.loss.item())
 
+    # ---- multi-rank only, outside the timed region: how much of the gradient all-reduce the schedule leaves EXPOSED --
+    # the time the launch stream spends in the collectives after the lower backward graph has finished (all of bucket B
+    # plus whatever tail of bucket A the lower backward did not cover); with one bucket, the whole all-reduce.  HIP
+    # events on the launch stream around the collective calls of a few extra replayed steps.
+    graphs_per_step, allreduce_exposed_us, allreduce_bytes = None, None, None
+    if use_graph:
+        graphs_per_step = 1 + (eng._g_b2 is not None) + (eng._g_opt is not None)
+    if dist is not None and use_graph and eng._g_opt is not None:
+        ts = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            eng._g_fb.replay()
+            if eng._g_b2 is not None:
+                h = eng._allreduce_bucket_a()
+                eng._g_b2.replay()
+                e0.record()
+                eng._allreduce_bucket_b(h)
+                e1.record()
+            else:
+                e0.record()
+                eng.allreduce_grads()
+                e1.record()
+            eng._g_opt.replay()
+            e1.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e3)
+        tt = torch.tensor([float(np.median(ts))], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        allreduce_exposed_us = float(tt.item())
+        allreduce_bytes = {"bucket_a_overlapped": 4 * (eng.nparams - eng.bucket_off) if eng._g_b2 is not None else 0,
+                           "bucket_b_exposed": 4 * (eng.bucket_off if eng._g_b2 is not None else eng.nparams)}
+
     # ---- roofline of the dominant kernel: HIP events on the launch stream, eager launches
     eng.timing = True
     eng.spans.clear()
@@ -250,16 +297,30 @@ def main():
     #  SRWN_FUSE=0: layer_bwd_kernel, one launch per layer: reads G_{l+2}, df_{l+1}, dcs_l, z_l, writes G_{l+1}, df_l.
     fused = eng.fused_bwd
     cfg_key = "config: %s B=%d T=%d L=%d R=%d S=%d" % (args.dtype, B, T, L, R, S)
+    # The operand list behind bytes_per_launch is stated in the line (roofline.operands), and the same figure over the
+    # MINIMAL operand set beside it (frac_min_operands): c^T is z sigmoid(z) stored a second time in another layout, so
+    # counting it raises the algorithmic bytes without being information the kernel could not have derived.
     if fused:
         ngr = len(eng.groups)
         extra = 1.0 if eng.fused_wt else 0.0      # (the bottom gradient; without the weight gradients it is one of the 4)
         bwd_bytes_step = sum((4.0 * (l1 - l0) + extra + (1.0 if l1 < L else 0.0)) * R * es * N for l0, l1 in eng.groups)
         nlaunch, kname = ngr, "group_bwd_kernel"
         traffic, traffic_src = profiled_traffic("group_bwd_kernel", cfg_key + (" wt=1" if eng.fused_wt else " wt=0"))
+        if eng.fused_wt:
+            operands = ("per layer and sample row: z, dcs, x^T tile, c^T tile read (4 x R x %d B); per launch: the group's "
+                        "top gradient read (where there is one), its bottom gradient written (R x %d B each); the fp32 "
+                        "weight-gradient partials it leaves are in `traffic`, not here" % (es, es))
+            min_bytes_step = sum((3.0 * (l1 - l0) + 1.0 + (1.0 if l1 < L else 0.0)) * R * es * N for l0, l1 in eng.groups)
+            operands_min = "x, z, dcs per layer (c^T = z sigmoid(z) is derivable from z) + top gradient in + bottom gradient out"
+        else:
+            operands = "per layer and sample row: z, dcs read, df, G written (4 x R x %d B); per launch: the top gradient read" % es
+            min_bytes_step, operands_min = bwd_bytes_step, "the same"
     else:
         bwd_bytes_step = 6.0 * R * es * N * (L + 1)
         nlaunch, kname = L + 1, "layer_bwd_kernel"
         traffic, traffic_src = profiled_traffic("layer_bwd_kernel", cfg_key + " fuse=0")
+        operands = "per launch and sample row: G_{l+2}, df_{l+1}, dcs_l, z_l read, G_{l+1}, df_l written (6 x R x %d B)" % es
+        min_bytes_step, operands_min = bwd_bytes_step, "the same"
     bwd_launch_ms = spans["bwd_layers"] / nlaunch
     eager_launch_us = 1e3 * bwd_launch_ms
     # The eager passes above put an event pair around every launch (the per-kernel spans), and each event is a packet
@@ -298,7 +359,10 @@ def main():
                 # MI355X_MICROARCH.md), read at run time from the tracked profile named in traffic_source (null when
                 # no tracked profile covers this configuration); not measured in this run
                 "traffic": traffic, "traffic_source": traffic_src,
-                "bytes_per_launch": bwd_bytes_step / nlaunch, "launch_us": 1e3 * bwd_launch_ms,
+                "bytes_per_launch": bwd_bytes_step / nlaunch, "operands": operands,
+                "bytes_per_launch_min_operands": min_bytes_step / nlaunch, "operands_min": operands_min,
+                "frac_min_operands": min_bytes_step / nlaunch / (bwd_launch_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                "launch_us": 1e3 * bwd_launch_ms,
                 "launch_us_eager_with_span_events": eager_launch_us,
                 # the same launches timed inside the schedule the timed region replays (weight-gradient passes running
                 # beside them on the side stream): what the kernel costs in the step, vs. alone on the chip above
@@ -324,10 +388,16 @@ def main():
             "config": {"workload": "30-layer teacher WaveNet (3x[1..512] dilations, 64 res / 256 skip ch, 256-way "
                                    "mu-law softmax), fwd+bwd+Adam, batch %dx%d samples per GPU" % (B, T),
                        "global_batch": world * B, "seq_len": T, "parallelism": "dp%d" % world,
-                       "launch": "hipGraph" if use_graph else "eager", "final_loss": loss},
+                       "launch": "hipGraph" if use_graph else "eager", "graphs_per_step": graphs_per_step,
+                       "final_loss": loss},
             "roofline": roofline,
             "roofline_gemm": roofline_gemm,
         }
+        if dist is not None:
+            # (not part of `value`: measured on extra steps after the timed region)
+            out["allreduce_exposed_us"] = allreduce_exposed_us
+            out["allreduce_bytes"] = allreduce_bytes
+            out["dist_backend"] = dist.get_backend()
         if not args.no_extras and world == 1 and args.dtype == "bf16":
             # after (and outside) the timed region: BASELINE configs[3] and [4] at their one-GPU shapes
             del eng

@@ -19,8 +19,13 @@ def main():
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     torch.cuda.set_device(0)            # every rank shares the one GPU of the box; the collective goes through gloo
     import torch.distributed as dist
-    if world > 1:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+    # (SRWN_FORCE_DIST=1 with one rank and SRWN_DIST_BACKEND=nccl: the collectives of the schedule run through RCCL -- the
+    # only RCCL configuration a one-GPU box allows: two ranks on one card end in "Duplicate GPU detected")
+    backend = os.environ.get("SRWN_DIST_BACKEND", "gloo")
+    grouped = world > 1 or os.environ.get("SRWN_FORCE_DIST") == "1"
+    if grouped:
+        kw = {"device_id": torch.device("cuda", 0)} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     EG = importlib.import_module("sr-wavenet_amd.engine")
     from oracle import wavenet_np as O   # parameter / input generators only
     GB, T, R, S = 4, 700, 64, 256
@@ -43,11 +48,13 @@ def main():
         codes = O.mu_law_encode(audio, 256).astype(np.int32)
         eng.set_inputs(dev(audio[sl]), dev(codes[sl], torch.int32))
         info = {"bucketed": bool(eng.bucketed), "world": eng.world, "fused": bool(eng.fused_bwd),
-                "split_layer": int(eng.split_layer), "layers": eng.L}
+                "split_layer": int(eng.split_layer), "layers": eng.L,
+                "backend": dist.get_backend() if grouped else "none"}
         eng.train_step()
         torch.cuda.synchronize()
         grads1, params1 = eng.grads.cpu().clone(), eng.params.cpu().clone()
         eng.capture_graphs()
+        info["graphs"] = 1 + (eng._g_b2 is not None) + (eng._g_opt is not None)
         eng.train_step_graphed()
         eng.train_step_graphed()
         torch.cuda.synchronize()
@@ -82,7 +89,7 @@ def main():
                "loss": torch.tensor(stu.losses()["loss"]),
                "info": {"world": stu.world}}
     torch.save(res, out)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -22,6 +22,7 @@ from tests.test_gpu_kernels import DEV, dev, rel_err
 pytestmark = pytest.mark.gpu
 
 DIL30 = [1, 2, 4, 8, 16, 32, 64, 128, 256, 512] * 3
+GEN16_ORACLE_TOL = 1.5e-2    # srwn_generate16 (bf16) against the fp64 oracle, max-abs / max-abs: 2 x the 7.1e-3 measured (round 4)
 
 
 _ORACLE_CACHE = {}
@@ -177,8 +178,21 @@ def test_config5_shape_generation_crosses_the_receptive_field(dt, tol):
     late = slice(3072, T)          # steps whose receptive field is entirely inside the clip
     err_late = float((inc[:, late] - full[:, late]).abs().max() / full[:, late].abs().max())
     assert err_late < tol, err_late
+    # ... and against oracle (ii) DIRECTLY, both dtypes: in bf16 `generate` runs the latency-optimised kernel
+    # (srwn_generate16, what bench.py's extra.gen_* times), which the two hops above -- == the throughput kernel, == the bf16
+    # full forward -- tied to the oracle only loosely.  Two of the 32 utterances, all 3200 teacher-forced steps, fp64
+    # reference; bf16 bound = twice the error measured on MI355X (round 4: SRWN_PRINT_ERR=1 pytest -s prints it).
+    ref = OT.TorchStack(sp, requires_grad=False).forward(torch.tensor(audio[:2].astype(np.float64)), shift_input=True).numpy()
+    got = inc[:2].cpu().numpy()
+    e_all, e_late = rel_err(got, ref), rel_err(got[:, late], ref[:, late])
+    import os
+    if os.environ.get("SRWN_PRINT_ERR"):
+        print("MEASURED config5 generate vs oracle (%s): all %.3e late %.3e; full forward vs oracle %.3e" %
+              (dt, e_all, e_late, rel_err(full[:2].cpu().numpy(), ref)))
+    otol = 1e-3 if dt == torch.float32 else GEN16_ORACLE_TOL
+    assert e_all < otol and e_late < otol, (e_all, e_late)
+    if dt == torch.bfloat16:
+        assert eng.o_g16 is not None      # the latency kernel is what ran
     if dt == torch.float32:
-        ref = OT.TorchStack(sp, requires_grad=False).forward(torch.tensor(audio[:2].astype(np.float64)), shift_input=True)
-        assert rel_err(inc[:2].cpu().numpy(), ref.numpy()) < tol
         dec = O.mu_law_decode(c.cpu().numpy(), C)
         assert np.array_equal(a.cpu().numpy().view(np.uint32), dec.view(np.uint32))

@@ -18,13 +18,16 @@ pytestmark = pytest.mark.gpu
 WORKER = os.path.join(ROOT, "tests", "dp_worker.py")
 
 
-def _run(mode, world, tmp_path, tag, buckets, port):
+def _run(mode, world, tmp_path, tag, buckets, port, backend="gloo", force_dist=False):
     outs, procs = [], []
     for r in range(world):
         out = str(tmp_path / ("%s_%s_w%d_r%d.pt" % (mode, tag, world, r)))
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), SRWN_DIST_BACKEND="gloo", SRWN_BUCKETS=buckets,
+                   MASTER_PORT=str(port), SRWN_DIST_BACKEND=backend, SRWN_BUCKETS=buckets,
                    HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.pop("SRWN_FORCE_DIST", None)
+        if force_dist:
+            env["SRWN_FORCE_DIST"] = "1"
         procs.append(subprocess.Popen([sys.executable, WORKER, mode, out], env=env, cwd=ROOT,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
         outs.append(out)
@@ -83,3 +86,25 @@ def test_two_ranks_equal_one_process_on_the_global_batch(tmp_path, mode, buckets
         assert abs(l2 - lg) < 1e-4 * abs(lg)
     else:
         assert abs(l2 / 2 - lg) < 1e-4 * abs(lg)
+
+
+@pytest.mark.parametrize("mode", ["deep", "softmax"])
+def test_rccl_one_rank_three_graph_schedule_equals_plain_step(tmp_path, mode):
+    """The engine's bucketed data-parallel schedule over backend "nccl" (= RCCL) -- {forward, upper backward} | all-reduce of
+    the skip + head bucket in flight on RCCL's stream | {lower backward} | all-reduce of the layer bucket | {Adam, re-pack},
+    eager once and then as three hipGraphs -- with ONE rank, the only RCCL configuration a one-GPU box allows.  The
+    collectives are identities, so parameters, first-step gradients and loss must equal the plain one-graph step bit for
+    bit: what this holds is the stream ordering between RCCL's stream and the replayed graphs (a bucket reduced before
+    its gradients are final, or Adam replayed before the second bucket landed, would show).  "deep" = the benchmark's
+    stack and dtype (30 layers, bf16, cut at layer 10); the gloo twin of this test is
+    tests/test_gpu_engine.py::test_bucketed_allreduce_schedule_matches_plain_step."""
+    port = 29900 + (os.getpid() % 90) + (0 if mode == "deep" else 97)
+    ref = _run(mode, 1, tmp_path, "plain", "0", port)[0]
+    got = _run(mode, 1, tmp_path, "rccl1", "1", port + 200, backend="nccl", force_dist=True)[0]
+    assert ref["info"]["backend"] == "none" and not ref["info"]["bucketed"] and ref["info"]["graphs"] == 1
+    assert got["info"]["backend"] == "nccl" and got["info"]["bucketed"] and got["info"]["graphs"] == 3, got["info"]
+    assert got["info"]["world"] == 1
+    assert torch.equal(got["grads1"], ref["grads1"])
+    assert torch.equal(got["params1"], ref["params1"])
+    assert torch.equal(got["params"], ref["params"])
+    assert float(got["loss"]) == float(ref["loss"])

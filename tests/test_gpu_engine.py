@@ -25,11 +25,23 @@ def _engine(sp, B, T, R, S, C, dt, shift=True, E=0, pool=1, lr=1e-3):
 
 
 @pytest.fixture(autouse=True)
-def _keep_inner_layer_inputs(monkeypatch):
-    """The default path does not store the inputs of the layers inside a group (only their transposed tiles, which feed
-    the weight gradients); the bf16 tests below rebuild the oracle's backward from the engine's saved activations, so
-    they ask for the rows too.  (tests/test_gpu_group.py and tests/test_gpu_depth.py run the default setting.)"""
+def _shipped_default(monkeypatch):
+    """Every test of this file runs the SHIPPED default (SRWN_WT_STORE_X=0: the inputs of the layers inside a group are
+    not stored, only their transposed tiles) unless it asks otherwise: the two bf16 tests that rebuild the oracle's
+    backward from the engine's saved activations build a second engine with the rows kept (_with_inner_inputs) and
+    hold the default engine's gradients to that one's bit for bit."""
+    monkeypatch.setenv("SRWN_WT_STORE_X", "0")
+
+
+def _with_inner_inputs(monkeypatch, build):
+    """`build()` once more with SRWN_WT_STORE_X=1 (the rows of every layer input kept for inspection)."""
     monkeypatch.setenv("SRWN_WT_STORE_X", "1")
+    try:
+        eng = build()
+        assert eng.wt_store_x
+        return eng
+    finally:
+        monkeypatch.setenv("SRWN_WT_STORE_X", "0")
 
 
 def _bwd_oracle_on_engine_forward(eng, sp, cond=None, pool=1):
@@ -98,7 +110,7 @@ def test_stack_small_golden(golden_dir, dt, tol):
 
 @pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-3), (torch.bfloat16, 5e-2)])
 @pytest.mark.parametrize("R,S,C,B,T", [(64, 256, 256, 2, 300), (32, 128, 30, 1, 515), (64, 64, 100, 3, 64)])
-def test_stack_forward_backward_adam(dt, tol, R, S, C, B, T):
+def test_stack_forward_backward_adam(monkeypatch, dt, tol, R, S, C, B, T):
     dil = [1, 2, 4, 8, 16, 32, 64, 1, 2]
     sp = O.init_stack_params(21, dil, 2, R, S, C, bias_scale=0.05)
     rng = np.random.default_rng(T)
@@ -113,8 +125,15 @@ def test_stack_forward_backward_adam(dt, tol, R, S, C, B, T):
     assert rel_err(lg.cpu().numpy(), logits) < tol
     assert abs(float(eng.loss.item()) - loss) < tol * loss
     eng.backward()
+    assert not eng.wt_store_x
     if dt == torch.bfloat16:
-        grads = _bwd_oracle_on_engine_forward(eng, sp)
+        # the oracle's backward on the saved activations of a twin that keeps every layer input; the default engine
+        # (same kernels, fewer stores) must have formed exactly the same gradients
+        twin = _with_inner_inputs(monkeypatch, lambda: _engine(sp, B, T, R, S, C, dt, lr=1e-2))
+        twin.set_inputs(dev(audio), dev(codes, torch.int32))
+        twin.forward(want_logits=True); twin.backward()      # (the same head launches as `eng` ran)
+        assert torch.equal(twin.grads, eng.grads) and float(twin.loss.item()) == float(eng.loss.item())
+        grads = _bwd_oracle_on_engine_forward(twin, sp)
     _check_grads(eng, grads, tol)
     # one TF-Adam step on the oracle's gradients vs the engine's update
     before = {k: v.clone() for k, v in eng.named_tensors().items()}
@@ -137,7 +156,7 @@ def test_stack_forward_backward_adam(dt, tol, R, S, C, B, T):
 
 @pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-3), (torch.bfloat16, 5e-2)])
 @pytest.mark.parametrize("E", [16, 20])
-def test_stack_conditioned_decoder(dt, tol, E):
+def test_stack_conditioned_decoder(monkeypatch, dt, tol, E):
     """createDecoder variant (model.py:158-196): RightShift + per-layer conditioning add."""
     dil = [1, 2, 4, 8, 16, 1, 2, 4]
     R, S, C, B, T, pool = 64, 128, 64, 2, 256, 32
@@ -155,8 +174,13 @@ def test_stack_conditioned_decoder(dt, tol, E):
     assert rel_err(lg.cpu().numpy(), logits) < tol
     assert abs(float(eng.loss.item()) - loss) < tol * loss
     eng.backward()
+    assert not eng.wt_store_x
     if dt == torch.bfloat16:
-        grads = _bwd_oracle_on_engine_forward(eng, sp, cond=cond, pool=pool)
+        twin = _with_inner_inputs(monkeypatch, lambda: _engine(sp, B, T, R, S, C, dt, E=E, pool=pool))
+        twin.set_inputs(dev(audio), dev(codes, torch.int32), dev(cond))
+        twin.forward(want_logits=True); twin.backward()      # (the same head launches as `eng` ran)
+        assert torch.equal(twin.grads, eng.grads) and float(twin.loss.item()) == float(eng.loss.item())
+        grads = _bwd_oracle_on_engine_forward(twin, sp, cond=cond, pool=pool)
     _check_grads(eng, grads, tol, with_cond=True)
 
 
@@ -319,7 +343,9 @@ def test_stack_degenerate_clip_lengths(B, T, R, S):
     # re-home the big activation stacks inside canary-padded storage
     pad = 4096
     guards = []
-    for name in ("xs", "zs", "dfs", "gs", "dcs", "r0", "r1", "da1", "dtotal", "dlogits"):
+    assert eng.fused_wt and not eng.wt_store_x      # the shipped default path, its tiles and partial slabs included
+    for name in ("xs", "zs", "dfs", "gs", "dcs", "r0", "r1", "da1", "dtotal", "dlogits", "xTs", "cTs", "pl_f", "pl_r",
+                 "pl_bf", "pl_br"):
         if not hasattr(eng, name):
             continue
         t = getattr(eng, name)

@@ -12,6 +12,11 @@ from tests.test_gpu_kernels import DEV, dev, rel_err
 
 pytestmark = pytest.mark.gpu
 
+GEN16_ORACLE_TOL = 1.2e-2        # srwn_generate16 (bf16) against the fp64 oracle, 11-layer stacks: 2 x the worst measured
+#                                  (round 4, MI355X: 2.0e-3 .. 5.7e-3 over the ten shapes; fp32 mode: 4e-7 .. 1.2e-6)
+GEN16_MOL_ORACLE_TOL = 1.8e-2    # srwn_generate16_mol (bf16) against the fp64 oracle: 2 x the worst measured (6.0e-3 ..
+#                                  9.1e-3 over the five shapes; fp32 mode: 6e-7 .. 1.3e-6)
+
 
 def _engine(dt, dil, B, T, C=256, seed=4, R=64, S=256):
     EG = sub("engine")
@@ -39,10 +44,14 @@ def test_incremental_logits_equal_full_forward(dt, tol, B, T, C, R, S):
     inc = inc.cpu().numpy()
     assert np.isfinite(inc).all()
     assert rel_err(inc, full) < tol
+    # and against the CPU oracle directly (bf16: srwn_generate16 where the widths allow it; bound = 2 x measured)
+    ref, _ = O.stack_forward(sp, audio.astype(np.float64), shift_input=True)
+    e = rel_err(inc, ref)
+    import os
+    if os.environ.get("SRWN_PRINT_ERR"):
+        print("MEASURED softmax generate vs oracle (%s, B=%d T=%d C=%d R=%d S=%d): %.3e" % (dt, B, T, C, R, S, e))
+    assert e < (tol if dt == torch.float32 else GEN16_ORACLE_TOL), e
     if dt == torch.float32:
-        # and against the CPU oracle directly
-        ref, _ = O.stack_forward(sp, audio.astype(np.float64), shift_input=True)
-        assert rel_err(inc, ref) < tol
         agree = (c.cpu().numpy() == full.argmax(-1)).mean()
         assert agree > 0.999
         # emitted samples are the mu-law decode of the emitted codes, bit-exact
@@ -194,9 +203,16 @@ def test_mol_decoder_incremental_equals_full_forward(dt, tol, B, T, M, E, pool, 
                                cond=None if cond is None else dev(cond))
     inc = inc.cpu().numpy()
     assert np.isfinite(inc).all() and rel_err(inc, full) < tol
-    if dt == torch.float32:
-        ref, _ = O.stack_forward(sp, audio.astype(np.float64), shift_input=True, cond=cond, pool_stride=pool if E else 1)
-        assert rel_err(inc, ref) < tol
+    # against the CPU oracle directly, in both dtypes (bf16 runs srwn_generate16_mol, the latency-optimised body; its
+    # bound is twice the error measured on MI355X in round 4 -- SRWN_PRINT_ERR=1 pytest -s prints it)
+    ref, _ = O.stack_forward(sp, audio.astype(np.float64), shift_input=True, cond=cond, pool_stride=pool if E else 1)
+    e = rel_err(inc, ref)
+    import os
+    if os.environ.get("SRWN_PRINT_ERR"):
+        print("MEASURED mol generate vs oracle (%s, B=%d T=%d M=%d E=%d R=%d S=%d): %.3e" % (dt, B, T, M, E, R, S, e))
+    assert e < (tol if dt == torch.float32 else GEN16_MOL_ORACLE_TOL), e
+    if dt == torch.bfloat16:
+        assert eng.o_g16 is not None      # the latency kernel is what ran
     # sampler, draw for draw, on the kernel's own logits
     u1 = np.empty((B, T, M)); u2 = np.empty((B, T))
     for b in range(B):
