@@ -136,6 +136,11 @@ def generation_leg(nsteps=256):
 
 
 def main():
+    # Exactly ONE line goes to stdout: the JSON.  Everything else that may write there on the way (RCCL prints a version
+    # banner on stdout when its communicator is created) is sent to stderr: fd 1 is pointed at fd 2 until the final print.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -423,7 +428,8 @@ def main():
             # the CPU restatement on the box's host cores, and the same on ONE thread (half the time budget)
             out["cpu_baseline"] = cpu_baseline(dil, R, S, C, threads=min(os.cpu_count() or 1, 16), seconds_budget=16.0)
             out["cpu_baseline_1thread"] = cpu_baseline(dil, R, S, C, threads=1, seconds_budget=8.0)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

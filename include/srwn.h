@@ -64,6 +64,12 @@ int srwn_pack_a_index(int32_t* dst_idx, int32_t src_offset, int32_t rows_valid, 
                       int32_t row_stride, int32_t k_stride, int32_t mt_count, int32_t ks_total,
                       int32_t ks_offset, int32_t ks_count, int32_t perm_from_ks, void* stream);
 int srwn_pack_gather(const float* src, const int32_t* idx, void* dst, int64_t n, int32_t dtype, void* stream);
+/* srwn_pack_gather and, in the same launch, the column sums of a [sum_rows, sum_cols] fp32 matrix (fp64 accumulate, rows
+ * in order): sum_out[c] = sum_l sum_src[l*sum_cols + c].  The training step re-packs the weight images after every
+ * optimizer step; the sum of the layers' skip biases -- the bias of the skip sum, model.py:50 -- rides along instead of
+ * being a reduction launch in front of every forward pass.  sum_rows = 0: plain srwn_pack_gather. */
+int srwn_pack_gather_rowsum(const float* src, const int32_t* idx, void* dst, int64_t n, int32_t dtype,
+                            const float* sum_src, int32_t sum_rows, int32_t sum_cols, float* sum_out, void* stream);
 
 /* ---- generic dilated causal conv: _DilatedCausalConv1d / DilatedCausalConv1d (ops.py:6-20)
  * y[b,t,o] = bias[o] + sum_k sum_i x[b, t-(K-1-k)*dilation - shift, i] * w[k,i,o]  (zero for t<0).
@@ -75,7 +81,10 @@ int srwn_causal_conv1d_fwd(const float* x, const float* w, const float* bias, vo
                            int32_t dtype_out, void* stream);
 /* gradient of the Cin=1 input conv wrt its kernel [K,1,R] and bias [R] (autodiff of model.py:40):
  * gw[k,o] = sum_{b,t} audio[b,t-(K-1-k)-shift] * g[b,t,o]; gb[o] = sum g.  `partials` is a
- * workspace of srwn_init_conv_wgrad_partials(B,T,R,K) floats; result written (not accumulated). */
+ * workspace of srwn_init_conv_wgrad_partials(B,T,R,K) floats; result written (not accumulated).
+ * gw = gb = NULL: only the per-slab partials are written -- partials[slab][(K+1)*R] = [gw | gb] of each slab of rows,
+ * srwn_init_conv_wgrad_partials / ((K+1)*R) slabs -- for the caller to sum (the training step does it as one more job
+ * of its srwn_reduce_partials_multi launch instead of a launch of its own). */
 int64_t srwn_init_conv_wgrad_partials(int32_t B, int32_t T, int32_t R, int32_t K);
 int srwn_init_conv_wgrad(const float* audio, const void* g, float* partials, float* gw, float* gb, int32_t B,
                          int32_t T, int32_t R, int32_t K, int32_t shift, int32_t dtype, void* stream);

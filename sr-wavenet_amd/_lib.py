@@ -35,6 +35,7 @@ SIGNATURES = {
     "srwn_mu_law_decode": (C.c_int, [_p, _p, _i64, _i32, _p]),
     "srwn_pack_a_index": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "srwn_pack_gather": (C.c_int, [_p, _p, _p, _i64, _i32, _p]),
+    "srwn_pack_gather_rowsum": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _i32, _i32, _p, _p]),
     "srwn_causal_conv1d_fwd": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "srwn_init_conv_wgrad_partials": (_i64, [_i32, _i32, _i32, _i32]),
     "srwn_init_conv_wgrad": (C.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p]),

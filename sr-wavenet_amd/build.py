@@ -105,15 +105,22 @@ def _check_inflight(src, obj, flags, kernels):
                                % (src, k, "\n  ".join(bad[:8])))
 
 
-def build(force: bool = False, verbose: bool = False, diag: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, diag: bool = False, variant: str = "", extra_flags=()) -> str:
     """diag=False: libsrwn.so (+ libsrwn_io.so, the pybind11 module, the manifest).  diag=True: libsrwn_diag.so, the same
     sources with -DSRWN_DIAG (stamped kernel instantiations, SRWN_WT_DEBUG), objects under csrc/diag/; load it with
-    SRWN_LIB_PATH (ctypes binding, no manifest)."""
+    SRWN_LIB_PATH (ctypes binding, no manifest).  variant="name" + extra_flags: an A/B build of the same sources with
+    extra compiler flags -> ab/libsrwn_<name>.so (git-ignored; objects under csrc/ab_<name>/), also for SRWN_LIB_PATH."""
     import json
-    flags = FLAGS + (["-DSRWN_DIAG"] if diag else [])
-    odir = os.path.join(CSRC, "diag") if diag else CSRC
+    flags = FLAGS + (["-DSRWN_DIAG"] if diag else []) + list(extra_flags)
+    if variant:
+        diag = True      # (same treatment: no pybind module, no product manifest)
+        odir = os.path.join(CSRC, "ab_" + variant)
+        os.makedirs(os.path.join(HERE, "..", "ab"), exist_ok=True)
+        lib = os.path.join(HERE, "..", "ab", "libsrwn_%s.so" % variant)
+    else:
+        odir = os.path.join(CSRC, "diag") if diag else CSRC
+        lib = os.path.join(HERE, "libsrwn_diag.so") if diag else LIB
     os.makedirs(odir, exist_ok=True)
-    lib = os.path.join(HERE, "libsrwn_diag.so") if diag else LIB
     man_path = os.path.join(odir, "objects.manifest.json") if diag else MANIFEST
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     objs = [os.path.join(odir, os.path.splitext(os.path.basename(s))[0] + ".o") for s in srcs]
@@ -242,4 +249,7 @@ def build_io(force: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, diag="--diag" in sys.argv))
+    # python build.py [--force] [--diag] [--variant NAME -DFLAG ...]
+    _variant = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else ""
+    print(build(force="--force" in sys.argv, verbose=True, diag="--diag" in sys.argv, variant=_variant,
+                extra_flags=[a for a in sys.argv[1:] if a.startswith("-D")]))

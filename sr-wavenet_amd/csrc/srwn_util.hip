@@ -118,7 +118,18 @@ extern "C" int srwn_pack_a_index(int32_t* dst_idx, int32_t src_offset, int32_t r
 // is 4 MB), one 16-byte (bf16) or two (fp32) stores -- one element per thread spent 14 us on 3 M two-byte stores
 template <typename T>
 __global__ __launch_bounds__(256) void pack_gather_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx,
-                                                          T* __restrict__ dst, int64_t n) {
+                                                          T* __restrict__ dst, int64_t n, unsigned gather_blocks,
+                                                          const float* __restrict__ sum_src, int sum_rows, int sum_cols,
+                                                          float* __restrict__ sum_out) {
+  if (blockIdx.x >= gather_blocks) {      // the blocks behind the gather: column sums of [sum_rows, sum_cols] (rows in order, fp64)
+    const int c = (int)(blockIdx.x - gather_blocks) * 256 + (int)threadIdx.x;
+    if (c < sum_cols) {
+      double s = 0.0;
+      for (int l = 0; l < sum_rows; ++l) s += (double)sum_src[(size_t)l * sum_cols + c];
+      sum_out[c] = (float)s;
+    }
+    return;
+  }
   const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
   if (i0 >= n) return;
   if (i0 + 8 <= n) {
@@ -144,19 +155,31 @@ __global__ __launch_bounds__(256) void pack_gather_kernel(const float* __restric
   }
 }
 
-extern "C" int srwn_pack_gather(const float* src, const int32_t* idx, void* dst, int64_t n, int32_t dtype,
-                                void* stream) {
-  if (n == 0) return 0;
-  if (!src || !idx || !dst) return set_error(SRWN_E_NULL, "pack_gather: null pointer");
+extern "C" int srwn_pack_gather_rowsum(const float* src, const int32_t* idx, void* dst, int64_t n, int32_t dtype,
+                                       const float* sum_src, int32_t sum_rows, int32_t sum_cols, float* sum_out,
+                                       void* stream) {
+  const bool sum = sum_rows > 0 && sum_cols > 0;
+  if (n == 0 && !sum) return 0;
+  if (n < 0 || sum_rows < 0 || sum_cols < 0) return set_error(SRWN_E_SHAPE, "pack_gather: n=%lld sum %d x %d", (long long)n, sum_rows, sum_cols);
+  if (n > 0 && (!src || !idx || !dst)) return set_error(SRWN_E_NULL, "pack_gather: null pointer");
+  if (sum && (!sum_src || !sum_out)) return set_error(SRWN_E_NULL, "pack_gather_rowsum: null pointer");
   if (((uintptr_t)idx | (uintptr_t)dst) & 15) return set_error(SRWN_E_SHAPE, "pack_gather: idx and dst must be 16-byte aligned");
-  dim3 grid((unsigned)((n + 2047) / 2048)), block(256);
+  const unsigned gb = (unsigned)((n + 2047) / 2048), sb = sum ? (unsigned)((sum_cols + 255) / 256) : 0u;
+  dim3 grid(gb + sb), block(256);
   if (dtype == SRWN_F32)
-    hipLaunchKernelGGL(pack_gather_kernel<float>, grid, block, 0, (hipStream_t)stream, src, idx, (float*)dst, n);
+    hipLaunchKernelGGL(pack_gather_kernel<float>, grid, block, 0, (hipStream_t)stream, src, idx, (float*)dst, n, gb, sum_src,
+                       sum ? sum_rows : 0, sum ? sum_cols : 0, sum_out);
   else if (dtype == SRWN_BF16)
-    hipLaunchKernelGGL(pack_gather_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, src, idx, (bf16_t*)dst, n);
+    hipLaunchKernelGGL(pack_gather_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, src, idx, (bf16_t*)dst, n, gb, sum_src,
+                       sum ? sum_rows : 0, sum ? sum_cols : 0, sum_out);
   else
     return set_error(SRWN_E_DTYPE, "pack_gather: dtype %d", dtype);
   return check_launch("pack_gather");
+}
+
+extern "C" int srwn_pack_gather(const float* src, const int32_t* idx, void* dst, int64_t n, int32_t dtype,
+                                void* stream) {
+  return srwn_pack_gather_rowsum(src, idx, dst, n, dtype, nullptr, 0, 0, nullptr, stream);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -383,7 +406,7 @@ extern "C" int64_t srwn_init_conv_wgrad_partials(int32_t B, int32_t T, int32_t R
 extern "C" int srwn_init_conv_wgrad(const float* audio, const void* g, float* partials, float* gw, float* gb,
                                     int32_t B, int32_t T, int32_t R, int32_t K, int32_t shift, int32_t dtype,
                                     void* stream) {
-  if (!audio || !g || !partials || !gw || !gb) return set_error(SRWN_E_NULL, "init_conv_wgrad: null pointer");
+  if (!audio || !g || !partials || ((gw == nullptr) != (gb == nullptr))) return set_error(SRWN_E_NULL, "init_conv_wgrad: null pointer");
   if (B < 1 || T < 1 || K < 1 || K > 8 || (R != 32 && R != 64 && R != 128))
     return set_error(SRWN_E_SHAPE, "init_conv_wgrad: B=%d T=%d R=%d K=%d", B, T, R, K);
   int64_t rows = (int64_t)B * T;
@@ -403,6 +426,7 @@ extern "C" int srwn_init_conv_wgrad(const float* audio, const void* g, float* pa
 #undef SRWN_IC
   int rc = check_launch("init_conv_wgrad_stage1");
   if (rc) return rc;
+  if (!gw) return 0;      // partials only: the caller sums them (e.g. as one more job of srwn_reduce_partials_multi)
   int n = (K + 1) * R;
   hipLaunchKernelGGL(init_conv_wgrad_stage2, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, partials, nparts,
                      gw, gb, R, K);

@@ -62,6 +62,7 @@ struct Cursor {
 __global__ __launch_bounds__(512) void wgrad_skip_wt_kernel(WtSkipArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  SRWN_PRIO_YOUNG(8, wave, 4);
   const int slab = blockIdx.x;
   const WtBlk& bk = a.blk[blockIdx.y];
   const int st = bk.st, W = bk.W, nsub = bk.nsub, KT = bk.KT;

@@ -135,6 +135,7 @@ class WaveNetEngine:
         self.head_chain = (_os.environ.get("SRWN_HEAD_CHAIN", "1") != "0" and cfg.head_mode == "per_timestep"
                            and cfg.dtype == torch.bfloat16 and cfg.skip_channels == 256)
         self._head_bwd_done = False
+        self._ic_job = None
         self.side = None
         if torch.cuda.is_available() and self.overlap:
             # weight-gradient passes are throughput work: lowest priority, so the latency-critical dgrad
@@ -166,8 +167,8 @@ class WaveNetEngine:
             self._build_params(seed)
             self._build_packing()
         else:   # another (batch, length) view of the same model: parameters, moments, images are shared
-            for a in ("sections", "nparams", "params", "grads", "adam_m", "adam_v", "adam_step", "dead_gate",
-                      "packer", "packed", "o_conv", "o_res", "o_convT", "o_resT", "o_skipT", "o_skipT_all", "o_skip", "o_gen", "o_skip_gen",
+            for a in ("sections", "nparams", "params", "grads", "adam_m", "adam_v", "adam_step", "bs_sum", "dead_gate",
+                      "packer", "packed", "pack_train_elems", "o_conv", "o_res", "o_convT", "o_resT", "o_skipT", "o_skipT_all", "o_skip", "o_gen", "o_skip_gen",
                       "o_w1", "o_w2",
                       "o_w1T", "o_w2T", "o_w2p", "o_w2Tp", "o_w1Tp"):
                 setattr(self, a, getattr(share_from, a))
@@ -206,6 +207,7 @@ class WaveNetEngine:
         self.adam_m = torch.zeros(off, dtype=torch.float32, device=self.dev)
         self.adam_v = torch.zeros(off, dtype=torch.float32, device=self.dev)
         self.adam_step = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        self.bs_sum = torch.zeros(S, dtype=torch.float32, device=self.dev)      # sum_l BS[l] (kept current by repack())
         # the dead gate conv variables of ops.py:31-33 exist in reference checkpoints; they take no
         # part in the graph (TF reports None gradients) so they live outside the trained buffer.
         self.dead_gate = {"WG": torch.zeros((L, Kw, R, R), dtype=torch.float32, device=self.dev),
@@ -319,7 +321,10 @@ class WaveNetEngine:
         sec = self.sections
         pk = K.Packer(self.dev)
         self._pack_stack(pk)
+        self.pack_train_elems = None
         self._pack_head(pk)
+        if self.pack_train_elems is None:      # (a head without generation-only images)
+            self.pack_train_elems = pk.total
         pk.finalize()
         self.packer = pk
         self.packed = torch.zeros(max(pk.total, 1), dtype=self.dt, device=self.dev)
@@ -345,27 +350,6 @@ class WaveNetEngine:
         L, R, S, Kw, Cp = self.L, self.R, self.S, self.Kw, self.Cp
         sec = self.sections
         self.o_skipT = []
-        # generation images: per layer [conv (last tap permuted) | residual], back to back (srwn_generate)
-        self.o_gen = self.o_skip_gen = None
-        if R in (32, 64) and S in (128, 256) and Kw == 2:
-            for l in range(L):
-                o = P.pack_conv_gen(pk, sec["WF"].offset + l * Kw * R * R, Kw, R)
-                P.pack_res(pk, sec["WR"].offset + l * R * R, R)
-                if l == 0:
-                    self.o_gen = o
-            # skip kernels for generation: B operand is the gate tile in registers -> permuted k order
-            self.o_skip_gen = pk.reserve(S // 32, L * R // 16)
-            for l in range(L):
-                P.fill_linear(pk, self.o_skip_gen, sec["WS"].offset + l * R * S, R, S, S // 32, L * R // 16,
-                              ks_offset=l * R // 16, ks_count=R // 16, perm=True)
-        # the latency-optimised generator's fragment images (csrc/srwn_gen16.hip)
-        self.o_g16 = None
-        if (self.o_gen is not None and R in (32, 64) and S in (128, 256) and self.dt == torch.bfloat16 and L <= 64
-                and ((self.cfg.head_mode == "per_timestep" and not self.E) or self.cfg.head_mode == "mol")):
-            self.o_g16 = pk.reserve_raw(np.concatenate([P.gen16_layer_index(sec["WF"].offset, sec["WR"].offset,
-                                                                            sec["WS"].offset, l, R, S) for l in range(L)]))
-            self.o_g16_h1 = pk.reserve_raw(P.gen16_head_index(sec["head_w1"].offset, S, S, S))
-            self.o_g16_h2 = pk.reserve_raw(P.gen16_head_index(sec["head_w2"].offset, S, Cp, Cp, interleave=True))
         # transposed skip kernels of all layers back to back (srwn_skip_dgrad_all streams them in order)
         per = (R // 32) * (S // 16) * 512
         self.o_skipT_all = pk.reserve(L * (R // 32), S // 16)
@@ -387,12 +371,46 @@ class WaveNetEngine:
             self.o_w2p = P.pack_linear(pk, sec["head_w2"].offset, S, Cp, Cp, perm=True)
             self.o_w2Tp = P.pack_linear_T(pk, sec["head_w2"].offset, S, Cp, S, perm=True)
             self.o_w1Tp = P.pack_linear_T(pk, sec["head_w1"].offset, S, S, S, perm=True)
+        # ---- everything above is read by the training step and re-gathered after every optimizer step; the images below
+        # serve generate() only and are re-gathered there (they are 45 % of the image: 3.7 of 8.1 MB for config 2)
+        self.pack_train_elems = pk.total
+        # generation images: per layer [conv (last tap permuted) | residual], back to back (srwn_generate)
+        self.o_gen = self.o_skip_gen = None
+        if R in (32, 64) and S in (128, 256) and Kw == 2:
+            for l in range(L):
+                o = P.pack_conv_gen(pk, sec["WF"].offset + l * Kw * R * R, Kw, R)
+                P.pack_res(pk, sec["WR"].offset + l * R * R, R)
+                if l == 0:
+                    self.o_gen = o
+            # skip kernels for generation: B operand is the gate tile in registers -> permuted k order
+            self.o_skip_gen = pk.reserve(S // 32, L * R // 16)
+            for l in range(L):
+                P.fill_linear(pk, self.o_skip_gen, sec["WS"].offset + l * R * S, R, S, S // 32, L * R // 16,
+                              ks_offset=l * R // 16, ks_count=R // 16, perm=True)
+        # the latency-optimised generator's fragment images (csrc/srwn_gen16.hip)
+        self.o_g16 = None
+        if (self.o_gen is not None and R in (32, 64) and S in (128, 256) and self.dt == torch.bfloat16 and L <= 64
+                and ((self.cfg.head_mode == "per_timestep" and not self.E) or self.cfg.head_mode == "mol")):
+            self.o_g16 = pk.reserve_raw(np.concatenate([P.gen16_layer_index(sec["WF"].offset, sec["WR"].offset,
+                                                                            sec["WS"].offset, l, R, S) for l in range(L)]))
+            self.o_g16_h1 = pk.reserve_raw(P.gen16_head_index(sec["head_w1"].offset, S, S, S))
+            self.o_g16_h2 = pk.reserve_raw(P.gen16_head_index(sec["head_w2"].offset, S, Cp, Cp, interleave=True))
 
     def wptr(self, off: int) -> int:
         return self.packed.data_ptr() + off * self.packed.element_size()
 
     def repack(self):
-        self.packer.gather(self.params, self.packed)
+        """Rebuilds what the kernels derive from the parameters: the weight images the training / forward kernels read (the
+        generation-only tail: `_repack_generation`) and, in the same launch, the sum of the layers' skip biases (the bias of
+        the skip sum, model.py:50: it was a reduction launch in front of every forward pass)."""
+        bs = getattr(self, "bs_sum", None)      # (the flows of the student carry no skip path)
+        rs = (self.view("BS"), bs) if (bs is not None and "BS" in self.sections) else None
+        self.packer.gather(self.params, self.packed, 0, getattr(self, "pack_train_elems", None), rowsum=rs)
+
+    def _repack_generation(self):
+        n = getattr(self, "pack_train_elems", None)
+        if n is not None and n < self.packer.total:
+            self.packer.gather(self.params, self.packed, n, None)
 
     # ------------------------------------------------------------------------------------------
     # buffers
@@ -462,7 +480,6 @@ class WaveNetEngine:
             self.dcs = z(L, B, T, R)  # Ws_l . dtotal of every layer (one output-streaming GEMM)
         self.r0 = z(N, S); self.r1 = z(N, S); self.da1 = z(N, S); self.dtotal = z(N, S)
         self.dlogits = z(N, Cp)
-        self.bs_sum = z(S, dt=torch.float32)
         self.loss_parts = z((N + 31) // 32, dt=torch.float32)
         self.loss = z(1, dt=torch.float32)
         self.pooled = self.cfg.head_mode == "pooled"
@@ -528,10 +545,9 @@ class WaveNetEngine:
         self._tiles_valid = bool(train) and self.fused_wt
         with _Span(self, "fwd_layers"):
             self._stack_fwd(self.cond_all if self.E else None, wt=self._tiles_valid)
-        K.reduce_partials(v("BS").reshape(-1), L, S, 1, True, 1.0, self.bs_sum.data_ptr(), 0)
-        with _Span(self, "skip_sum"):
+        with _Span(self, "skip_sum"):      # model.py:50-51 (bs_sum = the sum of the layers' skip biases: formed by repack())
             K.pw_linear(self.zs.data_ptr(), R, N * R, R, L * R, self.wptr(self.o_skip), self.bs_sum, self.r0, S, S,
-                        N, pro=K.PRO_GATE, epi=K.EPI_RELU)                            # model.py:50-51
+                        N, pro=K.PRO_GATE, epi=K.EPI_RELU)
         self._head_bwd_done = False
         if self.head_chain and self.o_w2p is not None and not want_logits and with_loss:
             # model.py:53-56 + softmax CE + the two head data gradients: rows never leave the registers in between
@@ -699,9 +715,14 @@ class WaveNetEngine:
             if self.timing and not self.fused_wt:
                 for g in groups:
                     self._wgrad_layers_group(*g)
+            merged = self.use_wl      # the input conv's slab sum joins the final reduction launch
+            if merged and overlap:
+                side.wait_stream(main)      # (gs[0], which the input conv's gradient reads, is complete on the main stream)
             with torch.cuda.stream(side):
+                if merged:
+                    self._wgrad_input_conv_partials()
                 self._wgrad_layers_finish()
-            self._wgrad_input_and_cond()
+            self._wgrad_input_and_cond(input_conv=not merged)
             if overlap and join:
                 main.wait_stream(side)
             return
@@ -734,9 +755,14 @@ class WaveNetEngine:
         if self.timing:   # (timed runs keep the dgrad chain's span free of the weight-gradient passes)
             for g in groups:
                 self._wgrad_layers_group(*g)
+        merged = self.use_wl      # (as in the grouped path: the same sums in the same order)
+        if merged and overlap:
+            side.wait_stream(main)
         with torch.cuda.stream(side):
+            if merged:
+                self._wgrad_input_conv_partials()
             self._wgrad_layers_finish()
-        self._wgrad_input_and_cond()
+        self._wgrad_input_and_cond(input_conv=not merged)
         if overlap and join:
             main.wait_stream(side)
 
@@ -848,11 +874,14 @@ class WaveNetEngine:
         NR = N * R
         xs_p, zs_p, dfs_p, gs_p = self.xs.data_ptr(), self.zs.data_ptr(), self.dfs.data_ptr(), self.gs.data_ptr()
         if self.use_wl:
-            K.reduce_partials_multi([
-                (self.pl_f, ns, Kw * R * R, L, True, 1.0, gp + 4 * sec["WF"].offset, Kw * R * R),
-                (self.pl_bf, ns, R, L, True, 1.0, gp + 4 * sec["BF"].offset, R),
-                (self.pl_r, ns, R * R, L, True, SQRT_HALF, gp + 4 * sec["WR"].offset, R * R),
-                (self.pl_br, ns, R, L, True, SQRT_HALF, gp + 4 * sec["BR"].offset, R)])
+            jobs = [(self.pl_f, ns, Kw * R * R, L, True, 1.0, gp + 4 * sec["WF"].offset, Kw * R * R),
+                    (self.pl_bf, ns, R, L, True, 1.0, gp + 4 * sec["BF"].offset, R),
+                    (self.pl_r, ns, R * R, L, True, SQRT_HALF, gp + 4 * sec["WR"].offset, R * R),
+                    (self.pl_br, ns, R, L, True, SQRT_HALF, gp + 4 * sec["BR"].offset, R)]
+            if self._ic_job is not None:      # the input conv's kernel + bias gradient (init_w | init_b are adjacent)
+                jobs.append(self._ic_job)
+                self._ic_job = None
+            K.reduce_partials_multi(jobs)
             return
         for k in range(Kw):                                                          # dilated conv taps (legacy)
             shifts = [(Kw - 1 - k) * d for d in self.dil]
@@ -937,12 +966,22 @@ class WaveNetEngine:
             K.reduce_partials(self.wg_parts, ns, S * Cp, 1, True, 1.0, gp + 4 * sec["head_w2"].offset, 0)
             K.reduce_partials(self.wg_bparts, ns, Cp, 1, True, 1.0, gp + 4 * sec["head_b2"].offset, 0)
 
-    def _wgrad_input_and_cond(self):
+    def _wgrad_input_conv_partials(self):
+        """Stage 1 of the input conv's weight gradient (model.py:40): per-slab partial sums from gs[0]; its slab
+        reduction rides in the final srwn_reduce_partials_multi launch (it was a launch of its own)."""
+        sec = self.sections
+        assert sec["init_b"].offset == sec["init_w"].offset + sec["init_w"].numel
+        nsl = K.init_conv_wgrad(self.audio, self.gs[0], None, None, self.Kw, 1 if self.cfg.shift_input else 0, self.ic_ws)
+        self._ic_job = (self.ic_ws, nsl, (self.Kw + 1) * self.R, 1, True, 1.0,
+                        self.grads.data_ptr() + 4 * sec["init_w"].offset, 0)
+
+    def _wgrad_input_and_cond(self, input_conv: bool = True):
         B, T, L, R, Kw = self.B, self.T, self.L, self.R, self.Kw
         g = self.grads
         gp, sec, dt = g.data_ptr(), self.sections, self.dt
-        K.init_conv_wgrad(self.audio, self.gs[0], self.view("init_w", g).reshape(-1), self.view("init_b", g), Kw,
-                          1 if self.cfg.shift_input else 0, self.ic_ws)
+        if input_conv:
+            K.init_conv_wgrad(self.audio, self.gs[0], self.view("init_w", g).reshape(-1), self.view("init_b", g), Kw,
+                              1 if self.cfg.shift_input else 0, self.ic_ws)
         if self.E:
             # conditioning 1x1 (model.py:180): dcb_l = adjoint of the NN upsample applied to G_l
             rows_c, Ep, E = B * self.frames, self.Ep, self.E
@@ -1009,6 +1048,7 @@ class WaveNetEngine:
         if self.o_gen is None or self.pooled:
             raise NotImplementedError("generate: built for R=64 or 32, S=256 or 128, K=2 stacks with a per-time-step head")
         B = int(batch or self.B)
+        self._repack_generation()      # (the generation-only images follow the parameters lazily: not part of a training step)
         dl = (C.c_int32 * self.L)(*self.dil)
         relems = int(_lib.load().srwn_generate_ring_elems(dl, self.L, self.R))
         ring = torch.zeros(relems * ((B + 31) // 32), dtype=self.dt, device=self.dev)
@@ -1022,7 +1062,6 @@ class WaveNetEngine:
                 raise ValueError("forced must be [batch, nsteps]")
             fp = forced.data_ptr()
         v = self.view
-        K.reduce_partials(v("BS").reshape(-1), self.L, self.S, 1, True, 1.0, self.bs_sum.data_ptr(), 0)
         common = (self.wptr(self.o_gen), self.wptr(self.o_skip_gen), self.wptr(self.o_w1), self.wptr(self.o_w2),
                   v("BF").data_ptr(), v("BR").data_ptr(), self.bs_sum.data_ptr(), v("head_b1").data_ptr(),
                   v("head_b2").data_ptr(), v("init_w").data_ptr(), v("init_b").data_ptr(), ring.data_ptr(),

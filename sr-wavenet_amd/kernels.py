@@ -105,12 +105,26 @@ class Packer:
             self.idx[off:off + index.size].copy_(torch.as_tensor(index.reshape(-1), dtype=torch.int32))
         return self
 
-    def gather(self, params_flat: torch.Tensor, out: torch.Tensor):
-        """out[i] = (out.dtype) params_flat[idx[i]] (0 where idx<0)."""
+    def gather(self, params_flat: torch.Tensor, out: torch.Tensor, start: int = 0, stop: Optional[int] = None,
+               rowsum: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+        """out[i] = (out.dtype) params_flat[idx[i]] (0 where idx<0) for the image elements [start, stop) (default: all).
+        rowsum = (matrix [rows, cols] fp32, out [cols] fp32): its column sums are formed in the same launch."""
         _chk(params_flat, "params", torch.float32)
         _chk(out, "packed", None, (max(self.total, 1),))
-        call("srwn_pack_gather", params_flat.data_ptr(), self.idx.data_ptr(), out.data_ptr(), self.total,
-             abi_dtype(out.dtype), _stream())
+        stop = self.total if stop is None else int(stop)
+        start = int(start)
+        if not 0 <= start <= stop <= self.total:
+            raise ValueError("gather: range [%d, %d) of %d" % (start, stop, self.total))
+        if rowsum is not None:
+            mat, vec = rowsum
+            _chk(mat, "rowsum matrix", torch.float32)
+            _chk(vec, "rowsum out", torch.float32, (mat.shape[-1],))
+            call("srwn_pack_gather_rowsum", params_flat.data_ptr(), self.idx.data_ptr() + 4 * start,
+                 out.data_ptr() + start * out.element_size(), stop - start, abi_dtype(out.dtype), mat.data_ptr(),
+                 int(mat.numel() // mat.shape[-1]), int(mat.shape[-1]), vec.data_ptr(), _stream())
+        elif stop > start:
+            call("srwn_pack_gather", params_flat.data_ptr(), self.idx.data_ptr() + 4 * start,
+                 out.data_ptr() + start * out.element_size(), stop - start, abi_dtype(out.dtype), _stream())
         return out
 
 
@@ -137,8 +151,10 @@ def causal_conv1d_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Ten
     return y
 
 
-def init_conv_wgrad(audio: torch.Tensor, g: torch.Tensor, gw: torch.Tensor, gb: torch.Tensor, K: int, shift: int,
-                    workspace: torch.Tensor):
+def init_conv_wgrad(audio: torch.Tensor, g: torch.Tensor, gw: Optional[torch.Tensor], gb: Optional[torch.Tensor], K: int,
+                    shift: int, workspace: torch.Tensor) -> int:
+    """gw = gb = None: only the per-slab partials are left in `workspace` ([slabs][(K+1)*R] = [gw | gb] per slab of
+    rows); returns the number of slabs (the caller sums them, e.g. as one more job of reduce_partials_multi)."""
     B, T = audio.shape
     R = g.shape[-1]
     pa = _chk(audio, "audio", torch.float32)
@@ -146,12 +162,16 @@ def init_conv_wgrad(audio: torch.Tensor, g: torch.Tensor, gw: torch.Tensor, gb: 
     need = _lib.load().srwn_init_conv_wgrad_partials(B, T, R, K)
     if workspace.numel() < need or workspace.dtype != torch.float32:
         raise ValueError("init_conv_wgrad: workspace needs %d floats" % need)
-    _chk(gw, "gw", torch.float32)
-    _chk(gb, "gb", torch.float32)
-    if gw.numel() != K * R or gb.numel() != R:
-        raise ValueError("init_conv_wgrad: gw/gb size")
-    call("srwn_init_conv_wgrad", pa, pg, workspace.data_ptr(), gw.data_ptr(), gb.data_ptr(), B, T, R, K, int(shift),
-         abi_dtype(g.dtype), _stream())
+    if (gw is None) != (gb is None):
+        raise ValueError("init_conv_wgrad: gw and gb go together")
+    if gw is not None:
+        _chk(gw, "gw", torch.float32)
+        _chk(gb, "gb", torch.float32)
+        if gw.numel() != K * R or gb.numel() != R:
+            raise ValueError("init_conv_wgrad: gw/gb size")
+    call("srwn_init_conv_wgrad", pa, pg, workspace.data_ptr(), None if gw is None else gw.data_ptr(),
+         None if gb is None else gb.data_ptr(), B, T, R, K, int(shift), abi_dtype(g.dtype), _stream())
+    return int(need // ((K + 1) * R))
 
 
 # ----------------------------------------------------------------------------------------------

@@ -319,3 +319,62 @@ def test_reduce_partials_multi_matches_single_launches():
         assert float(a.abs().max()) > 0
     with pytest.raises(RuntimeError):
         Kn.reduce_partials_multi(jobs * 3)       # 18 jobs: more than one launch takes
+
+
+def test_adam_step_counter_ticks_inside_the_update_launch():
+    """The device step counter is advanced by the update launch itself (the block whose arrival comes last stores the new
+    count; the upper half of the 64-bit word is the arrival counter and is zero again afterwards): a grid of ~1000
+    blocks, several steps, eager and replayed from a hipGraph -- every block must have used the same t, the word must
+    read as a plain int64 count between launches."""
+    K = sub("kernels")
+    rng = np.random.default_rng(1)
+    n = 1_003_457          # ~980 blocks, a ragged tail
+    th = rng.standard_normal(n); m = np.zeros(n); v = np.zeros(n)
+    p = dev(th); pm = torch.zeros(n, device=DEV); pv = torch.zeros(n, device=DEV)
+    step = torch.zeros(1, dtype=torch.int64, device=DEV)
+    g = dev(rng.standard_normal(n) * 0.1)
+    gh = g.double().cpu().numpy()
+    for t in range(1, 4):
+        th, m, v = O.adam_step_tf(th, gh, m, v, t, lr=1e-2)
+        K.adam_step(p, g, pm, pv, step, 1e-2)
+        assert int(step.item()) == t
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        K.adam_step(p, g, pm, pv, step, 1e-2)
+    for t in range(4, 8):          # (the capture itself does not run the kernel)
+        th, m, v = O.adam_step_tf(th, gh, m, v, t, lr=1e-2)
+        gr.replay()
+    torch.cuda.synchronize()
+    assert int(step.item()) == 7
+    assert rel_err(p.cpu().numpy(), th) < 1e-5
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_pack_gather_with_column_sums(dt):
+    """srwn_pack_gather_rowsum: the image gather and, by extra blocks of the same launch, the column sums of a matrix (the
+    sum of the layers' skip biases, model.py:50) -- bit-equal to the plain gather and to srwn_reduce_partials."""
+    K = sub("kernels"); P = sub("packing")
+    rng = np.random.default_rng(7)
+    L, R, S = 30, 64, 256
+    params = dev(rng.standard_normal(L * R * S + L * S))
+    pk = K.Packer(DEV)
+    o = pk.reserve(S // 32, L * R // 16)
+    for l in range(L):
+        P.fill_linear(pk, o, l * R * S, R, S, S // 32, L * R // 16, ks_offset=l * R // 16, ks_count=R // 16)
+    pk.finalize()
+    plain = torch.zeros(pk.total, dtype=dt, device=DEV)
+    pk.gather(params, plain)
+    both = torch.zeros(pk.total, dtype=dt, device=DEV)
+    bias = params[L * R * S:].view(L, S)
+    got = torch.full((S,), float("nan"), dtype=torch.float32, device=DEV)
+    pk.gather(params, both, rowsum=(bias, got))
+    want = torch.empty(S, dtype=torch.float32, device=DEV)
+    K.reduce_partials(bias.reshape(-1), L, S, 1, True, 1.0, want.data_ptr(), 0)
+    assert torch.equal(both, plain) and torch.equal(got, want)
+    # a prefix of the image (what the training step re-gathers) + the tail (what generate() re-gathers) == the whole
+    parts = torch.zeros(pk.total, dtype=dt, device=DEV)
+    cut = (pk.total // 3) // 8 * 8
+    pk.gather(params, parts, 0, cut)
+    assert bool((parts[cut:] == 0).all())
+    pk.gather(params, parts, cut, None)
+    assert torch.equal(parts, plain)

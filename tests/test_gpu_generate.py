@@ -294,3 +294,27 @@ def test_mol_decoder_free_running_and_model_api(tmp_path):
     assert rel_err(lg_full[:, :64], lg.cpu().numpy()[:, :64]) < 1e-3
     with pytest.raises(ValueError):
         ae.generate(enc[:, :, :3])          # wrong latent width
+
+
+def test_generation_images_follow_the_parameters_after_training_steps():
+    """The weight images only generate() reads are not re-gathered by the training step (they are 45 % of the image);
+    generate() re-gathers them itself.  After eager and graph-replayed training steps, teacher-forced incremental logits
+    must still equal the full forward's on the UPDATED parameters (fp32: 1e-3)."""
+    dil = [1, 2, 4, 8, 16, 32, 1, 2]
+    B, T, C = 3, 200, 256
+    eng, _ = _engine(torch.float32, dil, B, T, C)
+    assert eng.pack_train_elems < eng.packer.total
+    audio = O.synthetic_audio(B, T, seed=9)
+    codes = O.mu_law_encode(audio, C)
+    eng.set_inputs(dev(audio), dev(codes, torch.int32))
+    before = eng.forward(want_logits=True).clone()
+    for _ in range(3):
+        eng.train_step()
+    eng.capture_graphs()
+    for _ in range(3):
+        eng.train_step_graphed()
+    torch.cuda.synchronize()
+    full = eng.forward(want_logits=True).cpu().numpy()
+    assert rel_err(full, before.cpu().numpy()) > 1e-2          # the parameters did move
+    _, _, inc = eng.generate(T, mode="argmax", forced=dev(audio), want_logits=True)
+    assert rel_err(inc.cpu().numpy(), full) < 1e-3
