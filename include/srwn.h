@@ -147,7 +147,12 @@ int srwn_residual_group_bwd(const void* g_top, void* g_out, void* df_out, const 
  * 16 x 16 blocks over the eight waves.  df is not stored; G of the inner layers only with write_all_g (the conditioned
  * decoders sum it per frame, model.py:180); g_out always receives the group's bottom gradient.  One partial slab per
  * workgroup (`nslabs` from srwn_group_wt_geometry; slabs beyond it must stay zero); finish with srwn_reduce_partials,
- * sqrt(.5) on the residual pair.  Halo (sum(dilations)/gcd) <= 31. */
+ * sqrt(.5) on the residual pair.  Halo (sum(dilations)/gcd) <= 31.
+ * part16 != 0 (dtype SRWN_BF16 only): part_f / part_r are written in the COMPUTE type instead of fp32 -- the same number
+ * of elements per (layer, slab), as 16 x 16 blocks in lane order (layout SRWN_PARTIALS_BLK16 of SrwnReduceJob below):
+ * half the bytes both ways for one more bf16 rounding per partial sum (the 256 x 30 partials of config 2 are 0.38 GB per
+ * step in fp32, written here and read back by the reduction; measured cost in accuracy: DESIGN.md 4c).  The two bias
+ * partials stay fp32. */
 int srwn_group_wt_geometry(const int32_t* dilations, int32_t nlayers, int32_t B, int32_t T, int32_t R, int32_t dtype,
                            int32_t seg_rows_in, int32_t* seg_rows, int32_t* tiles_per_seg, int64_t* elems_per_layer,
                            int32_t* nslabs);
@@ -160,9 +165,9 @@ int srwn_residual_group_fwd_wt(const void* x0, void* x_out, void* z_out, int64_t
 int srwn_residual_group_bwd_wt(const void* g_top, void* g_out, int32_t write_all_g, const void* z, const void* dcs,
                                int64_t layer_stride, const void* xT, const void* cT, int64_t wt_layer_stride,
                                const void* const* wconvT, const void* const* wresT, const int32_t* dilations,
-                               int32_t nlayers, float* part_f, float* part_r, float* part_bf, float* part_br,
-                               int32_t nslabs, int32_t B, int32_t T, int32_t R, int32_t K, int32_t seg_rows,
-                               int32_t dtype, void* stream);
+                               int32_t nlayers, void* part_f, void* part_r, float* part_bf, float* part_br,
+                               int32_t part16, int32_t nslabs, int32_t B, int32_t T, int32_t R, int32_t K,
+                               int32_t seg_rows, int32_t dtype, void* stream);
 /* the same cut chosen for a problem size (B clips of T steps, R channels, dtype): minimises the estimated run time of
  * the group kernels (tile rounds per layer + a fixed cost per launch) over all cuts into runs of <= max_layers layers. */
 int32_t srwn_group_plan_auto(const int32_t* dilations, int32_t nlayers, int32_t B, int32_t T, int32_t R, int32_t dtype,
@@ -286,9 +291,15 @@ int srwn_reduce_partials(const float* partials, int32_t nslabs, int64_t n, int32
                          float scale, float* out, int64_t out_batch_stride, void* stream);
 /* Up to 16 such reductions as ONE launch (host array of jobs; each job's result is bit-identical to its own
  * srwn_reduce_partials call). */
+#define SRWN_PARTIALS_F32 0   /* fp32 [batch][slab][n]: what srwn_reduce_partials takes */
+#define SRWN_PARTIALS_BLK16 1 /* bf16 [batch][slab][n] where the n = rows*blk_cols elements of a [rows, blk_cols] matrix
+                               * are stored as 16 x 16 blocks in MFMA-accumulator lane order: block (rb, cb) at
+                               * (rb*(blk_cols/16) + cb)*256 elements, lane l's four values -- rows 16 rb + 4 (l >> 4) + 0..3
+                               * of column 16 cb + (l & 15) -- at + 4 l (srwn_residual_group_bwd_wt with part16) */
 typedef struct SrwnReduceJob {
-  const float* partials; int32_t nslabs; int64_t n; int32_t nbatch; int32_t partials_batched; float scale;
+  const void* partials; int32_t nslabs; int64_t n; int32_t nbatch; int32_t partials_batched; float scale;
   float* out; int64_t out_batch_stride;
+  int32_t layout; int32_t blk_cols;      /* SRWN_PARTIALS_*; blk_cols: BLK16 only (a multiple of 16) */
 } SrwnReduceJob;
 int srwn_reduce_partials_multi(const SrwnReduceJob* jobs, int32_t njobs, void* stream);
 

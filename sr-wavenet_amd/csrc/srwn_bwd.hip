@@ -683,6 +683,7 @@ constexpr int kRpMaxJobs = 16;
 struct RpJob {
   const float* partials; float* out; int64_t n; int64_t out_batch_stride;
   int nslabs, nbatch, part_batch_mul; float scale; int wide; unsigned blocks_x, block0;
+  int blk_cols;      // wide == 3: `partials` holds bf16 16 x 16 blocks in lane order (SRWN_PARTIALS_BLK16)
 };
 struct RpMulti { RpJob j[kRpMaxJobs]; int njobs; };
 
@@ -695,7 +696,44 @@ __global__ __launch_bounds__(256) void reduce_partials_multi_kernel(RpMulti m) {
   const int l = (int)(b / job.blocks_x);
   const int nslabs = job.nslabs;
   const int64_t n = job.n;
-  if (job.wide == 1) {
+  if (job.wide == 3) {
+    // bf16 blocks in lane order: a thread takes two neighbouring lanes of one block (16 bytes per slab: four rows of two
+    // columns), eight slabs in flight; every output is summed slab by slab in order, in f64, like the fp32 bodies
+    const int64_t q = (int64_t)bx * 256 + threadIdx.x;      // (block, lane pair)
+    if (q * 8 >= n) return;
+    const int64_t blk = q >> 5;
+    const int pr = (int)(q & 31);
+    const bf16_t* p = reinterpret_cast<const bf16_t*>(job.partials) + (int64_t)l * job.part_batch_mul * nslabs * n + q * 8;
+    double s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.0;
+    int k = 0;
+    for (; k + 8 <= nslabs; k += 8) {
+      srwn::bf16x8 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const srwn::bf16x8*>(p + (int64_t)(k + j) * n);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += (double)(float)v[j][e];
+    }
+    for (; k < nslabs; ++k) {
+      const srwn::bf16x8 v = *reinterpret_cast<const srwn::bf16x8*>(p + (int64_t)k * n);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += (double)(float)v[e];
+    }
+    const int nib = job.blk_cols / 16;
+    const int lane = 2 * pr;
+    const int64_t row0 = 16 * (blk / nib) + 4 * (lane >> 4);
+    const int col = 16 * (int)(blk % nib) + (lane & 15);
+    const double sc = (double)job.scale;
+    float* o = job.out + (int64_t)l * job.out_batch_stride + row0 * job.blk_cols + col;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {      // lane `lane` holds s[0..3] (rows), lane + 1 holds s[4..7]: two neighbouring columns
+      typedef float f2 __attribute__((ext_vector_type(2)));
+      *reinterpret_cast<f2*>(o + (int64_t)rr * job.blk_cols) = f2{(float)(s[rr] * sc), (float)(s[4 + rr] * sc)};
+    }
+  } else if (job.wide == 1) {
     const int64_t i = (int64_t)bx * 16 + (threadIdx.x >> 4);
     const int sub = threadIdx.x & 15;
     double s = 0.0;
@@ -760,14 +798,23 @@ extern "C" int srwn_reduce_partials_multi(const SrwnReduceJob* jobs, int32_t njo
     if (q.nslabs < 1 || q.n < 0 || q.nbatch < 0 || q.nbatch > 65535)
       return set_error(SRWN_E_SHAPE, "reduce_partials_multi: job %d: nslabs=%d n=%lld nbatch=%d", k, q.nslabs, (long long)q.n, q.nbatch);
     RpJob& j = m.j[m.njobs++];
-    j.partials = q.partials; j.out = q.out; j.n = q.n; j.out_batch_stride = q.out_batch_stride;
+    j.partials = reinterpret_cast<const float*>(q.partials); j.out = q.out; j.n = q.n; j.out_batch_stride = q.out_batch_stride;
     j.nslabs = q.nslabs; j.nbatch = q.nbatch; j.part_batch_mul = q.partials_batched ? 1 : 0; j.scale = q.scale;
     j.wide = (q.n <= 4096 && q.nslabs >= 32) ? 1 : 0;           // the choice srwn_reduce_partials makes
     // >= 128 slabs of >= 1024 outputs (16-byte aligned blocks): the four-outputs-per-thread body
     if (q.nslabs >= 128 && q.n >= 1024 && q.n % 4 == 0 && q.out_batch_stride % 4 == 0 &&
         (reinterpret_cast<uintptr_t>(q.partials) | reinterpret_cast<uintptr_t>(q.out)) % 16 == 0)
       j.wide = 2;
-    j.blocks_x = (unsigned)(j.wide == 2 ? (q.n / 4 + 255) / 256 : j.wide ? (q.n + 15) / 16 : (q.n + 255) / 256);
+    j.blk_cols = 0;
+    if (q.layout == SRWN_PARTIALS_BLK16) {
+      if (q.blk_cols < 16 || q.blk_cols % 16 || q.n % (16 * (int64_t)q.blk_cols) || q.out_batch_stride % 2 ||
+          (reinterpret_cast<uintptr_t>(q.partials) % 16) || (reinterpret_cast<uintptr_t>(q.out) % 8))
+        return set_error(SRWN_E_SHAPE, "reduce_partials_multi: job %d: BLK16 layout needs n = rows*blk_cols in whole 16 x 16 blocks (n=%lld, blk_cols=%d)", k, (long long)q.n, q.blk_cols);
+      j.wide = 3; j.blk_cols = q.blk_cols;
+    } else if (q.layout != SRWN_PARTIALS_F32) {
+      return set_error(SRWN_E_UNSUPPORTED, "reduce_partials_multi: job %d: layout %d", k, q.layout);
+    }
+    j.blocks_x = (unsigned)(j.wide == 3 ? (q.n / 8 + 255) / 256 : j.wide == 2 ? (q.n / 4 + 255) / 256 : j.wide ? (q.n + 15) / 16 : (q.n + 255) / 256);
     j.block0 = (unsigned)blocks;
     blocks += (uint64_t)j.blocks_x * (uint64_t)q.nbatch;
     if (blocks > 0x7fffffffull) return set_error(SRWN_E_SHAPE, "reduce_partials_multi: grid too large");

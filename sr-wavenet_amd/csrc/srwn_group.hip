@@ -433,8 +433,12 @@ struct GroupBwdArgs {
   // xT / cT + g*wt_stride, tile (seg, k) at ((seg*KT)+k)*R*32) and the partial sums (layer g, slab s at ((g*nslabs)+s)*n
   // floats, in the layout srwn_wgrad_layers writes); df is not stored, G only with write_all_g
   const void* xT; const void* cT; int64_t wt_stride; int KT;
-  float* part_f; float* part_r; float* part_bf; float* part_br;
-  int nslabs, write_all_g;
+  // part_f / part_r: fp32 in srwn_wgrad_layers' layout, or (P16 instantiations: a.part16) bf16 16 x 16 blocks in lane
+  // order -- block (row block rb, column block ob) of a [rows, R] matrix at ((slab * nblocks) + rb * (R/16) + ob) * 256
+  // elements, lane l's four values (rows 16 rb + 4 (l >> 4) + 0..3 of column 16 ob + (l & 15)) at + 4 l: one 8-byte
+  // store per lane and block, a wave's block one contiguous 512 bytes (SRWN_PARTIALS_BLK16 of srwn_reduce_partials_multi)
+  void* part_f; void* part_r; float* part_bf; float* part_br;
+  int nslabs, write_all_g, part16;
   unsigned long long* stamps;     // diagnostic instantiation only (srwn_debug_stamp_buffer): waves 0 and 4 of workgroup 0
   int dbg;                        // diagnostic build only (SRWN_WT_DEBUG): 1 = skip the dWr contraction, 2 = skip the dWf one
 };
@@ -450,8 +454,9 @@ constexpr int kWtPadRows = 64;
 constexpr bool kWtStagger = false;   // half of the waves contract dWf before their taps, half after
 constexpr bool kWtEarlyC = false;    // the next layer's first c^T fragments requested a phase early   // finite (zero) rows behind the image: the shifted tap of the last weight-gradient tile reads past it
 
-template <typename T, int RT, bool DCS, int MAXT, int NWB, int NWV = 8, bool WT = false, bool STAMP = false>
+template <typename T, int RT, bool DCS, int MAXT, int NWB, int NWV = 8, bool WT = false, bool STAMP = false, bool P16 = false>
 __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
+  static_assert(!P16 || (WT && sizeof(T) == 2), "16-bit partial blocks: the bf16 weight-gradient-tile mode only");
   constexpr int R = 32 * RT, K = 2, KS = R / 16;
   Stamper<STAMP> stamp{nullptr, 0};      // (tools/gb_stamps.py) lane 0 of waves 0 and 4 -- the two waves of SIMD 0 -- of workgroup 0
   if (STAMP && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) & 3) == 0) stamp.p = a.stamps + (threadIdx.x >> 8) * 512;
@@ -768,7 +773,20 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
         }
         if (active) {
           // one 16 x 16 block per accumulator: lane l holds rows 4 (l >> 4) + rr of column l & 15
-          float* pl = a.part_r + pslab * (R * R) + (size_t)(16 * ib + 4 * (lw >> 4)) * R + 16 * ob0 + (lw & 15);
+          if constexpr (P16) {      // bf16 blocks in lane order: one 8-byte store per lane and block
+            typedef typename Raw4g<bf16_t>::type p4;
+            bf16_t* pl = reinterpret_cast<bf16_t*>(a.part_r) + ((pslab * NBLK + (size_t)(ib * NIB + ob0)) * 64 + lw) * 4;
+#pragma unroll
+            for (int bb = 0; bb < NBW; ++bb) {
+              if (sit > 0) {
+                const p4 o = *reinterpret_cast<const p4*>(pl + bb * 256);
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) acc[bb][rr] += (float)o[rr];
+              }
+              if (!(WT_DBG(a) & 16)) *reinterpret_cast<p4*>(pl + bb * 256) = Raw4g<bf16_t>::pack(acc[bb][0], acc[bb][1], acc[bb][2], acc[bb][3]);
+            }
+          } else {
+          float* pl = reinterpret_cast<float*>(a.part_r) + pslab * (R * R) + (size_t)(16 * ib + 4 * (lw >> 4)) * R + 16 * ob0 + (lw & 15);
           if (sit > 0) {       // a later segment of this workgroup: its sums join the earlier ones (fixed order)
 #pragma unroll
             for (int bb = 0; bb < NBW; ++bb) {
@@ -782,6 +800,7 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) pl[rr * R + 16 * bb] = acc[bb][rr];
             }
+          }
           }
         }
         if (!haveg) colsum(a.part_br + pslab * R, 0, false);      // (no gradient from above: dbr = 0 is still written)
@@ -949,7 +968,20 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) av[j] = bv[j];
           }
-          float* pl = a.part_f + pslab * (2 * R * R) + (size_t)tap * R * R + (size_t)(16 * ib + 4 * (lw >> 4)) * R + 16 * ob0 + (lw & 15);
+          if constexpr (P16) {      // (the [2 R, R] matrix of both taps: row block tap * R/16 + ib)
+            typedef typename Raw4g<bf16_t>::type p4;
+            bf16_t* pl = reinterpret_cast<bf16_t*>(a.part_f) + ((pslab * (2 * NBLK5) + (size_t)(tap * NBLK5 + ib * NIB5 + ob0)) * 64 + lw) * 4;
+#pragma unroll
+            for (int bb = 0; bb < NBF; ++bb) {
+              if (sit > 0) {
+                const p4 o = *reinterpret_cast<const p4*>(pl + bb * 256);
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) acc[bb][rr] += (float)o[rr];
+              }
+              if (!(WT_DBG(a) & 16)) *reinterpret_cast<p4*>(pl + bb * 256) = Raw4g<bf16_t>::pack(acc[bb][0], acc[bb][1], acc[bb][2], acc[bb][3]);
+            }
+          } else {
+          float* pl = reinterpret_cast<float*>(a.part_f) + pslab * (2 * R * R) + (size_t)tap * R * R + (size_t)(16 * ib + 4 * (lw >> 4)) * R + 16 * ob0 + (lw & 15);
           if (sit > 0) {
 #pragma unroll
             for (int bb = 0; bb < NBF; ++bb) {
@@ -964,6 +996,7 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
             for (int rr = 0; rr < 4; ++rr) pl[rr * R + 16 * bb] = acc[bb][rr];
             }
           }
+          }
         }
       };   // dwf
       // Both only READ the image.  The contraction is a burst of HBM traffic (every x^T tile of the segment), the taps are
@@ -975,6 +1008,49 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
       stamp(28);
       if (NWB == 2 && g > 0) dma_wait();
       stamp(29);
+#ifdef SRWN_DIAG
+      // Priced, not shipped ("partial sums across workgroups"): what summing the per-workgroup weight-gradient
+      // partials INSIDE the launch would cost.  Bit 32: the publish half -- every wave drains its partial stores, the
+      // workgroup's barrier, one lane's agent-scope release and a ticket on the counter of (layer, quad of workgroups with
+      // equal blockIdx % 8: one XCD under round-robin dispatch).  Bit 64: the combine half as well -- the quad's last
+      // arriver reads the four 49-KB partials back (sc1 loads, agent acquire) and sums them.  The sums are discarded:
+      // results with these bits set are meaningless, only the launch time is read (tools/fence_probe.py).
+      if (WT && (WT_DBG(a) & 32) && a.stamps) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wg_barrier();
+        __shared__ unsigned s_ticket;
+        const unsigned quad = (blockIdx.x & 7u) + 8u * (blockIdx.x >> 5);      // blocks b, b+8, b+16, b+24 of one XCD
+        unsigned* counters = reinterpret_cast<unsigned*>(a.stamps + 1024);     // (behind the two stamp areas)
+        if (threadIdx.x == 0) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          s_ticket = __hip_atomic_fetch_add(counters + g * 64 + (quad & 63u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (WT_DBG(a) & 64) {
+          wg_barrier();
+          if ((s_ticket & 3u) == 3u) {      // the last of the four: combine
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const unsigned b0 = (blockIdx.x & 7u) + (blockIdx.x & ~31u);
+            f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+            for (unsigned j = 0; j < 4; ++j) {      // six 16-byte sc1 loads per thread and slab in flight, then one wait
+              const size_t slab = (size_t)g * a.nslabs + b0 + 8u * j;
+              const f32x4* pf = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.part_f) + slab * (2 * R * R)) + threadIdx.x;
+              const f32x4* pr = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.part_r) + slab * (R * R)) + threadIdx.x;
+              constexpr int NF = 2 * R * R / 4 / (64 * NWV), NR = R * R / 4 / (64 * NWV);
+              f32x4 v[NF + NR > 0 ? NF + NR : 1];
+#pragma unroll
+              for (int i = 0; i < NF; ++i) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[i]) : "v"(pf + i * 64 * NWV) : "memory");
+#pragma unroll
+              for (int i = 0; i < NR; ++i) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[NF + i]) : "v"(pr + i * 64 * NWV) : "memory");
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+              for (int i = 0; i < NF + NR; ++i) { asm volatile("" : "+v"(v[i])); sum += v[i]; }
+            }
+            if (sum[0] + sum[1] + sum[2] + sum[3] == 12345.678f) counters[4095] = 1;      // (keeps the loads alive)
+          }
+        }
+      }
+#endif
       wg_barrier();
       stamp(30);
     }
@@ -1068,8 +1144,11 @@ int launch_group_bwd(GroupBwdArgs& a, int seg_rows, hipStream_t st) {
 #define SRWN_GB(D)                                                                                              \
   {                                                                                                             \
     auto kfn = two ? group_bwd_kernel<T, RT, D, MT2, NWB, NWV, WT> : group_bwd_kernel<T, RT, D, MAXT, NWB, NWV, WT>; \
+    if constexpr (WT && sizeof(T) == 2) {                                                                          \
+      if (a.part16) kfn = two ? group_bwd_kernel<T, RT, D, MT2, NWB, NWV, WT, false, true> : group_bwd_kernel<T, RT, D, MAXT, NWB, NWV, WT, false, true>; \
+    }                                                                                                           \
     if constexpr (WT && D && sizeof(T) == 2 && RT == 2) {                                                        \
-      SRWN_DIAG_ONLY(if (g_stamps) { a.stamps = g_stamps; kfn = two ? group_bwd_kernel<T, RT, D, MT2, NWB, NWV, WT, true> : group_bwd_kernel<T, RT, D, MAXT, NWB, NWV, WT, true>; }) \
+      SRWN_DIAG_ONLY(if (g_stamps && !a.part16) { a.stamps = g_stamps; if (!(a.dbg & 32)) kfn = two ? group_bwd_kernel<T, RT, D, MT2, NWB, NWV, WT, true> : group_bwd_kernel<T, RT, D, MAXT, NWB, NWV, WT, true>; }) \
     }                                                                                                           \
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);  \
     if (e != hipSuccess) return set_error((int)e, "residual_group_bwd: LDS %zu: %s", sh, hipGetErrorString(e)); \
@@ -1085,7 +1164,7 @@ int launch_group_bwd(GroupBwdArgs& a, int seg_rows, hipStream_t st) {
 namespace {
 struct WtBwd {   // the extra operands of srwn_residual_group_bwd_wt
   const void* xT; const void* cT; int64_t wt_stride;
-  float* part_f; float* part_r; float* part_bf; float* part_br; int nslabs; int write_all_g;
+  void* part_f; void* part_r; float* part_bf; float* part_br; int nslabs; int write_all_g; int part16;
 };
 }
 
@@ -1108,13 +1187,15 @@ static int group_bwd_impl(const void* g_top, void* g_out, void* df_out, const vo
   if (!g_top && !dcs) return set_error(SRWN_E_SHAPE, "residual_group_bwd: no top gradient and no skip path: every gradient would be zero");
   GroupBwdArgs a;
   a.g_top = g_top; a.g_out = g_out; a.df_out = df_out; a.z = z; a.dcs = dcs; a.layer_stride = layer_stride;
-  a.xT = a.cT = nullptr; a.wt_stride = 0; a.KT = 0; a.part_f = a.part_r = a.part_bf = a.part_br = nullptr; a.nslabs = 0; a.write_all_g = 0;
+  a.xT = a.cT = nullptr; a.wt_stride = 0; a.KT = 0; a.part_f = a.part_r = nullptr; a.part_bf = a.part_br = nullptr; a.nslabs = 0; a.write_all_g = 0; a.part16 = 0;
   a.dbg = 0;
   SRWN_DIAG_ONLY(static const int wt_dbg = [] { const char* e = getenv("SRWN_WT_DEBUG"); return e ? atoi(e) : 0; }(); a.dbg = wt_dbg;)
   a.stamps = nullptr;
   if (wt) {
     a.xT = wt->xT; a.cT = wt->cT; a.wt_stride = wt->wt_stride; a.part_f = wt->part_f; a.part_r = wt->part_r;
     a.part_bf = wt->part_bf; a.part_br = wt->part_br; a.nslabs = wt->nslabs; a.write_all_g = wt->write_all_g ? 1 : 0;
+    a.part16 = wt->part16 ? 1 : 0;
+    if (a.part16 && dtype != SRWN_BF16) return set_error(SRWN_E_UNSUPPORTED, "residual_group_bwd_wt: 16-bit partial blocks are the bf16 mode's (dtype %d)", dtype);
   }
   for (int g = 0; g < kMaxGroup; ++g) {
     const bool in = g < nlayers;
@@ -1160,10 +1241,10 @@ extern "C" int srwn_residual_group_bwd(const void* g_top, void* g_out, void* df_
 extern "C" int srwn_residual_group_bwd_wt(const void* g_top, void* g_out, int32_t write_all_g, const void* z,
                                           const void* dcs, int64_t layer_stride, const void* xT, const void* cT,
                                           int64_t wt_layer_stride, const void* const* wconvT, const void* const* wresT,
-                                          const int32_t* dilations, int32_t nlayers, float* part_f, float* part_r,
-                                          float* part_bf, float* part_br, int32_t nslabs, int32_t B, int32_t T,
+                                          const int32_t* dilations, int32_t nlayers, void* part_f, void* part_r,
+                                          float* part_bf, float* part_br, int32_t part16, int32_t nslabs, int32_t B, int32_t T,
                                           int32_t R, int32_t K, int32_t seg_rows, int32_t dtype, void* stream) {
-  const WtBwd wt{xT, cT, wt_layer_stride, part_f, part_r, part_bf, part_br, nslabs, write_all_g};
+  const WtBwd wt{xT, cT, wt_layer_stride, part_f, part_r, part_bf, part_br, nslabs, write_all_g, part16};
   return group_bwd_impl(g_top, g_out, nullptr, z, dcs, layer_stride, wconvT, wresT, dilations, nlayers, B, T, R, K, seg_rows,
                         dtype, stream, &wt);
 }

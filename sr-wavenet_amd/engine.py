@@ -454,9 +454,16 @@ class WaveNetEngine:
             cus = torch.cuda.get_device_properties(self.dev).multi_processor_count if torch.cuda.is_available() else 256
             widest = max(l1 - l0 for l0, l1 in self.groups)
             self.nslabs = int(max(1, min(cus // widest, (N + 255) // 256, 256)))
+        # SRWN_PART16 (default on; bf16 weight-gradient-tile mode only): the per-workgroup partial sums of the conv-tap and
+        # residual 1x1 weight gradients are stored in the compute type (16 x 16 blocks in lane order) instead of fp32 --
+        # 256 workgroups x 30 layers x 48 KB = 0.38 GB per step written by the backward group kernels and read back by the
+        # reduction, halved, for one more bf16 rounding per partial (measured: +1.3e-4 .. 5.7e-4 relative L2 on those
+        # gradients, whose bf16-mode error against the exact-fp32 mode is 7e-3: DESIGN.md 4c)
+        self.part16 = (self.fused_wt and self.dt == torch.bfloat16 and _os.environ.get("SRWN_PART16", "1") != "0")
         if self.use_wl:
             ns = self.nslabs
-            self.pl_f = z(L * ns * 2 * R * R, dt=torch.float32); self.pl_r = z(L * ns * R * R, dt=torch.float32)
+            pdt = torch.bfloat16 if self.part16 else torch.float32
+            self.pl_f = z(L * ns * 2 * R * R, dt=pdt); self.pl_r = z(L * ns * R * R, dt=pdt)
             self.pl_bf = z(L * ns * R, dt=torch.float32); self.pl_br = z(L * ns * R, dt=torch.float32)
         from . import _lib
         self.ic_ws = z(int(_lib.load().srwn_init_conv_wgrad_partials(B, T, R, self.Kw)), dt=torch.float32)
@@ -874,9 +881,10 @@ class WaveNetEngine:
         NR = N * R
         xs_p, zs_p, dfs_p, gs_p = self.xs.data_ptr(), self.zs.data_ptr(), self.dfs.data_ptr(), self.gs.data_ptr()
         if self.use_wl:
-            jobs = [(self.pl_f, ns, Kw * R * R, L, True, 1.0, gp + 4 * sec["WF"].offset, Kw * R * R),
+            blk = (R,) if self.part16 else ()      # (bf16 partial blocks in lane order: SRWN_PARTIALS_BLK16, R columns)
+            jobs = [(self.pl_f, ns, Kw * R * R, L, True, 1.0, gp + 4 * sec["WF"].offset, Kw * R * R) + blk,
                     (self.pl_bf, ns, R, L, True, 1.0, gp + 4 * sec["BF"].offset, R),
-                    (self.pl_r, ns, R * R, L, True, SQRT_HALF, gp + 4 * sec["WR"].offset, R * R),
+                    (self.pl_r, ns, R * R, L, True, SQRT_HALF, gp + 4 * sec["WR"].offset, R * R) + blk,
                     (self.pl_br, ns, R, L, True, SQRT_HALF, gp + 4 * sec["BR"].offset, R)]
             if self._ic_job is not None:      # the input conv's kernel + bias gradient (init_w | init_b are adjacent)
                 jobs.append(self._ic_job)

@@ -311,7 +311,8 @@ def residual_group_bwd_wt(g_top: Optional[torch.Tensor], g_out: torch.Tensor, z:
                           K: int = 2, write_all_g: bool = False):
     """Backward chain of a layer group + its layer weight-gradient partials in one launch (8 waves, output-split; the A
     operands are the forward kernel's weight-gradient tiles xT / cT [>=n, elems]).  g_out / z / dcs: [n,B,T,R] stacks;
-    part_*: fp32 partial buffers starting at the group's first layer, [n][nslabs][2RR | RR | R | R]."""
+    part_*: partial buffers starting at the group's first layer, [n][nslabs][2RR | RR | R | R]; part_f / part_r fp32, or in
+    the compute type bf16 -- the kernel then writes them as 16 x 16 blocks in lane order (reduce with layout BLK16)."""
     import ctypes as C
     n = len(dilations)
     _, B, T, R = z.shape
@@ -329,17 +330,21 @@ def residual_group_bwd_wt(g_top: Optional[torch.Tensor], g_out: torch.Tensor, z:
         _chk(t, name, z.dtype)
         if t.dim() != 2 or t.shape[0] < n:
             raise ValueError("%s: shape %s, expected [>=%d, elems]" % (name, tuple(t.shape), n))
+    part16 = part_f.dtype == torch.bfloat16
+    if part16 and (z.dtype != torch.bfloat16 or part_r.dtype != torch.bfloat16):
+        raise ValueError("residual_group_bwd_wt: bf16 partial blocks go with bf16 activations (part_f and part_r alike)")
     for name, t, per in (("part_f", part_f, 2 * R * R), ("part_r", part_r, R * R), ("part_bf", part_bf, R),
                          ("part_br", part_br, R)):
-        _chk(t, name, torch.float32)
+        _chk(t, name, torch.bfloat16 if (part16 and name in ("part_f", "part_r")) else torch.float32)
         if t.numel() < n * nslabs * per:
-            raise ValueError("%s: %d floats, needs %d" % (name, t.numel(), n * nslabs * per))
+            raise ValueError("%s: %d elements, needs %d" % (name, t.numel(), n * nslabs * per))
     pg = _opt(g_top, "g_top", z.dtype, (B, T, R))
     dl = (C.c_int32 * n)(*[int(d) for d in dilations])
     call("srwn_residual_group_bwd_wt", pg, g_out.data_ptr(), 1 if write_all_g else 0, z.data_ptr(),
          None if dcs is None else dcs.data_ptr(), B * T * R, xT.data_ptr(), cT.data_ptr(), int(xT.shape[1]),
          _ptr_array(wconvT_ptrs), _ptr_array(wresT_ptrs), dl, n, part_f.data_ptr(), part_r.data_ptr(),
-         part_bf.data_ptr(), part_br.data_ptr(), int(nslabs), B, T, R, int(K), int(seg_rows), dt, _stream())
+         part_bf.data_ptr(), part_br.data_ptr(), 1 if part16 else 0, int(nslabs), B, T, R, int(K), int(seg_rows), dt,
+         _stream())
 
 
 def residual_group_bwd(g_top: Optional[torch.Tensor], g_out: torch.Tensor, df_out: torch.Tensor, z: torch.Tensor,
@@ -618,14 +623,18 @@ class _ReduceJob(_ct.Structure):
     """include/srwn.h: SrwnReduceJob"""
     _fields_ = [("partials", _ct.c_void_p), ("nslabs", _ct.c_int32), ("n", _ct.c_int64), ("nbatch", _ct.c_int32),
                 ("partials_batched", _ct.c_int32), ("scale", _ct.c_float), ("out", _ct.c_void_p),
-                ("out_batch_stride", _ct.c_int64)]
+                ("out_batch_stride", _ct.c_int64), ("layout", _ct.c_int32), ("blk_cols", _ct.c_int32)]
 
 
 def reduce_partials_multi(jobs):
-    """jobs: the argument tuples of `reduce_partials`, finished by one launch (at most 16)."""
+    """jobs: the argument tuples of `reduce_partials`, finished by one launch (at most 16).  A ninth entry `blk_cols`
+    marks a bf16 partial buffer in 16 x 16-block lane order (SRWN_PARTIALS_BLK16; n = rows * blk_cols)."""
     arr = (_ReduceJob * len(jobs))()
-    for j, (partials, nslabs, n, nbatch, batched, scale, out_ptr, out_stride) in zip(arr, jobs):
-        j.partials = _chk(partials, "partials", torch.float32)
+    for j, job in zip(arr, jobs):
+        partials, nslabs, n, nbatch, batched, scale, out_ptr, out_stride = job[:8]
+        blk_cols = int(job[8]) if len(job) > 8 else 0
+        j.partials = _chk(partials, "partials", torch.bfloat16 if blk_cols else torch.float32)
+        j.layout, j.blk_cols = (1, blk_cols) if blk_cols else (0, 0)
         j.nslabs, j.n, j.nbatch, j.partials_batched = int(nslabs), int(n), int(nbatch), int(bool(batched))
         j.scale, j.out, j.out_batch_stride = float(scale), int(out_ptr), int(out_stride)
     call("srwn_reduce_partials_multi", _ct.addressof(arr), len(jobs), _stream())

@@ -12,6 +12,9 @@ from tests.test_gpu_kernels import DEV
 
 pytestmark = pytest.mark.gpu
 
+PART16_TOL = 5e-3      # bf16 partial blocks vs fp32 partials, kernel gradients: 2 x the worst measured (1.5e-3 .. 2.4e-3 over these
+#                        shapes, few segments each; config 2 at full size: 1.3e-4 .. 5.7e-4, tools/partial16_probe.py)
+
 
 def _pair(monkeypatch, dil, B, T, R, S, C, dt, E=0, pool=1, seg_rows=0, seed=3, ref_fuse="0", fuse_wt="0"):
     """The same model twice: one launch per layer (SRWN_FUSE=0) and the multi-layer kernels.  fuse_wt = "1": the second
@@ -374,3 +377,75 @@ def test_head_chain_equals_separate_launches(monkeypatch, B, T, C):
     gr, gf = ref.named_tensors(ref.grads), fus.named_tensors(fus.grads)
     for n in gr:
         assert _rel(gf[n], gr[n]) < 2e-2, "%s: %g" % (n, _rel(gf[n], gr[n]))
+
+
+def _blk16(mat):
+    """[rows, cols] fp32 -> the SRWN_PARTIALS_BLK16 order: 16 x 16 blocks (row block major), each as 64 lanes x 4 values --
+    lane l holds rows 4 (l >> 4) + 0..3 of column l & 15 (the accumulator layout of v_mfma_f32_16x16x32_bf16)."""
+    rows, cols = mat.shape
+    b = mat.reshape(rows // 16, 4, 4, cols // 16, 16)          # [rb][l>>4][rr][cb][l&15]
+    return b.permute(0, 3, 1, 4, 2).reshape(-1)               # [rb][cb][l>>4][l&15][rr]
+
+
+@pytest.mark.parametrize("rows,cols,nslabs,nbatch", [(128, 64, 256, 3), (64, 64, 37, 2), (64, 32, 8, 1), (32, 32, 300, 5)])
+def test_reduce_partials_bf16_blocks(rows, cols, nslabs, nbatch):
+    """srwn_reduce_partials_multi on the bf16 16 x 16-block layout the backward group kernel writes with part16: equal (to
+    the bit) to the fp32-slab reduction of the same (bf16-representable) values."""
+    K = sub("kernels")
+    g = torch.Generator(device="cpu").manual_seed(rows + nslabs)
+    vals = torch.randn(nbatch, nslabs, rows, cols, generator=g).bfloat16()
+    blocks = torch.stack([torch.stack([_blk16(vals[l, s].float()) for s in range(nslabs)]) for l in range(nbatch)]).bfloat16()
+    n = rows * cols
+    out16 = torch.full((nbatch, n + 8), float("nan"), dtype=torch.float32, device=DEV)
+    out32 = torch.full((nbatch, n + 8), float("nan"), dtype=torch.float32, device=DEV)
+    p16 = blocks.to(DEV).contiguous().view(-1)
+    p32 = vals.float().to(DEV).contiguous().view(-1)
+    K.reduce_partials_multi([(p16, nslabs, n, nbatch, True, 0.5, out16.data_ptr(), n + 8, cols)])
+    K.reduce_partials_multi([(p32, nslabs, n, nbatch, True, 0.5, out32.data_ptr(), n + 8)])
+    assert torch.equal(out16[:, :n], out32[:, :n])
+    assert bool(torch.isnan(out16[:, n:]).all())              # nothing written beyond a batch's block
+    ref = 0.5 * vals.double().sum(1).reshape(nbatch, n)
+    assert float((out16[:, :n].cpu().double() - ref).abs().max()) < 1e-4 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("dil,B,T,R,S,seg", SHAPES)
+def test_group_wt_bf16_partial_blocks_vs_fp32_partials(monkeypatch, dil, B, T, R, S, seg):
+    """SRWN_PART16 (default): the backward group kernels store their per-workgroup weight-gradient partials as bf16 blocks
+    instead of fp32.  Same chain, same products: activations, bottom gradients and every gradient that does not pass
+    through those partials are bit-equal to the fp32-partial build of the same path; the conv-tap and residual 1x1 kernel
+    gradients differ by one bf16 rounding per partial sum (bound: 2 x the worst measured over these shapes)."""
+    EG = sub("engine")
+    cfg = EG.StackConfig(dilations=list(dil), dilation_channels=R, skip_channels=S, output_channels=64, shift_input=True,
+                         dtype=torch.bfloat16)
+    monkeypatch.setenv("SRWN_SEG_ROWS", str(seg))
+    engs = []
+    for p16 in ("0", "1"):
+        monkeypatch.setenv("SRWN_PART16", p16)
+        e = EG.WaveNetEngine(cfg, B, T, DEV, seed=3)
+        assert e.fused_wt and e.part16 == (p16 == "1")
+        engs.append(e)
+    ref, fus = engs
+    rng = np.random.default_rng(3)
+    audio = torch.tensor(np.clip(0.5 * np.sin(np.arange(B * T).reshape(B, T) * 0.05) + 0.1 * rng.normal(size=(B, T)), -1, 1),
+                         dtype=torch.float32, device=DEV)
+    tg = torch.tensor(rng.integers(0, 64, size=(B, T)), dtype=torch.int32, device=DEV)
+    for e in engs:
+        e.set_inputs(audio, tg)
+        e.forward(); e.backward()
+    torch.cuda.synchronize()
+    assert float(ref.loss.item()) == float(fus.loss.item())
+    for l0, _ in fus.groups:
+        assert torch.equal(ref.gs[l0], fus.gs[l0])
+    import os
+    worst = 0.0
+    for name, sec in fus.sections.items():
+        a, b = ref.view(name, ref.grads), fus.view(name, fus.grads)
+        if name in ("WF", "WR"):
+            assert bool(torch.isfinite(b).all())
+            e = _rel(b, a)
+            worst = max(worst, e)
+            assert e < PART16_TOL, (name, e)
+        else:
+            assert torch.equal(a, b), name
+    if os.environ.get("SRWN_PRINT_ERR"):
+        print("MEASURED part16 vs fp32 partials, WF/WR rel (%s B=%d T=%d R=%d): %.3e" % (dil, B, T, R, worst))

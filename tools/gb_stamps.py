@@ -4,6 +4,7 @@ workgroup 0, waves 0 and 4 = the two waves of SIMD 0): s_memtime cycles between 
 import importlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ["SRWN_PART16"] = "0"      # (this tool reads / stamps the fp32-partial instantiation)
 # the stamped kernel instantiations live in the diagnostic build only (python sr-wavenet_amd/build.py --diag)
 os.environ.setdefault("SRWN_LIB_PATH", os.path.join(ROOT, "sr-wavenet_amd", "libsrwn_diag.so"))
 import torch
