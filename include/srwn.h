@@ -386,11 +386,14 @@ int srwn_wgrad_layers(const void* x, const void* z, const void* df, const void* 
  * the dilations) and the segment length (srwn_group_wt_geometry) of the group layer l was run in -- they fix which
  * positions its tiles hold; d: dskip [B*T, d_row_stride] (256 columns used).  Partials in srwn_wgrad256's layout:
  * partials[slab][nlayers*64][256], bias_partials[slab][256] (column sums of d; may be NULL); nslabs from
- * srwn_wgrad_skip_wt_slabs.  bf16, R = 64, S = 256 (csrc/srwn_wgradt.hip); other shapes: srwn_wgrad_wide on z. */
+ * srwn_wgrad_skip_wt_slabs.  part16 != 0: `partials` holds the same [nlayers*64, 256] matrix per slab in bf16, as 16 x 16
+ * blocks in lane order (SRWN_PARTIALS_BLK16 with 256 columns: half the partial bytes both ways, one more bf16 rounding
+ * per partial sum).  bf16, R = 64, S = 256 (csrc/srwn_wgradt.hip); other shapes: srwn_wgrad_wide on z. */
 int32_t srwn_wgrad_skip_wt_slabs(const int32_t* st, const int32_t* seg_rows, int32_t nlayers, int32_t T);
 int srwn_wgrad_skip_wt(const void* cT, int64_t wt_layer_stride, const int32_t* st, const int32_t* seg_rows,
-                       int32_t nlayers, const void* d, int64_t d_row_stride, float* partials, float* bias_partials,
-                       int32_t nslabs, int32_t B, int32_t T, int32_t R, int32_t S, int32_t dtype, void* stream);
+                       int32_t nlayers, const void* d, int64_t d_row_stride, void* partials, float* bias_partials,
+                       int32_t part16, int32_t nslabs, int32_t B, int32_t T, int32_t R, int32_t S, int32_t dtype,
+                       void* stream);
 
 /* ---- queue-cached incremental generation (BASELINE config 5; the reference only has the O(T^2 L) loop
  * of teacher.py:140-171).  Persistent workgroups generate `nsteps` samples, 32 utterances per workgroup,

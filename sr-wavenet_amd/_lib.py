@@ -87,7 +87,7 @@ SIGNATURES = {
     "srwn_wgrad_layers": (C.c_int, [_p, _p, _p, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i32, _p, _p, _p, _p, _i64,
                                     _i32, _i32, _i32, _i32, _i32, _p]),
     "srwn_wgrad_skip_wt_slabs": (_i32, [_p, _p, _i32, _i32]),
-    "srwn_wgrad_skip_wt": (C.c_int, [_p, _i64, _p, _p, _i32, _p, _i64, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    "srwn_wgrad_skip_wt": (C.c_int, [_p, _i64, _p, _p, _i32, _p, _i64, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "srwn_generate_ring_elems": (_i64, [_p, _i32, _i32]),
     "srwn_generate": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32,
                                 _i32, _i32, _i32, _i32, _i32, _i32, C.c_uint64, _i32, _p]),

@@ -85,7 +85,6 @@ __global__ __launch_bounds__(64 * rg_waves(EPI, NT), (EPI == SRWN_EPI_SOFTMAX_CE
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  SRWN_PRIO_YOUNG(1, wave, 4);
   const int col = lane & 31, half = lane >> 5;
   const int64_t tile0 = ((int64_t)blockIdx.x * kRgWaves + wave) * NT;   // first 32-row tile of this wave
   int64_t rowv[NT];
@@ -454,7 +453,6 @@ __global__ __launch_bounds__(64 * NW) void colgemm_kernel(CgArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [NBUF][CHUNK_B] weights | NW row stages
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  SRWN_PRIO_YOUNG(2, wave, NW / 2);
   const int col = lane & 31, half = lane >> 5;
   T* stage = reinterpret_cast<T*>(smem + NBUF * CHUNK_B) + wave * (32 * RowStage<T>::stride(R));
   const int64_t row0 = ((int64_t)blockIdx.x * NW + wave) * 32;

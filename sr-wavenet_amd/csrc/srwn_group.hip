@@ -83,7 +83,6 @@ __global__ __launch_bounds__(64 * NWV) void group_fwd_kernel(GroupFwdArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 31, half = lane >> 5;
   const int rsub = lane / LPR, piece = lane % LPR;
-  SRWN_PRIO_YOUNG(16, wave, NWV / 2);
   Stamper<STAMP> stamp{nullptr, 0};
   if (STAMP && blockIdx.x == 0 && lane == 0 && (wave & 3) == 0 && wave < 8) stamp.p = a.stamps + (wave >> 2) * 512;   // waves 0 and 4: the two waves of SIMD 0
   stamp(1);
@@ -475,7 +474,6 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 31, half = lane >> 5;
   const int rsub = lane / LPR, piece = lane % LPR;
-  SRWN_PRIO_YOUNG(32, wave, NWV / 2);
 
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   auto wload = [&](int g, int buf) {   // layer g's [convT | resT] images -> weight buffer `buf` by LDS-DMA
@@ -619,9 +617,6 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
       rows_load(reinterpret_cast<const T*>(a.z) + (size_t)g * a.layer_stride, q, zr);
       if (DCS) rows_load(reinterpret_cast<const T*>(a.dcs) + (size_t)g * a.layer_stride, q, dr);
     };
-#ifdef SRWN_EXP_EARLY_ISSUE
-    issue(gtop, wave < a.NT ? wave : a.NT - 1);      // (experiment: the first tile's z / dcs requested before the top gradient's rows)
-#endif
 #pragma unroll
     for (int m = 0; m < MAXT; ++m) {
       const int q = wave + NWV * m;
@@ -645,9 +640,7 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
     }
     dma_wait();
     // operands of the first tile of the top layer (one tile ahead from here on)
-#ifndef SRWN_EXP_EARLY_ISSUE
     issue(gtop, wave < a.NT ? wave : a.NT - 1);
-#endif
     wg_barrier();
 
     for (int n = 0; n < a.nl; ++n) {

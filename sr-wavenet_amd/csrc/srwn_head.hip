@@ -83,7 +83,6 @@ __global__ __launch_bounds__(64 * kHcWaves) void headchain_kernel(HcArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][CHUNK_B] weights | 8 row stages
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  SRWN_PRIO_YOUNG(4, wave, kHcWaves / 2);
   const int col = lane & 31, half = lane >> 5;
   const int64_t tile = (int64_t)blockIdx.x * kHcWaves + wave;
   const int64_t r0row = tile * 32;

@@ -36,7 +36,8 @@ struct WtBlk { int nl; int layer[4]; int st, W, nsub, KT; };
 struct WtSkipArgs {
   const void* cT; long long wt_stride;
   const void* d; long long d_row_stride;
-  float* partials; float* bias_partials;
+  void* partials; float* bias_partials;      // partials: fp32 [slab][layer*64 + n][256], or (part16) the same matrix as bf16
+  int part16;                                //           16 x 16 blocks in lane order (SRWN_PARTIALS_BLK16, 256 columns)
   int B, Tlen, nslabs, mtotal;
   int safe_wait;                         // SRWN_SAFE_WAIT: vmcnt(0) instead of the counted waits
   int bias_blk;                          // the block whose idle waves sum dskip's columns (-1: none does)
@@ -62,7 +63,6 @@ struct Cursor {
 __global__ __launch_bounds__(512) void wgrad_skip_wt_kernel(WtSkipArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  SRWN_PRIO_YOUNG(8, wave, 4);
   const int slab = blockIdx.x;
   const WtBlk& bk = a.blk[blockIdx.y];
   const int st = bk.st, W = bk.W, nsub = bk.nsub, KT = bk.KT;
@@ -218,8 +218,18 @@ __global__ __launch_bounds__(512) void wgrad_skip_wt_kernel(WtSkipArgs a) {
 #undef SRWN_WT_ITER
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(A0[0]), "+v"(A1[0]), "+v"(A2[0])::"memory");   // nothing in flight at exit
 
-  if (live) {
-    float* pb = a.partials + ((size_t)slab * a.mtotal + (size_t)layer * 64) * 256 + 128 * nh + (lane & 15);
+  if (live && a.part16) {      // block (row block layer*4 + mb, column block 8 nh + i): one 8-byte store per lane
+    bf16_t* pb = reinterpret_cast<bf16_t*>(a.partials) + (size_t)slab * a.mtotal * 256;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const size_t blk = (size_t)(layer * 4 + mb) * 16 + 8 * nh + i;
+        *reinterpret_cast<bf16x4*>(pb + (blk * 64 + lane) * 4) =
+            bf16x4{(bf16_t)acc[mb][i][0], (bf16_t)acc[mb][i][1], (bf16_t)acc[mb][i][2], (bf16_t)acc[mb][i][3]};
+      }
+  } else if (live) {
+    float* pb = reinterpret_cast<float*>(a.partials) + ((size_t)slab * a.mtotal + (size_t)layer * 64) * 256 + 128 * nh + (lane & 15);
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
@@ -289,9 +299,9 @@ extern "C" int32_t srwn_wgrad_skip_wt_slabs(const int32_t* st, const int32_t* se
 }
 
 extern "C" int srwn_wgrad_skip_wt(const void* cT, int64_t wt_layer_stride, const int32_t* st, const int32_t* seg_rows,
-                                  int32_t nlayers, const void* d, int64_t d_row_stride, float* partials,
-                                  float* bias_partials, int32_t nslabs, int32_t B, int32_t T, int32_t R, int32_t S,
-                                  int32_t dtype, void* stream) {
+                                  int32_t nlayers, const void* d, int64_t d_row_stride, void* partials,
+                                  float* bias_partials, int32_t part16, int32_t nslabs, int32_t B, int32_t T, int32_t R,
+                                  int32_t S, int32_t dtype, void* stream) {
   if (B == 0 || T == 0 || nlayers == 0) return 0;
   if (!cT || !st || !seg_rows || !d || !partials) return set_error(SRWN_E_NULL, "wgrad_skip_wt: null pointer");
   if (dtype != SRWN_BF16 || R != 64 || S != 256)
@@ -303,6 +313,7 @@ extern "C" int srwn_wgrad_skip_wt(const void* cT, int64_t wt_layer_stride, const
     if (st[l] < 1 || seg_rows[l] < 1) return set_error(SRWN_E_SHAPE, "wgrad_skip_wt: layer %d stride %d segment %d", l, st[l], seg_rows[l]);
   WtSkipArgs a;
   a.cT = cT; a.wt_stride = wt_layer_stride; a.d = d; a.d_row_stride = d_row_stride; a.partials = partials;
+  a.part16 = part16 ? 1 : 0;
   a.bias_partials = bias_partials; a.B = B; a.Tlen = T; a.nslabs = nslabs; a.mtotal = nlayers * 64;
   const int nb = plan_blocks(st, seg_rows, nlayers, T, a.blk);
   if (nb < 1) return set_error(SRWN_E_UNSUPPORTED, "wgrad_skip_wt: more than %d layer blocks", kMaxBlk);

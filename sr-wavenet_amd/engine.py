@@ -509,9 +509,13 @@ class WaveNetEngine:
         # skip weight gradients from the forward's transposed gate outputs (csrc/srwn_wgradt.hip)
         self.skip_wt = (self.use_w256 and self.fused_wt and self.dt == torch.bfloat16 and (R, S) == (64, 256)
                         and _os_environ_flag("SRWN_WGRAD_WT", True))
+        self.skip_parts16 = None
         if self.skip_wt:
             self.ns_skip_wt = K.wgrad_skip_wt_slabs(self.wt_layer_st, self.wt_layer_seg, T)
-            big = max(big, -(-self.ns_skip_wt * L * R * S // self.nslabs))
+            if self.part16:      # its partial slabs in the compute type too (a buffer of their own: wg_parts is fp32)
+                self.skip_parts16 = z(self.ns_skip_wt * L * R * S)
+            else:
+                big = max(big, -(-self.ns_skip_wt * L * R * S // self.nslabs))
         self.wg_parts = z(self.nslabs * big, dt=torch.float32)
         self.wg_bparts = z(max(self.nslabs * max(L * S, Cp), 256 * 256), dt=torch.float32)
         # the two head products keep partials of their own, so that skip + head finish in ONE reduction launch
@@ -916,7 +920,8 @@ class WaveNetEngine:
             with _Span(self, "wgrad_skip"):
                 if self.skip_wt and self.fused_wt:
                     ns_skip = self.ns_skip_wt
-                    K.wgrad_skip_wt(self.cTs, self.wt_layer_st, self.wt_layer_seg, self.dtotal, self.wg_parts,
+                    K.wgrad_skip_wt(self.cTs, self.wt_layer_st, self.wt_layer_seg, self.dtotal,
+                                    self.wg_parts if self.skip_parts16 is None else self.skip_parts16,
                                     self.wg_bparts, ns_skip, self.B, T, R)
                 else:
                     K.wgrad256(zs_p, NR, R, L, self.dtotal, self.wg_parts, self.wg_bparts, N, self.ns_skip,
@@ -929,7 +934,9 @@ class WaveNetEngine:
                 K.wgrad256(self.r0.data_ptr(), 64, S, S // 64, self.da1, self.hd_parts[0], self.hd_bparts[0], N, self.ns_head)
                 K.wgrad256(self.r1.data_ptr(), 64, S, S // 64, self.dlogits, self.hd_parts[1], self.hd_bparts[1], N,
                            self.ns_head)
+            skip16 = self.skip_wt and self.fused_wt and self.skip_parts16 is not None
             K.reduce_partials_multi([
+                (self.skip_parts16, ns_skip, L * R * S, 1, True, 1.0, gp + 4 * sec["WS"].offset, 0, S) if skip16 else
                 (self.wg_parts, ns_skip, L * R * S, 1, True, 1.0, gp + 4 * sec["WS"].offset, 0),
                 (self.wg_bparts, ns_skip, S, L, False, 1.0, gp + 4 * sec["BS"].offset, S),
                 (self.hd_parts[0], self.ns_head, S * S, 1, True, 1.0, gp + 4 * sec["head_w1"].offset, 0),
@@ -943,12 +950,16 @@ class WaveNetEngine:
             with _Span(self, "wgrad_skip"):
                 if self.skip_wt and self.fused_wt:
                     ns_skip = self.ns_skip_wt
-                    K.wgrad_skip_wt(self.cTs, self.wt_layer_st, self.wt_layer_seg, self.dtotal, self.wg_parts,
+                    K.wgrad_skip_wt(self.cTs, self.wt_layer_st, self.wt_layer_seg, self.dtotal,
+                                    self.wg_parts if self.skip_parts16 is None else self.skip_parts16,
                                     self.wg_bparts, ns_skip, self.B, T, R)
                 else:
                     K.wgrad256(zs_p, NR, R, L, self.dtotal, self.wg_parts, self.wg_bparts, N, self.ns_skip,
                                pro=K.PRO_GATE, chunk_width=R)
-            K.reduce_partials(self.wg_parts, ns_skip, L * R * S, 1, True, 1.0, gp + 4 * sec["WS"].offset, 0)
+            if self.skip_wt and self.fused_wt and self.skip_parts16 is not None:
+                K.reduce_partials_multi([(self.skip_parts16, ns_skip, L * R * S, 1, True, 1.0, gp + 4 * sec["WS"].offset, 0, S)])
+            else:
+                K.reduce_partials(self.wg_parts, ns_skip, L * R * S, 1, True, 1.0, gp + 4 * sec["WS"].offset, 0)
             K.reduce_partials(self.wg_bparts, ns_skip, S, L, False, 1.0, gp + 4 * sec["BS"].offset, S)
             K.wgrad256(self.r0.data_ptr(), 64, S, S // 64, self.da1, self.wg_parts, self.wg_bparts, N, self.ns_head)
             K.reduce_partials(self.wg_parts, self.ns_head, S * S, 1, True, 1.0, gp + 4 * sec["head_w1"].offset, 0)

@@ -596,21 +596,24 @@ def wgrad_skip_wt_slabs(st, seg_rows, T: int) -> int:
 def wgrad_skip_wt(cT: torch.Tensor, st, seg_rows, d: torch.Tensor, partials: torch.Tensor,
                   bias_partials: Optional[torch.Tensor], nslabs: int, B: int, T: int, R: int):
     """Skip 1x1 weight gradients of every layer from the transposed gate outputs cT [L, elems] the forward group kernels
-    wrote (st / seg_rows: per layer, the stride and segment length of its group); d: dskip [B*T, 256]."""
+    wrote (st / seg_rows: per layer, the stride and segment length of its group); d: dskip [B*T, 256].  partials: fp32
+    [slab][L*R][S], or bf16: the kernel then writes each slab's matrix as 16 x 16 blocks in lane order (BLK16, S columns)."""
     L = cT.shape[0]
     if len(st) != L or len(seg_rows) != L or d.shape[0] != B * T:
         raise ValueError("wgrad_skip_wt: %d layers, st %d, seg_rows %d, d %s" % (L, len(st), len(seg_rows), tuple(d.shape)))
     S = d.shape[-1]
-    pp = _chk(partials, "partials", torch.float32)
+    part16 = partials.dtype == torch.bfloat16
+    pp = _chk(partials, "partials", torch.bfloat16 if part16 else torch.float32)
     if partials.numel() < nslabs * L * R * S:
-        raise ValueError("wgrad_skip_wt: partials needs %d floats" % (nslabs * L * R * S))
+        raise ValueError("wgrad_skip_wt: partials needs %d elements" % (nslabs * L * R * S))
     pb = None
     if bias_partials is not None:
         pb = _chk(bias_partials, "bias_partials", torch.float32)
         if bias_partials.numel() < nslabs * S:
             raise ValueError("wgrad_skip_wt: bias_partials needs %d floats" % (nslabs * S))
     call("srwn_wgrad_skip_wt", _chk(cT, "cT"), int(cT.stride(0)), _i32_array(st), _i32_array(seg_rows), L, _chk(d, "d"),
-         int(d.stride(0)), pp, pb, int(nslabs), int(B), int(T), int(R), int(S), abi_dtype(d.dtype), _stream())
+         int(d.stride(0)), pp, pb, 1 if part16 else 0, int(nslabs), int(B), int(T), int(R), int(S), abi_dtype(d.dtype),
+         _stream())
 
 
 def reduce_partials(partials: torch.Tensor, nslabs: int, n: int, nbatch: int, partials_batched: bool, scale: float,

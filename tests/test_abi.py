@@ -68,12 +68,12 @@ def test_argument_errors_do_not_need_a_gpu(binding):
     # the round-3 entry points: the same contract
     import ctypes as C
     i32 = lambda *v: (C.c_int32 * len(v))(*v)
-    assert lib.srwn_wgrad_skip_wt(None, 0, None, None, 0, None, 256, None, None, 1, 8, 100, 64, 256, 1, None) == 0    # no layers
-    assert lib.srwn_wgrad_skip_wt(None, 0, i32(1), i32(100), 1, None, 256, None, None, 1, 1, 100, 64, 256, 1, None) == -3
-    assert lib.srwn_wgrad_skip_wt(1, 1 << 20, i32(1), i32(100), 1, 1, 256, 1, None, 1, 1, 100, 64, 256, 0, None) == -4     # fp32: not built
-    assert lib.srwn_wgrad_skip_wt(1, 1 << 20, i32(1), i32(100), 1, 1, 256, 1, None, 1, 1, 100, 32, 128, 1, None) == -4     # widths
-    assert lib.srwn_wgrad_skip_wt(1, 10, i32(1), i32(100), 1, 1, 256, 1, None, 1, 1, 100, 64, 256, 1, None) == -2          # tiles exceed the layer stride
-    assert lib.srwn_wgrad_skip_wt(1, 1 << 20, i32(0), i32(100), 1, 1, 256, 1, None, 1, 1, 100, 64, 256, 1, None) == -2     # stride 0
+    assert lib.srwn_wgrad_skip_wt(None, 0, None, None, 0, None, 256, None, None, 0, 1, 8, 100, 64, 256, 1, None) == 0    # no layers
+    assert lib.srwn_wgrad_skip_wt(None, 0, i32(1), i32(100), 1, None, 256, None, None, 0, 1, 1, 100, 64, 256, 1, None) == -3
+    assert lib.srwn_wgrad_skip_wt(1, 1 << 20, i32(1), i32(100), 1, 1, 256, 1, None, 0, 1, 1, 100, 64, 256, 0, None) == -4     # fp32: not built
+    assert lib.srwn_wgrad_skip_wt(1, 1 << 20, i32(1), i32(100), 1, 1, 256, 1, None, 0, 1, 1, 100, 32, 128, 1, None) == -4     # widths
+    assert lib.srwn_wgrad_skip_wt(1, 10, i32(1), i32(100), 1, 1, 256, 1, None, 0, 1, 1, 100, 64, 256, 1, None) == -2          # tiles exceed the layer stride
+    assert lib.srwn_wgrad_skip_wt(1, 1 << 20, i32(0), i32(100), 1, 1, 256, 1, None, 0, 1, 1, 100, 64, 256, 1, None) == -2     # stride 0
     assert lib.srwn_wgrad_skip_wt_slabs(i32(1, 1, 1, 1, 32, 32), i32(500, 500, 500, 500, 500, 500), 6, 16000) >= 1
     assert lib.srwn_generate16(None, None, None, None, None, None, None, None, None, None, None, None, None, None, None, None,
                                2, 0, 8, 8, 64, 256, 256, 0, 0, None) == 0                                                  # no utterances
