@@ -11,6 +11,11 @@ using namespace srwn;
 // the block whose add comes last -- every other block has read the count by then -- stores the new count.  No payload
 // crosses workgroups: the arrival counter is the upper half of the 64-bit step word, zero again when the launch ends
 // (the final store writes the whole word), so the word reads as a plain int64 step count between launches.
+constexpr int kAdamBlocks = 256;      // one block per CU
+static unsigned adam_grid(int64_t n) {
+  const int64_t b = (n + 1023) / 1024;
+  return (unsigned)(b < kAdamBlocks ? b : kAdamBlocks);
+}
 static int adam_vec(const void* a, const void* b, const void* c, const void* d) {
   return ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)d)) & 15) == 0;
 }
@@ -36,14 +41,16 @@ __global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ thet
   __syncthreads();
   const float lr_t = s_lr;
   if (scale_dev) grad_scale *= scale_dev[0];
-  const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   auto one = [&](float gi, float& mi, float& vi, float& th) {
     gi *= grad_scale;
     mi = b1 * mi + (1.0f - b1) * gi;
     vi = b2 * vi + (1.0f - b2) * gi * gi;
     th -= lr_t * mi / (sqrtf(vi) + eps);
   };
-  if (i0 < n) {
+  // at most kAdamBlocks blocks walk the buffer (grid stride): every block is one arrival on ONE counter, and arrivals on
+  // one address are served one after the other at the memory side (~12 ns each: 980 blocks -- one per 1024 parameters --
+  // made this a 18-us kernel; 256 arrivals cost ~3 us)
+  for (int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i0 < n; i0 += (int64_t)gridDim.x * blockDim.x * 4) {
     if (vec && i0 + 4 <= n) {      // vec: all four buffers 16-byte aligned (host check)
       typedef float f4 __attribute__((ext_vector_type(4)));
       f4 gg = *reinterpret_cast<const f4*>(g + i0), mm = *reinterpret_cast<f4*>(m + i0), vv = *reinterpret_cast<f4*>(v + i0),
@@ -71,7 +78,7 @@ extern "C" int srwn_adam_step(float* params, const float* grads, float* m, float
   if (!params || !grads || !m || !v || !step) return set_error(SRWN_E_NULL, "adam_step: null pointer");
   if (n < 0) return set_error(SRWN_E_SHAPE, "adam_step: n=%lld", (long long)n);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, params, grads, m, v, n,
+  hipLaunchKernelGGL(adam_step_kernel, dim3(adam_grid(n)), dim3(256), 0, st, params, grads, m, v, n,
                      step, 1, lr, beta1, beta2, eps, grad_scale, (const float*)nullptr, adam_vec(params, grads, m, v));
   return check_launch("adam_step");
 }
@@ -86,7 +93,7 @@ extern "C" int srwn_adam_step_scaled(float* params, const float* grads, float* m
     return set_error(SRWN_E_NULL, "adam_step_scaled: null pointer");
   if (n < 0) return set_error(SRWN_E_SHAPE, "adam_step_scaled: n=%lld", (long long)n);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, params, grads, m, v, n,
+  hipLaunchKernelGGL(adam_step_kernel, dim3(adam_grid(n)), dim3(256), 0, st, params, grads, m, v, n,
                      step, tick ? 1 : 0, lr, beta1, beta2, eps, 1.0f, grad_scale_dev, adam_vec(params, grads, m, v));
   return check_launch("adam_step_scaled");
 }
