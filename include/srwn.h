@@ -162,6 +162,19 @@ int srwn_residual_group_fwd_wt(const void* x0, void* x_out, void* z_out, int64_t
                                int32_t cond_frames, int32_t pool_stride, int32_t cond_row_stride,
                                const int32_t* dilations, int32_t nlayers, int32_t B, int32_t T, int32_t R, int32_t K,
                                int32_t seg_rows, int32_t dtype, void* stream);
+/* the FIRST group of a stack with the stack's input conv fused in (model.py:40 / 172-173: DilatedCausalConv1d 1 -> R,
+ * K = 2 taps, d = 1; RightShift, ops.py:78-80, as `shift` in {0, 1}): what srwn_causal_conv1d_fwd(audio, init_w, init_b)
+ * would have written as the group's input is computed into the kernel's segment image in the same arithmetic (the
+ * activations are bit-identical) and never reaches HBM -- one launch, a 2*R-byte-per-sample write and the read that
+ * fetches it back less.  audio [B,T] fp32, init_w [2,1,R], init_b [R] fp32.  Otherwise srwn_residual_group_fwd_wt (xT / cT
+ * required).  Not built for the conditioned decoders (their first layer's bias is added
+ * to the input conv's output: srwn_add_frame_bias). */
+int srwn_residual_group_fwd_ic(const float* audio, const float* init_w, const float* init_b, int32_t shift, void* x_out,
+                               void* z_out, int64_t layer_stride, void* xT, void* cT, int64_t wt_layer_stride,
+                               int32_t store_inner_x, const void* const* wconv, const void* const* wres,
+                               const float* const* bias_f, const float* const* bias_r, const int32_t* dilations,
+                               int32_t nlayers, int32_t B, int32_t T, int32_t R, int32_t K, int32_t seg_rows,
+                               int32_t dtype, void* stream);
 int srwn_residual_group_bwd_wt(const void* g_top, void* g_out, int32_t write_all_g, const void* z, const void* dcs,
                                int64_t layer_stride, const void* xT, const void* cT, int64_t wt_layer_stride,
                                const void* const* wconvT, const void* const* wresT, const int32_t* dilations,

@@ -47,6 +47,8 @@ SIGNATURES = {
     "srwn_group_wt_geometry": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p]),
     "srwn_residual_group_fwd_wt": (C.c_int, [_p, _p, _p, _i64, _p, _p, _i64, _i32, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p,
                                              _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    "srwn_residual_group_fwd_ic": (C.c_int, [_p, _p, _p, _i32, _p, _p, _i64, _p, _p, _i64, _i32, _p, _p, _p, _p, _p, _i32,
+                                             _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "srwn_residual_group_bwd_wt": (C.c_int, [_p, _p, _i32, _p, _p, _i64, _p, _p, _i64, _p, _p, _p, _i32, _p, _p, _p, _p,
                                              _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "srwn_debug_stamp_buffer": (C.c_int, [_p]),

@@ -51,6 +51,11 @@ struct GroupFwdArgs {
   // the positions each segment owns, layer g at xT / cT + g*wt_stride, tile (seg, k) at ((seg*KT)+k)*R*32
   void* xT; void* cT; int64_t wt_stride; int KT;
   int store_inner_x;              // WT: 0 = only the group's top layer stores its output rows (nothing reads the inner ones)
+  // input conv fused in (srwn_residual_group_fwd_ic; x0 == null): the group's input rows are computed where they would be
+  // loaded -- x0[b,t,c] = ic_b[c] + ic_w[0][c] audio[b, t-1-shift] + ic_w[1][c] audio[b, t-shift] (model.py:40 / 172-173,
+  // RightShift folded into the taps, zeros before the clip) -- instead of a launch that writes them and a read that
+  // fetches them back (16.4 MB each way for config 2)
+  const float* ic_audio; const float* ic_w; const float* ic_b; int ic_shift;
 };
 
 // In-kernel time stamps (MI355X guide, "In-kernel stamps"): lane 0 of waves 0 and 1 of workgroup 0 append the shader
@@ -66,8 +71,9 @@ template <> struct Stamper<true> {
   }
 };
 
-template <typename T, int RT, bool COND, int MAXT, int NWB, int NWV = 8, bool WDMA = true, bool STAMP = false, bool WT = false>
+template <typename T, int RT, bool COND, int MAXT, int NWB, int NWV = 8, bool WDMA = true, bool STAMP = false, bool WT = false, bool IC = false>
 __global__ __launch_bounds__(64 * NWV) void group_fwd_kernel(GroupFwdArgs a) {
+  static_assert(!IC || (WT && !COND), "input conv fused in: the unconditioned weight-gradient-tile kernels only");
   constexpr int R = 32 * RT, K = 2, KS = R / 16;
   constexpr int NCONV = RT * K * KS, NRES = RT * KS, NW = NCONV + NRES;   // weight fragments per layer
   constexpr int LS = RowStage<T>::stride(R), VEC = RowStage<T>::VEC;
@@ -163,7 +169,27 @@ __global__ __launch_bounds__(64 * NWV) void group_fwd_kernel(GroupFwdArgs a) {
 
     // ---- segment image + the first layer's weights
     wload(0, 0);
-    {
+    if constexpr (IC) {    // the input conv of the stack, in the arithmetic of causal_conv_cin1_kernel:
+      const int nrows = a.NT * 32;      // v = bias; v = fma(x[t-1-shift], w0, v); v = fma(x[t-shift], w1, v); one rounding to T
+      constexpr int RPP = 64 * NWV / LPR;
+      const int c0 = (tid % LPR) * VEC;
+      float w0[VEC], w1[VEC], bb[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { w0[e] = a.ic_w[c0 + e]; w1[e] = a.ic_w[R + c0 + e]; bb[e] = a.ic_b[c0 + e]; }
+      const float* au = a.ic_audio + clip;
+      for (int i = tid / LPR; i < nrows; i += RPP) {
+        const int t = (int)(grow(jbase + i) - clip);        // (rows beyond the clip are clamped re-computations, as the loads were)
+        const int t1 = t - a.ic_shift, t0 = t1 - 1;
+        const float x1 = (t1 >= 0 && t1 < a.Tlen) ? au[t1] : 0.0f;
+        const float x0v = (t0 >= 0 && t0 < a.Tlen) ? au[t0] : 0.0f;
+        float v[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[e] = fmaf(x1, w1[e], fmaf(x0v, w0[e], bb[e]));
+        T* dst = img + (size_t)i * LS + c0;
+#pragma unroll
+        for (int e = 0; e < VEC; e += 4) store4(dst + e, v[e], v[e + 1], v[e + 2], v[e + 3]);
+      }
+    } else {
       const T* x0 = reinterpret_cast<const T*>(a.x0);
       const int nrows = a.NT * 32;
       constexpr int RPP = 64 * NWV / LPR;            // rows per pass of the whole workgroup
@@ -1080,6 +1106,8 @@ template <typename T, int RT, int MAXT, int NWB, int NWV> int bwd_nt_max(bool wt
 
 template <typename T, int RT, int MAXT, int NWB, int NWV = 8, bool WDMA = true, bool STAMP = false, bool WT = false>
 int launch_group_fwd(GroupFwdArgs& a, bool cond, int seg_rows, hipStream_t st) {
+  if (a.ic_audio && (!WT || cond || STAMP))
+    return set_error(SRWN_E_UNSUPPORTED, "residual_group_fwd_ic: built for the unconditioned weight-gradient-tile kernels (pass xT / cT)");
   constexpr int R = 32 * RT, KS = R / 16, NW = RT * 2 * KS + RT * KS;
   const size_t fixed = (size_t)NWB * NW * 64 * sizeof(Frag<T>) + (size_t)NWB * 2 * R * 4;
   const size_t row_bytes = (size_t)RowStage<T>::stride(R) * sizeof(T);
@@ -1105,6 +1133,15 @@ int launch_group_fwd(GroupFwdArgs& a, bool cond, int seg_rows, hipStream_t st) {
     if (e != hipSuccess) return set_error((int)e, "residual_group_fwd: LDS %zu: %s", sh, hipGetErrorString(e)); \
     hipLaunchKernelGGL(kfn, grid, block, sh, st, a);                                                            \
     return check_launch("residual_group_fwd");                                                                  \
+  }
+  if constexpr (WT && !STAMP) {
+    if (a.ic_audio) {
+      auto kfn = group_fwd_kernel<T, RT, false, MAXT, NWB, NWV, WDMA, false, true, true>;
+      hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+      if (e != hipSuccess) return set_error((int)e, "residual_group_fwd_ic: LDS %zu: %s", sh, hipGetErrorString(e));
+      hipLaunchKernelGGL(kfn, grid, block, sh, st, a);
+      return check_launch("residual_group_fwd_ic");
+    }
   }
   if (cond) SRWN_GF(true) else SRWN_GF(false)
 #undef SRWN_GF
@@ -1248,9 +1285,17 @@ static int group_fwd_impl(const void* x0, void* x_out, void* z_out, int64_t laye
                           const void* const* cond_next, int32_t cond_frames, int32_t pool_stride,
                           int32_t cond_row_stride, const int32_t* dilations, int32_t nlayers, int32_t B,
                           int32_t T, int32_t R, int32_t K, int32_t seg_rows, int32_t dtype,
-                          void* stream, void* xT, void* cT, int64_t wt_stride, int32_t store_inner_x) {
+                          void* stream, void* xT, void* cT, int64_t wt_stride, int32_t store_inner_x,
+                          const float* ic_audio = nullptr, const float* ic_w = nullptr, const float* ic_b = nullptr,
+                          int32_t ic_shift = 0) {
   if (B == 0 || T == 0 || nlayers == 0) return 0;
   const bool wt = xT != nullptr || cT != nullptr;
+  if (ic_audio) {      // the input conv fused in: x0 is not read
+    if (!ic_w || !ic_b) return set_error(SRWN_E_NULL, "residual_group_fwd_ic: null pointer");
+    if (cond_next) return set_error(SRWN_E_UNSUPPORTED, "residual_group_fwd_ic: not built for the conditioned decoders");
+    if (ic_shift < 0 || ic_shift > 1) return set_error(SRWN_E_SHAPE, "residual_group_fwd_ic: shift %d", ic_shift);
+    x0 = ic_audio;      // (non-null for the checks below)
+  }
   if (wt && (!xT || !cT || seg_rows < 1 || wt_stride < 0))
     return set_error(SRWN_E_SHAPE, "residual_group_fwd_wt: xT, cT and seg_rows (srwn_group_wt_geometry) are all required");
   if (!x0 || !x_out || !z_out || !wconv || !wres || !bias_f || !bias_r || !dilations)
@@ -1264,6 +1309,8 @@ static int group_fwd_impl(const void* x0, void* x_out, void* z_out, int64_t laye
   a.safe_wait = safe_wait();
   a.x0 = x0; a.x_out = x_out; a.z_out = z_out; a.layer_stride = layer_stride;
   a.xT = xT; a.cT = cT; a.wt_stride = wt_stride; a.KT = 0; a.store_inner_x = store_inner_x ? 1 : 0;
+  a.ic_audio = ic_audio; a.ic_w = ic_w; a.ic_b = ic_b; a.ic_shift = ic_shift;
+  if (ic_audio) a.x0 = nullptr;
   bool any_cond = false;
   for (int g = 0; g < kMaxGroup; ++g) {
     const bool in = g < nlayers;
@@ -1339,6 +1386,24 @@ extern "C" int srwn_residual_group_fwd_wt(const void* x0, void* x_out, void* z_o
   return group_fwd_impl(x0, x_out, z_out, layer_stride, wconv, wres, bias_f, bias_r, cond_next, cond_frames, pool_stride,
                         cond_row_stride, dilations, nlayers, B, T, R, K, seg_rows, dtype, stream, xT, cT, wt_layer_stride,
                         store_inner_x);
+}
+
+// The FIRST group of a stack with the stack's input conv fused in (model.py:40 / 172-173; K = 2 taps, 1 -> R channels,
+// RightShift as `shift`): what srwn_causal_conv1d_fwd would have written to x0 is computed into the segment image, in
+// the same arithmetic (bit-identical activations), and never reaches HBM.
+extern "C" int srwn_residual_group_fwd_ic(const float* audio, const float* init_w, const float* init_b, int32_t shift,
+                                          void* x_out, void* z_out, int64_t layer_stride, void* xT, void* cT,
+                                          int64_t wt_layer_stride, int32_t store_inner_x, const void* const* wconv,
+                                          const void* const* wres, const float* const* bias_f,
+                                          const float* const* bias_r, const int32_t* dilations, int32_t nlayers,
+                                          int32_t B, int32_t T, int32_t R, int32_t K, int32_t seg_rows, int32_t dtype,
+                                          void* stream) {
+  if (B == 0 || T == 0 || nlayers == 0) return 0;
+  if (!audio) return set_error(SRWN_E_NULL, "residual_group_fwd_ic: null pointer");
+  if (!xT || !cT) return set_error(SRWN_E_NULL, "residual_group_fwd_ic: xT and cT are required (the weight-gradient-tile kernels)");
+  return group_fwd_impl(audio, x_out, z_out, layer_stride, wconv, wres, bias_f, bias_r, nullptr, 1, 1, R, dilations, nlayers,
+                        B, T, R, K, seg_rows, dtype, stream, xT, cT, wt_layer_stride, xT ? store_inner_x : 1, audio, init_w,
+                        init_b, shift);
 }
 
 // The segment cut both _wt kernels of a group must be given (seg_rows_in = 0: the library's choice), the weight-gradient

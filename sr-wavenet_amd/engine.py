@@ -116,6 +116,8 @@ class WaveNetEngine:
         # (csrc/srwn_group.hip, _wt entry points).  0: chain kernel + separate weight-gradient pass (the parity twin)
         self.fuse_wt = _os.environ.get("SRWN_FUSE_WT", "1") != "0"
         self.wt_store_x = _os.environ.get("SRWN_WT_STORE_X", "0") != "0"
+        # SRWN_FUSE_IC (default on): the input conv inside the first layer group's forward kernel (unconditioned stacks)
+        self.fuse_ic = _os.environ.get("SRWN_FUSE_IC", "1") != "0"
         # frozen: a stack that is never trained (a distillation teacher, model.py:334): fixed before allocation, so no
         # weight-gradient tiles / per-workgroup partial slabs are allocated for it and backward() refuses to run.  A
         # trainable stack can still be run forward-only (forward(train=False): the student does that to its teacher).
@@ -548,12 +550,17 @@ class WaveNetEngine:
         B, T, N, L, R, S = self.B, self.T, self.N, self.L, self.R, self.S
         es = self.packed.element_size()
         v = self.view
-        # input conv (model.py:40 / 172-173); RightShift folded into the tap offset
-        K.causal_conv1d_fwd(self.audio.view(B, T, 1), v("init_w"), v("init_b"), 1,
-                            1 if self.cfg.shift_input else 0, out=self.xs[0])
+        # input conv (model.py:40 / 172-173); RightShift folded into the tap offset.  Where the first layer group runs as a
+        # group kernel on an unconditioned stack, the conv is computed inside it (its output never reaches HBM: nothing else
+        # reads xs[0] unless the inner layer inputs are kept for inspection)
+        self._tiles_valid = bool(train) and self.fused_wt
+        self._ic_fused = (self.fuse_ic and self._tiles_valid and not self.E and self.Kw == 2 and not self.wt_store_x
+                          and bool(self.groups))
+        if not self._ic_fused:
+            K.causal_conv1d_fwd(self.audio.view(B, T, 1), v("init_w"), v("init_b"), 1,
+                                1 if self.cfg.shift_input else 0, out=self.xs[0])
         if self.E:
             self._cond_bias_to_input()
-        self._tiles_valid = bool(train) and self.fused_wt
         with _Span(self, "fwd_layers"):
             self._stack_fwd(self.cond_all if self.E else None, wt=self._tiles_valid)
         with _Span(self, "skip_sum"):      # model.py:50-51 (bs_sum = the sum of the layers' skip biases: formed by repack())
@@ -645,6 +652,17 @@ class WaveNetEngine:
             cond3 = [cond_all[l + 1].view(self.B, self.frames, self.R) if l + 1 < self.L else None for l in range(l0, l1)]
         wt = {}
         use_wt = use_wt and self.fused_wt
+        if l0 == 0 and getattr(self, "_ic_fused", False):
+            if use_wt:
+                wt = dict(xT=self.xTs[l0:l1], cT=self.cTs[l0:l1], store_inner_x=self.wt_store_x)
+            K.residual_group_fwd_ic(self.audio, v("init_w"), v("init_b"), 1 if self.cfg.shift_input else 0,
+                                    self.xs[l0 + 1:l1 + 1], self.zs[l0:l1],
+                                    [self.wptr(self.o_conv[l]) for l in range(l0, l1)],
+                                    [self.wptr(self.o_res[l]) for l in range(l0, l1)],
+                                    [v("BF")[l] for l in range(l0, l1)], [v("BR")[l] for l in range(l0, l1)],
+                                    self.dil[l0:l1], self.Kw,
+                                    seg_rows=self.wt_seg_rows[self.groups.index((l0, l1))] if use_wt else self.seg_rows, **wt)
+            return
         if use_wt:
             # (xs of the layers inside a group is NOT written in this mode: only the weight gradients would read it, and they
             # take the transposed tiles; SRWN_WT_STORE_X=1 keeps it for inspection)

@@ -305,6 +305,43 @@ def group_wt_geometry(dilations, B: int, T: int, R: int, dtype: torch.dtype, seg
     return sr.value, kt.value, el.value, ns.value
 
 
+def residual_group_fwd_ic(audio: torch.Tensor, init_w: torch.Tensor, init_b: torch.Tensor, shift: int, x_out: torch.Tensor,
+                          z_out: torch.Tensor, wconv_ptrs, wres_ptrs, biases_f, biases_r, dilations, K: int = 2,
+                          seg_rows: int = 0, xT: Optional[torch.Tensor] = None, cT: Optional[torch.Tensor] = None,
+                          store_inner_x: bool = True):
+    """The stack's FIRST layer group with the input conv fused in: `audio` [B,T] fp32 instead of the group's input rows
+    (srwn_residual_group_fwd_ic).  Other arguments as residual_group_fwd (no conditioning)."""
+    import ctypes as C
+    n = len(dilations)
+    B, T = audio.shape
+    R = z_out.shape[-1]
+    if not (len(wconv_ptrs) == len(wres_ptrs) == len(biases_f) == len(biases_r) == n):
+        raise ValueError("residual_group_fwd_ic: per-layer argument lists differ in length")
+    pa = _chk(audio, "audio", torch.float32)
+    pw = _chk(init_w, "init_w", torch.float32)
+    pb = _chk(init_b, "init_b", torch.float32, (R,))
+    if init_w.numel() != K * R:
+        raise ValueError("init_w: %d elements, expected %d" % (init_w.numel(), K * R))
+    for name, t in (("x_out", x_out), ("z_out", z_out)):
+        _chk(t, name, z_out.dtype)
+        if t.dim() != 4 or t.shape[0] < n or tuple(t.shape[1:]) != (B, T, R):
+            raise ValueError("%s: shape %s, expected [>=%d,%d,%d,%d]" % (name, tuple(t.shape), n, B, T, R))
+    pbf = [_chk(b, "bias_f", torch.float32, (R,)) for b in biases_f]
+    pbr = [_chk(b, "bias_r", torch.float32, (R,)) for b in biases_r]
+    px = pc = None
+    stride = 0
+    if xT is not None or cT is not None:
+        for name, t in (("xT", xT), ("cT", cT)):
+            _chk(t, name, z_out.dtype)
+            if t.dim() != 2 or t.shape[0] < n:
+                raise ValueError("%s: shape %s, expected [>=%d, elems]" % (name, tuple(t.shape), n))
+        px, pc, stride = xT.data_ptr(), cT.data_ptr(), int(xT.shape[1])
+    dl = (C.c_int32 * n)(*[int(d) for d in dilations])
+    call("srwn_residual_group_fwd_ic", pa, pw, pb, int(shift), x_out.data_ptr(), z_out.data_ptr(), B * T * R, px, pc, stride,
+         1 if store_inner_x else 0, _ptr_array(wconv_ptrs), _ptr_array(wres_ptrs), _ptr_array(pbf), _ptr_array(pbr), dl, n,
+         B, T, R, int(K), int(seg_rows), abi_dtype(z_out.dtype), _stream())
+
+
 def residual_group_bwd_wt(g_top: Optional[torch.Tensor], g_out: torch.Tensor, z: torch.Tensor, dcs: Optional[torch.Tensor],
                           xT: torch.Tensor, cT: torch.Tensor, wconvT_ptrs, wresT_ptrs, dilations, part_f: torch.Tensor,
                           part_r: torch.Tensor, part_bf: torch.Tensor, part_br: torch.Tensor, nslabs: int, seg_rows: int,

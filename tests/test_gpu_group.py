@@ -453,3 +453,41 @@ def test_group_wt_bf16_partial_blocks_vs_fp32_partials(monkeypatch, dil, B, T, R
             assert torch.equal(a, b), name
     if os.environ.get("SRWN_PRINT_ERR"):
         print("MEASURED part16 vs fp32 partials, WF/WR rel (%s B=%d T=%d R=%d): %.3e" % (dil, B, T, R, worst))
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dil,B,T,R,S,seg", [SHAPES[0], SHAPES[1], SHAPES[3], ([1, 2, 4], 3, 1, 64, 256, 0), ([512, 1], 1, 600, 64, 256, 0)])
+def test_input_conv_fused_into_the_first_group(monkeypatch, dt, dil, B, T, R, S, seg):
+    """SRWN_FUSE_IC (default): the stack's input conv (model.py:40 / 172-173, RightShift folded in) is computed inside the
+    first layer group's forward kernel instead of being a launch that writes the group's input rows and a read that
+    fetches them back.  Same arithmetic: every stored activation, the loss and every gradient are bit-equal to the
+    separate launch; xs[0] is not written in this mode."""
+    EG = sub("engine")
+    cfg = EG.StackConfig(dilations=list(dil), dilation_channels=R, skip_channels=S, output_channels=64, shift_input=True, dtype=dt)
+    monkeypatch.setenv("SRWN_SEG_ROWS", str(seg))
+    engs = []
+    for ic in ("0", "1"):
+        monkeypatch.setenv("SRWN_FUSE_IC", ic)
+        e = EG.WaveNetEngine(cfg, B, T, DEV, seed=3)
+        g = torch.Generator(device="cpu").manual_seed(5)
+        for name in ("init_b", "BF", "BR"):
+            e.view(name).copy_(0.1 * torch.randn(e.view(name).shape, generator=g))
+        e.repack()
+        engs.append(e)
+    ref, fus = engs
+    rng = np.random.default_rng(3)
+    audio = torch.tensor(np.clip(0.5 * np.sin(np.arange(B * T).reshape(B, T) * 0.05) + 0.1 * rng.normal(size=(B, T)), -1, 1),
+                         dtype=torch.float32, device=DEV)
+    tg = torch.tensor(rng.integers(0, 64, size=(B, T)), dtype=torch.int32, device=DEV)
+    for e in engs:
+        e.xs.fill_(7.0)
+        e.set_inputs(audio, tg)
+        e.forward(); e.backward()
+    torch.cuda.synchronize()
+    assert fus.fused_wt and fus._ic_fused and not ref._ic_fused
+    assert bool((fus.xs[0] == 7.0).all()) and not bool((ref.xs[0] == 7.0).any())
+    assert torch.equal(ref.zs, fus.zs) and torch.equal(ref.xTs, fus.xTs) and torch.equal(ref.cTs, fus.cTs)
+    for l0, l1 in fus.groups:
+        assert torch.equal(ref.xs[l1], fus.xs[l1])
+    assert float(ref.loss.item()) == float(fus.loss.item())
+    assert torch.equal(ref.grads, fus.grads)
