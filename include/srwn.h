@@ -152,7 +152,12 @@ int srwn_residual_group_bwd(const void* g_top, void* g_out, void* df_out, const 
  * of elements per (layer, slab), as 16 x 16 blocks in lane order (layout SRWN_PARTIALS_BLK16 of SrwnReduceJob below):
  * half the bytes both ways for one more bf16 rounding per partial sum (the 256 x 30 partials of config 2 are 0.38 GB per
  * step in fp32, written here and read back by the reduction; measured cost in accuracy: DESIGN.md 4c).  The two bias
- * partials stay fp32. */
+ * partials stay fp32.
+ * ic_audio != NULL (the stack's FIRST group, dcs given; bf16 mode: with part16): the launch also leaves the partial sums
+ * of the input conv's kernel and bias gradient (model.py:40; what srwn_init_conv_wgrad's first stage forms from g_out in a
+ * launch of its own) -- ic_partials[slab][3 R] = [sum_t audio[t-1-ic_shift] G_0[t,:] | sum_t audio[t-ic_shift] G_0[t,:] |
+ * sum_t G_0[t,:]] over the rows the workgroup's segments own, fp32, one slab per workgroup (`nslabs`); the audio enters
+ * the bf16 MFMA as a high and a low bf16 part (exact to 2^-17).  audio [B,T] fp32. */
 int srwn_group_wt_geometry(const int32_t* dilations, int32_t nlayers, int32_t B, int32_t T, int32_t R, int32_t dtype,
                            int32_t seg_rows_in, int32_t* seg_rows, int32_t* tiles_per_seg, int64_t* elems_per_layer,
                            int32_t* nslabs);
@@ -179,8 +184,9 @@ int srwn_residual_group_bwd_wt(const void* g_top, void* g_out, int32_t write_all
                                int64_t layer_stride, const void* xT, const void* cT, int64_t wt_layer_stride,
                                const void* const* wconvT, const void* const* wresT, const int32_t* dilations,
                                int32_t nlayers, void* part_f, void* part_r, float* part_bf, float* part_br,
-                               int32_t part16, int32_t nslabs, int32_t B, int32_t T, int32_t R, int32_t K,
-                               int32_t seg_rows, int32_t dtype, void* stream);
+                               int32_t part16, const float* ic_audio, float* ic_partials, int32_t ic_shift,
+                               int32_t nslabs, int32_t B, int32_t T, int32_t R, int32_t K, int32_t seg_rows,
+                               int32_t dtype, void* stream);
 /* the same cut chosen for a problem size (B clips of T steps, R channels, dtype): minimises the estimated run time of
  * the group kernels (tile rounds per layer + a fixed cost per launch) over all cuts into runs of <= max_layers layers. */
 int32_t srwn_group_plan_auto(const int32_t* dilations, int32_t nlayers, int32_t B, int32_t T, int32_t R, int32_t dtype,

@@ -50,7 +50,7 @@ SIGNATURES = {
     "srwn_residual_group_fwd_ic": (C.c_int, [_p, _p, _p, _i32, _p, _p, _i64, _p, _p, _i64, _i32, _p, _p, _p, _p, _p, _i32,
                                              _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "srwn_residual_group_bwd_wt": (C.c_int, [_p, _p, _i32, _p, _p, _i64, _p, _p, _i64, _p, _p, _p, _i32, _p, _p, _p, _p,
-                                             _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+                                             _i32, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "srwn_debug_stamp_buffer": (C.c_int, [_p]),
     "srwn_group_plan_auto": (_i32, [_p, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "srwn_log_softmax": (C.c_int, [_p, _p, _p, _i64, _i32, _p]),

@@ -464,6 +464,11 @@ struct GroupBwdArgs {
   // store per lane and block, a wave's block one contiguous 512 bytes (SRWN_PARTIALS_BLK16 of srwn_reduce_partials_multi)
   void* part_f; void* part_r; float* part_bf; float* part_br;
   int nslabs, write_all_g, part16;
+  // ICG instantiations (the stack's FIRST group): the input conv's kernel + bias gradient (model.py:40; tf.gradients of
+  // ops.py:6-20 for the 1 -> R conv) from the group's bottom gradient while it is in the image:
+  //   ic_part[slab][k*R + c] = sum_t audio[t - (1-k) - shift] G_0[t][c],   ic_part[slab][2R + c] = sum_t G_0[t][c]
+  // over the rows the workgroup's segments own (srwn_init_conv_wgrad's stage-1 layout, one slab per workgroup)
+  const float* ic_audio; float* ic_part; int ic_shift;
   unsigned long long* stamps;     // diagnostic instantiation only (srwn_debug_stamp_buffer): waves 0 and 4 of workgroup 0
   int dbg;                        // diagnostic build only (SRWN_WT_DEBUG): 1 = skip the dWr contraction, 2 = skip the dWf one
 };
@@ -479,9 +484,10 @@ constexpr int kWtPadRows = 64;
 constexpr bool kWtStagger = false;   // half of the waves contract dWf before their taps, half after
 constexpr bool kWtEarlyC = false;    // the next layer's first c^T fragments requested a phase early   // finite (zero) rows behind the image: the shifted tap of the last weight-gradient tile reads past it
 
-template <typename T, int RT, bool DCS, int MAXT, int NWB, int NWV = 8, bool WT = false, bool STAMP = false, bool P16 = false>
+template <typename T, int RT, bool DCS, int MAXT, int NWB, int NWV = 8, bool WT = false, bool STAMP = false, bool P16 = false, bool ICG = false>
 __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
   static_assert(!P16 || (WT && sizeof(T) == 2), "16-bit partial blocks: the bf16 weight-gradient-tile mode only");
+  static_assert(!ICG || WT, "input conv gradient: the weight-gradient-tile mode only");
   constexpr int R = 32 * RT, K = 2, KS = R / 16;
   Stamper<STAMP> stamp{nullptr, 0};      // (tools/gb_stamps.py) lane 0 of waves 0 and 4 -- the two waves of SIMD 0 -- of workgroup 0
   if (STAMP && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) & 3) == 0) stamp.p = a.stamps + (threadIdx.x >> 8) * 512;
@@ -1084,6 +1090,59 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
       tile_store_raw(img + (size_t)(32 * q) * LS, reinterpret_cast<T*>(a.g_out), q, hi, G[m]);
     }
     wg_barrier();
+    if constexpr (ICG) {
+      // ---- the input conv's weight gradient: every owned tile's G_0 is in the image now (tile_store_raw left it there;
+      // rows beyond the owned ones are masked in the A fragment).  Wave w < R/16 takes the 16 channels 16 w..: per tile one
+      // A fragment built from the audio -- row 0 / 1: audio[t-1-shift] as bf16 high / low part (fp32 mode: the value / 0),
+      // row 2 / 3: audio[t-shift] likewise, row 4: ones, time steps in the tiles' order kordW -- one transposing read, one
+      // MFMA.  It was a launch of its own reading the 2R bytes per sample this kernel has just written.
+      if (wave < R / 16) {
+        int lw = lane;
+        asm volatile("" : "+v"(lw));
+        const T* cb = LdT16p<T>::base(img, LS, lw) + 16 * wave;
+        const int arow = lw & 15, kg = lw >> 4;
+        const float* au = a.ic_audio + clip;
+        const int ktn = (Wseg + 31) / 32;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int k = 0; k < ktn; ++k) {
+          Frag<T> af;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int pos = 32 * k + kordW(kg, e);
+            const bool own = pos < Wseg;
+            const long long t = (long long)(jbase + pos) * a.st + r;
+            const long long t1 = t - a.ic_shift, t0 = t1 - 1;
+            float x = 0.0f;
+            if (arow < 4 && own) {
+              const long long tt = arow < 2 ? t0 : t1;
+              if (tt >= 0 && tt < a.Tlen) x = au[tt];
+            }
+            float val;
+            if (sizeof(T) == 2) {
+              const float hi_ = (float)(bf16_t)x;
+              val = (arow & 1) ? (x - hi_) : hi_;        // rows 0, 2: high part; rows 1, 3: what bf16 dropped
+            } else {
+              val = (arow & 1) ? 0.0f : x;
+            }
+            if (arow == 4) val = own ? 1.0f : 0.0f;
+            if (arow > 4) val = 0.0f;
+            af.set(e, val);
+          }
+          const Frag<T> bfv = LdT16p<T>::template load<LS>(cb + (size_t)(32 * k) * LS, 0);
+          mma16(acc, af, bfv);
+        }
+        // D: lane l holds rows 4 (l >> 4) + 0..3 of column l & 15
+        float* pp = a.ic_part + (size_t)blockIdx.x * (3 * R) + 16 * wave + (lw & 15);
+        if (lw < 16) {
+          pp[0] = (sit > 0 ? pp[0] : 0.0f) + (acc[0] + acc[1]);
+          pp[R] = (sit > 0 ? pp[R] : 0.0f) + (acc[2] + acc[3]);
+        } else if (lw < 32) {
+          pp[2 * R] = (sit > 0 ? pp[2 * R] : 0.0f) + acc[0];
+        }
+      }
+      wg_barrier();      // (the next segment zeroes the image)
+    }
   }
 }
 
@@ -1177,8 +1236,16 @@ int launch_group_bwd(GroupBwdArgs& a, int seg_rows, hipStream_t st) {
     if constexpr (WT && sizeof(T) == 2) {                                                                          \
       if (a.part16) kfn = two ? group_bwd_kernel<T, RT, D, MT2, NWB, NWV, WT, false, true> : group_bwd_kernel<T, RT, D, MAXT, NWB, NWV, WT, false, true>; \
     }                                                                                                           \
+    if constexpr (WT && D) {                                                                                     \
+      if (a.ic_audio) {                                                                                          \
+        if (sizeof(T) == 2 && !a.part16) return set_error(SRWN_E_UNSUPPORTED, "residual_group_bwd_wt: the input conv gradient goes with bf16 partial blocks (part16) in bf16 mode"); \
+        kfn = two ? group_bwd_kernel<T, RT, D, MT2, NWB, NWV, WT, false, sizeof(T) == 2, true> : group_bwd_kernel<T, RT, D, MAXT, NWB, NWV, WT, false, sizeof(T) == 2, true>; \
+      }                                                                                                          \
+    } else {                                                                                                     \
+      if (a.ic_audio) return set_error(SRWN_E_UNSUPPORTED, "residual_group_bwd_wt: the input conv gradient is built for stacks with a skip path"); \
+    }                                                                                                           \
     if constexpr (WT && D && sizeof(T) == 2 && RT == 2) {                                                        \
-      SRWN_DIAG_ONLY(if (g_stamps && !a.part16) { a.stamps = g_stamps; if (!(a.dbg & 32)) kfn = two ? group_bwd_kernel<T, RT, D, MT2, NWB, NWV, WT, true> : group_bwd_kernel<T, RT, D, MAXT, NWB, NWV, WT, true>; }) \
+      SRWN_DIAG_ONLY(if (g_stamps && !a.part16 && !a.ic_audio) { a.stamps = g_stamps; if (!(a.dbg & 32)) kfn = two ? group_bwd_kernel<T, RT, D, MT2, NWB, NWV, WT, true> : group_bwd_kernel<T, RT, D, MAXT, NWB, NWV, WT, true>; }) \
     }                                                                                                           \
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);  \
     if (e != hipSuccess) return set_error((int)e, "residual_group_bwd: LDS %zu: %s", sh, hipGetErrorString(e)); \
@@ -1195,6 +1262,7 @@ namespace {
 struct WtBwd {   // the extra operands of srwn_residual_group_bwd_wt
   const void* xT; const void* cT; int64_t wt_stride;
   void* part_f; void* part_r; float* part_bf; float* part_br; int nslabs; int write_all_g; int part16;
+  const float* ic_audio; float* ic_part; int ic_shift;
 };
 }
 
@@ -1218,6 +1286,7 @@ static int group_bwd_impl(const void* g_top, void* g_out, void* df_out, const vo
   GroupBwdArgs a;
   a.g_top = g_top; a.g_out = g_out; a.df_out = df_out; a.z = z; a.dcs = dcs; a.layer_stride = layer_stride;
   a.xT = a.cT = nullptr; a.wt_stride = 0; a.KT = 0; a.part_f = a.part_r = nullptr; a.part_bf = a.part_br = nullptr; a.nslabs = 0; a.write_all_g = 0; a.part16 = 0;
+  a.ic_audio = nullptr; a.ic_part = nullptr; a.ic_shift = 0;
   a.dbg = 0;
   SRWN_DIAG_ONLY(static const int wt_dbg = [] { const char* e = getenv("SRWN_WT_DEBUG"); return e ? atoi(e) : 0; }(); a.dbg = wt_dbg;)
   a.stamps = nullptr;
@@ -1225,6 +1294,11 @@ static int group_bwd_impl(const void* g_top, void* g_out, void* df_out, const vo
     a.xT = wt->xT; a.cT = wt->cT; a.wt_stride = wt->wt_stride; a.part_f = wt->part_f; a.part_r = wt->part_r;
     a.part_bf = wt->part_bf; a.part_br = wt->part_br; a.nslabs = wt->nslabs; a.write_all_g = wt->write_all_g ? 1 : 0;
     a.part16 = wt->part16 ? 1 : 0;
+    if (wt->ic_audio) {
+      if (!wt->ic_part) return set_error(SRWN_E_NULL, "residual_group_bwd_wt: ic_audio without ic_partials");
+      if (wt->ic_shift < 0 || wt->ic_shift > 1) return set_error(SRWN_E_SHAPE, "residual_group_bwd_wt: ic_shift %d", wt->ic_shift);
+      a.ic_audio = wt->ic_audio; a.ic_part = wt->ic_part; a.ic_shift = wt->ic_shift;
+    }
     if (a.part16 && dtype != SRWN_BF16) return set_error(SRWN_E_UNSUPPORTED, "residual_group_bwd_wt: 16-bit partial blocks are the bf16 mode's (dtype %d)", dtype);
   }
   for (int g = 0; g < kMaxGroup; ++g) {
@@ -1272,9 +1346,10 @@ extern "C" int srwn_residual_group_bwd_wt(const void* g_top, void* g_out, int32_
                                           const void* dcs, int64_t layer_stride, const void* xT, const void* cT,
                                           int64_t wt_layer_stride, const void* const* wconvT, const void* const* wresT,
                                           const int32_t* dilations, int32_t nlayers, void* part_f, void* part_r,
-                                          float* part_bf, float* part_br, int32_t part16, int32_t nslabs, int32_t B, int32_t T,
+                                          float* part_bf, float* part_br, int32_t part16, const float* ic_audio,
+                                          float* ic_partials, int32_t ic_shift, int32_t nslabs, int32_t B, int32_t T,
                                           int32_t R, int32_t K, int32_t seg_rows, int32_t dtype, void* stream) {
-  const WtBwd wt{xT, cT, wt_layer_stride, part_f, part_r, part_bf, part_br, nslabs, write_all_g, part16};
+  const WtBwd wt{xT, cT, wt_layer_stride, part_f, part_r, part_bf, part_br, nslabs, write_all_g, part16, ic_audio, ic_partials, ic_shift};
   return group_bwd_impl(g_top, g_out, nullptr, z, dcs, layer_stride, wconvT, wresT, dilations, nlayers, B, T, R, K, seg_rows,
                         dtype, stream, &wt);
 }

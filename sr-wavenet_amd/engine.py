@@ -468,7 +468,13 @@ class WaveNetEngine:
             self.pl_f = z(L * ns * 2 * R * R, dt=pdt); self.pl_r = z(L * ns * R * R, dt=pdt)
             self.pl_bf = z(L * ns * R, dt=torch.float32); self.pl_br = z(L * ns * R, dt=torch.float32)
         from . import _lib
-        self.ic_ws = z(int(_lib.load().srwn_init_conv_wgrad_partials(B, T, R, self.Kw)), dt=torch.float32)
+        # the input conv's weight-gradient partials: srwn_init_conv_wgrad's stage-1 slabs, or -- default path, unconditioned
+        # stacks with a skip path -- one slab per workgroup of the FIRST group's backward launch, which forms them from its
+        # bottom gradient while it is on the chip (no launch of its own)
+        self.fuse_icg = (self.fused_wt and self.fuse_ic and not self.E and self.Kw == 2 and self.use_dcs
+                         and (self.part16 or self.dt == torch.float32))
+        self.ic_ws = z(max(int(_lib.load().srwn_init_conv_wgrad_partials(B, T, R, self.Kw)),
+                           self.nslabs * (self.Kw + 1) * R if self.fuse_icg else 0), dt=torch.float32)
         if self.E:
             self.cond_in = z(B * self.frames, self.Ep)
             self.cond_all = z(L, B * self.frames, R)      # cb of every layer, layer by layer: a layer's frame rows are dense
@@ -748,7 +754,7 @@ class WaveNetEngine:
             if merged and overlap:
                 side.wait_stream(main)      # (gs[0], which the input conv's gradient reads, is complete on the main stream)
             with torch.cuda.stream(side):
-                if merged:
+                if merged and self._ic_job is None:      # (not already left by the first group's backward launch)
                     self._wgrad_input_conv_partials()
                 self._wgrad_layers_finish()
             self._wgrad_input_and_cond(input_conv=not merged)
@@ -819,6 +825,11 @@ class WaveNetEngine:
         flow = self.cfg.head_mode == "flow"
         R, ns = self.R, self.nslabs
         g_top = self.gs[l1] if (flow or l1 < self.L) else None
+        ic = None
+        if l0 == 0 and self.fuse_icg:      # the stack's first group: the input conv's weight-gradient partials ride along
+            ic = (self.audio, self.ic_ws, 1 if self.cfg.shift_input else 0)
+            sec = self.sections
+            self._ic_job = (self.ic_ws, ns, (self.Kw + 1) * R, 1, True, 1.0, self.grads.data_ptr() + 4 * sec["init_w"].offset, 0)
         with _Span(self, "group_bwd_wt"):
             K.residual_group_bwd_wt(g_top, self.gs[l0:l1], self.zs[l0:l1], None if flow else self.dcs[l0:l1],
                                     self.xTs[l0:l1], self.cTs[l0:l1],
@@ -826,7 +837,7 @@ class WaveNetEngine:
                                     [self.wptr(self.o_resT[l]) for l in range(l0, l1)], self.dil[l0:l1],
                                     self.pl_f[l0 * ns * 2 * R * R:], self.pl_r[l0 * ns * R * R:],
                                     self.pl_bf[l0 * ns * R:], self.pl_br[l0 * ns * R:], ns,
-                                    self.wt_seg_rows[self.groups.index((l0, l1))], self.Kw, write_all_g=bool(self.E))
+                                    self.wt_seg_rows[self.groups.index((l0, l1))], self.Kw, write_all_g=bool(self.E), ic=ic)
 
     def _group_bwd(self, l0: int, l1: int):
         flow = self.cfg.head_mode == "flow"

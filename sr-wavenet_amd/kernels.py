@@ -345,11 +345,13 @@ def residual_group_fwd_ic(audio: torch.Tensor, init_w: torch.Tensor, init_b: tor
 def residual_group_bwd_wt(g_top: Optional[torch.Tensor], g_out: torch.Tensor, z: torch.Tensor, dcs: Optional[torch.Tensor],
                           xT: torch.Tensor, cT: torch.Tensor, wconvT_ptrs, wresT_ptrs, dilations, part_f: torch.Tensor,
                           part_r: torch.Tensor, part_bf: torch.Tensor, part_br: torch.Tensor, nslabs: int, seg_rows: int,
-                          K: int = 2, write_all_g: bool = False):
+                          K: int = 2, write_all_g: bool = False, ic: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None):
     """Backward chain of a layer group + its layer weight-gradient partials in one launch (8 waves, output-split; the A
     operands are the forward kernel's weight-gradient tiles xT / cT [>=n, elems]).  g_out / z / dcs: [n,B,T,R] stacks;
     part_*: partial buffers starting at the group's first layer, [n][nslabs][2RR | RR | R | R]; part_f / part_r fp32, or in
-    the compute type bf16 -- the kernel then writes them as 16 x 16 blocks in lane order (reduce with layout BLK16)."""
+    the compute type bf16 -- the kernel then writes them as 16 x 16 blocks in lane order (reduce with layout BLK16).
+    ic = (audio [B,T] fp32, partials fp32 [nslabs * 3R], shift): the stack's first group also leaves the input conv's
+    kernel + bias gradient partials (one slab per workgroup, srwn_init_conv_wgrad's stage-1 layout)."""
     import ctypes as C
     n = len(dilations)
     _, B, T, R = z.shape
@@ -375,13 +377,17 @@ def residual_group_bwd_wt(g_top: Optional[torch.Tensor], g_out: torch.Tensor, z:
         _chk(t, name, torch.bfloat16 if (part16 and name in ("part_f", "part_r")) else torch.float32)
         if t.numel() < n * nslabs * per:
             raise ValueError("%s: %d elements, needs %d" % (name, t.numel(), n * nslabs * per))
+    if ic is not None and ic[1].numel() < nslabs * 3 * R:
+        raise ValueError("ic partials: %d floats, needs %d" % (ic[1].numel(), nslabs * 3 * R))
     pg = _opt(g_top, "g_top", z.dtype, (B, T, R))
     dl = (C.c_int32 * n)(*[int(d) for d in dilations])
     call("srwn_residual_group_bwd_wt", pg, g_out.data_ptr(), 1 if write_all_g else 0, z.data_ptr(),
          None if dcs is None else dcs.data_ptr(), B * T * R, xT.data_ptr(), cT.data_ptr(), int(xT.shape[1]),
          _ptr_array(wconvT_ptrs), _ptr_array(wresT_ptrs), dl, n, part_f.data_ptr(), part_r.data_ptr(),
-         part_bf.data_ptr(), part_br.data_ptr(), 1 if part16 else 0, int(nslabs), B, T, R, int(K), int(seg_rows), dt,
-         _stream())
+         part_bf.data_ptr(), part_br.data_ptr(), 1 if part16 else 0,
+         None if ic is None else _chk(ic[0], "audio", torch.float32, (B, T)),
+         None if ic is None else _chk(ic[1], "ic_partials", torch.float32), 0 if ic is None else int(ic[2]),
+         int(nslabs), B, T, R, int(K), int(seg_rows), dt, _stream())
 
 
 def residual_group_bwd(g_top: Optional[torch.Tensor], g_out: torch.Tensor, df_out: torch.Tensor, z: torch.Tensor,

@@ -449,6 +449,10 @@ def test_group_wt_bf16_partial_blocks_vs_fp32_partials(monkeypatch, dil, B, T, R
             e = _rel(b, a)
             worst = max(worst, e)
             assert e < PART16_TOL, (name, e)
+        elif name in ("init_w", "init_b") and fus.fuse_icg != ref.fuse_icg:
+            # (bf16 mode: the first group's backward launch forms the input conv's gradient itself only together with the
+            # bf16 partial blocks; with fp32 slabs srwn_init_conv_wgrad does -- the same products in another order)
+            assert _rel(b, a) < 2e-5, (name, _rel(b, a))
         else:
             assert torch.equal(a, b), name
     if os.environ.get("SRWN_PRINT_ERR"):
@@ -490,4 +494,13 @@ def test_input_conv_fused_into_the_first_group(monkeypatch, dt, dil, B, T, R, S,
     for l0, l1 in fus.groups:
         assert torch.equal(ref.xs[l1], fus.xs[l1])
     assert float(ref.loss.item()) == float(fus.loss.item())
-    assert torch.equal(ref.grads, fus.grads)
+    # ... and the first group's BACKWARD launch forms the input conv's kernel + bias gradient from its bottom gradient
+    # while it is on the chip (the audio as a high + a low bf16 part on the matrix pipe; per segment) instead of
+    # srwn_init_conv_wgrad's pass over gs[0] (FMAs; slabs of 256 rows): the same products in another order
+    assert fus.fuse_icg and not ref.fuse_icg
+    for name in fus.sections:
+        a, b = ref.view(name, ref.grads), fus.view(name, fus.grads)
+        if name in ("init_w", "init_b"):
+            assert bool(torch.isfinite(b).all()) and _rel(b, a) < 2e-5, (name, _rel(b, a))
+        else:
+            assert torch.equal(a, b), name
