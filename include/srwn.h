@@ -315,6 +315,8 @@ int srwn_reduce_partials(const float* partials, int32_t nslabs, int64_t n, int32
                                * are stored as 16 x 16 blocks in MFMA-accumulator lane order: block (rb, cb) at
                                * (rb*(blk_cols/16) + cb)*256 elements, lane l's four values -- rows 16 rb + 4 (l >> 4) + 0..3
                                * of column 16 cb + (l & 15) -- at + 4 l (srwn_residual_group_bwd_wt with part16) */
+#define SRWN_PARTIALS_SUM 2   /* fp32; ONE output: out[0] = scale * the sum of all nslabs*n values, in srwn_reduce_loss's
+                               * order and precision (the loss partials of a training step: bit-equal to that launch) */
 typedef struct SrwnReduceJob {
   const void* partials; int32_t nslabs; int64_t n; int32_t nbatch; int32_t partials_batched; float scale;
   float* out; int64_t out_batch_stride;

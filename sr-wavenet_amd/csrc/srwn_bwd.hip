@@ -696,6 +696,22 @@ __global__ __launch_bounds__(256) void reduce_partials_multi_kernel(RpMulti m) {
   const int l = (int)(b / job.blocks_x);
   const int nslabs = job.nslabs;
   const int64_t n = job.n;
+  if (job.wide == 4) {
+    // one output = the sum of ALL nslabs * n values (the loss partials of a training step), in srwn_reduce_loss's order
+    // and precision: 256 strided f64 sums, then a tree over them in LDS -- the same bits as that launch
+    __shared__ double red[256];
+    const int64_t total = (int64_t)nslabs * n;
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < total; i += 256) acc += (double)job.partials[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) job.out[0] = (float)(red[0] * (double)job.scale);
+    return;
+  }
   if (job.wide == 3) {
     // bf16 blocks in lane order: a thread takes two neighbouring lanes of one block (16 bytes per slab: four rows of two
     // columns), eight slabs in flight; every output is summed slab by slab in order, in f64, like the fp32 bodies
@@ -811,10 +827,13 @@ extern "C" int srwn_reduce_partials_multi(const SrwnReduceJob* jobs, int32_t njo
           (reinterpret_cast<uintptr_t>(q.partials) % 16) || (reinterpret_cast<uintptr_t>(q.out) % 8))
         return set_error(SRWN_E_SHAPE, "reduce_partials_multi: job %d: BLK16 layout needs n = rows*blk_cols in whole 16 x 16 blocks (n=%lld, blk_cols=%d)", k, (long long)q.n, q.blk_cols);
       j.wide = 3; j.blk_cols = q.blk_cols;
+    } else if (q.layout == SRWN_PARTIALS_SUM) {
+      if (q.nbatch != 1) return set_error(SRWN_E_SHAPE, "reduce_partials_multi: job %d: SUM layout has one output", k);
+      j.wide = 4;
     } else if (q.layout != SRWN_PARTIALS_F32) {
       return set_error(SRWN_E_UNSUPPORTED, "reduce_partials_multi: job %d: layout %d", k, q.layout);
     }
-    j.blocks_x = (unsigned)(j.wide == 3 ? (q.n / 8 + 255) / 256 : j.wide == 2 ? (q.n / 4 + 255) / 256 : j.wide ? (q.n + 15) / 16 : (q.n + 255) / 256);
+    j.blocks_x = (unsigned)(j.wide == 4 ? 1 : j.wide == 3 ? (q.n / 8 + 255) / 256 : j.wide == 2 ? (q.n / 4 + 255) / 256 : j.wide ? (q.n + 15) / 16 : (q.n + 255) / 256);
     j.block0 = (unsigned)blocks;
     blocks += (uint64_t)j.blocks_x * (uint64_t)q.nbatch;
     if (blocks > 0x7fffffffull) return set_error(SRWN_E_SHAPE, "reduce_partials_multi: grid too large");

@@ -138,6 +138,8 @@ class WaveNetEngine:
                            and cfg.dtype == torch.bfloat16 and cfg.skip_channels == 256)
         self._head_bwd_done = False
         self._ic_job = None
+        self._loss_job = None
+        self.defer_loss = _os.environ.get("SRWN_DEFER_LOSS", "1") != "0"      # (0: the loss sum keeps a launch of its own)
         self.side = None
         if torch.cuda.is_available() and self.overlap:
             # weight-gradient passes are throughput work: lowest priority, so the latency-critical dgrad
@@ -549,10 +551,12 @@ class WaveNetEngine:
             self.cond_in.zero_()
             self.cond_in[:, :self.E].copy_(cond.reshape(self.B * self.frames, self.E))
 
-    def forward(self, want_logits: bool = False, with_loss: bool = True, train: bool = True) -> Optional[torch.Tensor]:
+    def forward(self, want_logits: bool = False, with_loss: bool = True, train: bool = True,
+                defer_loss: bool = False) -> Optional[torch.Tensor]:
         """Runs the stack on the staged inputs; leaves loss in self.loss and dlogits for backward.
         Returns fp32 per-time-step logits [B,T,C] when want_logits.  train=False: forward only (no weight-gradient tiles
-        are written; backward() refuses to follow such a pass)."""
+        are written; backward() refuses to follow such a pass).  defer_loss (the training step): the final sum of the loss
+        partials is left to the backward pass, where it is one more job of the skip / head reduction launch."""
         B, T, N, L, R, S = self.B, self.T, self.N, self.L, self.R, self.S
         es = self.packed.element_size()
         v = self.view
@@ -580,7 +584,10 @@ class WaveNetEngine:
                              self.wptr(self.o_w1Tp), v("head_b1"), v("head_b2"), self.targets, self.loss_parts,
                              self.r1, self.dlogits, self.da1, self.dtotal, self.C, 1.0 / N)
             self._head_bwd_done = True
-            K.reduce_loss(self.loss_parts, self.loss_parts.numel(), 1.0 / N, self.loss)
+            if defer_loss and train and self.batch_reduce and not self.frozen and self.defer_loss:
+                self._loss_job = (self.loss_parts, self.loss_parts.numel(), 1, 1, True, 1.0 / N, self.loss.data_ptr(), 0, "sum")
+            else:
+                K.reduce_loss(self.loss_parts, self.loss_parts.numel(), 1.0 / N, self.loss)
             return None
         with _Span(self, "head_1x1"):
             K.pw_linear(self.r0.data_ptr(), S, 0, S, S, self.wptr(self.o_w1), v("head_b1"), self.r1, S, S, N,
@@ -964,14 +971,18 @@ class WaveNetEngine:
                 K.wgrad256(self.r1.data_ptr(), 64, S, S // 64, self.dlogits, self.hd_parts[1], self.hd_bparts[1], N,
                            self.ns_head)
             skip16 = self.skip_wt and self.fused_wt and self.skip_parts16 is not None
-            K.reduce_partials_multi([
+            jobs = [
                 (self.skip_parts16, ns_skip, L * R * S, 1, True, 1.0, gp + 4 * sec["WS"].offset, 0, S) if skip16 else
                 (self.wg_parts, ns_skip, L * R * S, 1, True, 1.0, gp + 4 * sec["WS"].offset, 0),
                 (self.wg_bparts, ns_skip, S, L, False, 1.0, gp + 4 * sec["BS"].offset, S),
                 (self.hd_parts[0], self.ns_head, S * S, 1, True, 1.0, gp + 4 * sec["head_w1"].offset, 0),
                 (self.hd_bparts[0], self.ns_head, S, 1, True, 1.0, gp + 4 * sec["head_b1"].offset, 0),
                 (self.hd_parts[1], self.ns_head, S * Cp, 1, True, 1.0, gp + 4 * sec["head_w2"].offset, 0),
-                (self.hd_bparts[1], self.ns_head, Cp, 1, True, 1.0, gp + 4 * sec["head_b2"].offset, 0)])
+                (self.hd_bparts[1], self.ns_head, Cp, 1, True, 1.0, gp + 4 * sec["head_b2"].offset, 0)]
+            if self._loss_job is not None:      # the loss the forward pass deferred: one more (one-output) reduction
+                jobs.append(self._loss_job)
+                self._loss_job = None
+            K.reduce_partials_multi(jobs)
             return
         if self.use_w256:
             # every skip 1x1 at once: out[L*R, S] = c_all^T . dtotal (dtotal re-read once per 4 layers)
@@ -1073,7 +1084,7 @@ class WaveNetEngine:
         """fwd + bwd + (all-reduce) + Adam on the staged inputs; returns the device loss scalar.
         With several ranks the gradient all-reduce runs in two buckets, the first (skip + head kernels, 65 % of the
         bytes) overlapped with the lower part of the backward pass."""
-        self.forward()
+        self.forward(defer_loss=True)
         if self.bucketed and not self.timing:
             self.backward(part=1)
             h = self._allreduce_bucket_a()
@@ -1165,14 +1176,14 @@ class WaveNetEngine:
         if self.world == 1 and _os.environ.get("SRWN_FORCE_DIST") != "1":
             # no collective to leave between the graphs: the whole step is one replay
             with torch.cuda.graph(self._g_fb):
-                self.forward()
+                self.forward(defer_loss=True)
                 self.backward()
                 self.optimizer_step()
             self._g_opt = None
             torch.cuda.synchronize()
             return
         with torch.cuda.graph(self._g_fb):
-            self.forward()
+            self.forward(defer_loss=True)
             self.backward(part=1 if self.bucketed else 0)
         if self.bucketed:   # {forward, upper backward} | bucket A in flight | {lower backward} | bucket B | {Adam}
             self._g_b2 = torch.cuda.CUDAGraph()

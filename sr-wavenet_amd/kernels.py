@@ -674,13 +674,14 @@ class _ReduceJob(_ct.Structure):
 
 def reduce_partials_multi(jobs):
     """jobs: the argument tuples of `reduce_partials`, finished by one launch (at most 16).  A ninth entry `blk_cols`
-    marks a bf16 partial buffer in 16 x 16-block lane order (SRWN_PARTIALS_BLK16; n = rows * blk_cols)."""
+    marks a bf16 partial buffer in 16 x 16-block lane order (SRWN_PARTIALS_BLK16; n = rows * blk_cols); the string "sum"
+    there: one output, the sum of all nslabs * n values in reduce_loss's order (SRWN_PARTIALS_SUM)."""
     arr = (_ReduceJob * len(jobs))()
     for j, job in zip(arr, jobs):
         partials, nslabs, n, nbatch, batched, scale, out_ptr, out_stride = job[:8]
-        blk_cols = int(job[8]) if len(job) > 8 else 0
+        blk_cols = int(job[8]) if len(job) > 8 and job[8] != "sum" else 0
         j.partials = _chk(partials, "partials", torch.bfloat16 if blk_cols else torch.float32)
-        j.layout, j.blk_cols = (1, blk_cols) if blk_cols else (0, 0)
+        j.layout, j.blk_cols = (1, blk_cols) if blk_cols else ((2, 0) if (len(job) > 8 and job[8] == "sum") else (0, 0))
         j.nslabs, j.n, j.nbatch, j.partials_batched = int(nslabs), int(n), int(nbatch), int(bool(batched))
         j.scale, j.out, j.out_batch_stride = float(scale), int(out_ptr), int(out_stride)
     call("srwn_reduce_partials_multi", _ct.addressof(arr), len(jobs), _stream())

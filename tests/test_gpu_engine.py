@@ -378,3 +378,29 @@ def test_ctypes_binding_runs_the_same_smoke_step():
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "smoke ok" in r.stdout and "binding ctypes" in r.stdout
+
+
+def test_training_step_loss_equals_forward_loss():
+    """The training step leaves the final sum of its loss partials to the skip / head reduction launch of the backward pass
+    (one more job there instead of a launch of its own); the value must be the one forward() alone reports, to the bit."""
+    EG = sub("engine")
+    dil = [1, 2, 4, 8, 16, 32] * 2
+    B, T, R, S, C = 2, 700, 64, 256, 256
+    cfg = EG.StackConfig(dilations=dil, dilation_channels=R, skip_channels=S, output_channels=C, shift_input=True,
+                         dtype=torch.bfloat16, learning_rate=1e-3)
+    eng = EG.WaveNetEngine(cfg, B, T, DEV, seed=5)
+    audio = O.synthetic_audio(B, T, seed=3)
+    eng.set_inputs(dev(audio), dev(O.mu_law_encode(audio, C), torch.int32))
+    assert eng.head_chain and eng.batch_reduce
+    eng.forward()
+    l_fwd = float(eng.loss.item())
+    eng.loss.fill_(-1.0)
+    eng.train_step()                       # (the loss is of the parameters BEFORE the update)
+    assert float(eng.loss.item()) == l_fwd
+    eng.forward()
+    l2 = float(eng.loss.item())
+    eng.capture_graphs()
+    eng.loss.fill_(-1.0)
+    eng.train_step_graphed()
+    torch.cuda.synchronize()
+    assert float(eng.loss.item()) == l2 and l2 != l_fwd

@@ -4,6 +4,7 @@ config-2 training step replayed as a hipGraph (ms/step, best and median of `--ro
 per-kernel spans of a few eager steps.  Each measurement is a fresh child process (SRWN_LIB_PATH is read at import).
 
   python tools/ab_step.py base=sr-wavenet_amd/libsrwn.so prio=ab/libsrwn_prio.so [--rounds 3] [--steps 200]
+  a variant may carry environment settings: nodefer=sr-wavenet_amd/libsrwn.so,SRWN_DEFER_LOSS=0
 """
 import json
 import os
@@ -48,8 +49,12 @@ def main():
     libs = [a.split("=", 1) for a in args]
     out = {n: {"ms": [], "spans": []} for n, _ in libs}
     for r in range(rounds):
-        for name, path in libs:
+        for name, spec in libs:
             env = dict(os.environ)
+            path, *sets = spec.split(",")
+            for kv in sets:
+                k, v = kv.split("=", 1)
+                env[k] = v
             p = os.path.join(ROOT, path)
             if os.path.abspath(p) != os.path.join(ROOT, "sr-wavenet_amd", "libsrwn.so"):
                 env["SRWN_LIB_PATH"] = p
