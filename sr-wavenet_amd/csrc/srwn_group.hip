@@ -273,6 +273,9 @@ __global__ __launch_bounds__(64 * NWV) void group_fwd_kernel(GroupFwdArgs a) {
       for (int m = 0; m < MAXT; ++m) {
         const int q = wave + NWV * m;
         if (q >= a.NT) continue;
+        // (WT: the halo is whole tiles, and the group's TOP layer feeds no tap inside the launch: its halo tiles would be
+        // computed for nobody -- for 500 + 32 rows that is the 17th tile, a third round of eight waves for one of them)
+        if (WT && !more && q < a.H / 32) continue;
         T* trow = img + (size_t)(32 * q) * LS;           // the tile's own rows
         const int j = jbase + 32 * q + col;              // this lane's position
         const bool ok0 = (j - d) >= 0;                   // causal zero padding of the delayed tap (ops.py:9)
