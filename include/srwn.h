@@ -205,6 +205,17 @@ int srwn_probs_logistic(const float* scale, const float* mu, const float* y, flo
  * channel counts; ops.py:232-236 builds an 8-channel layer on a 1-channel input): z = tanh(f), c = z*sigmoid(z)
  * (ops.py:28,33,36); dense = (inputs + residual)*sqrt(.5) with a 1-channel input broadcast (ops.py:40); relu (ops.py:49,52) */
 int srwn_tanh_gate(const float* f, float* z, float* c, int64_t n, void* stream);
+/* the gated activation unit with SURVEY 8(b)'s gate_mode: z = tanh(f) and
+ *   SRWN_GATE_REFERENCE: c = z * sigmoid(z)   -- the graph the reference RUNS (ops.py:33 overwrites the gate conv's result
+ *                                                with sigmoid(filter_conv); g is not read and may be NULL) = srwn_tanh_gate
+ *   SRWN_GATE_WAVENET:   c = z * sigmoid(g)   -- the canonical WaveNet unit ops.py:31-32 builds and then discards; g = the
+ *                                                gate conv's output (srwn_causal_conv1d_fwd with the `_gate` kernel)
+ * Forward, fp32, any shape: the ops-level ResidualDilationLayer(gate_mode="wavenet") of sr-wavenet_amd/ops.py runs on it.
+ * The fused training kernels (srwn_residual_layer_* / srwn_residual_group_*) implement SRWN_GATE_REFERENCE only: parity is
+ * judged on the graph the reference executes, and its `_gate` variables receive no gradient there. */
+#define SRWN_GATE_REFERENCE 0
+#define SRWN_GATE_WAVENET 1
+int srwn_gated_activation(const float* f, const float* g, float* z, float* c, int64_t n, int32_t gate_mode, void* stream);
 int srwn_residual_combine(const float* x, int32_t cin, const float* res, int32_t R, float* out, int64_t rows,
                           void* stream);
 int srwn_relu(const float* x, float* y, int64_t n, void* stream);

@@ -57,6 +57,7 @@ SIGNATURES = {
     "srwn_categorical_sample": (C.c_int, [_p, _p, _i64, _i32, C.c_uint64, _p]),
     "srwn_probs_logistic": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _f32, _p]),
     "srwn_tanh_gate": (C.c_int, [_p, _p, _p, _i64, _p]),
+    "srwn_gated_activation": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p]),
     "srwn_residual_combine": (C.c_int, [_p, _i32, _p, _i32, _p, _i64, _p]),
     "srwn_relu": (C.c_int, [_p, _p, _i64, _p]),
     "srwn_mol_nll_rows": (C.c_int, [_p, _i64, _p, _i32, _p, _i64, _p]),

@@ -89,6 +89,18 @@ __global__ void tanh_gate_kernel(const float* __restrict__ f, float* __restrict_
   c[i] = zz * sigmoidf_(zz);
 }
 
+// gate_mode of SURVEY 8(b): SRWN_GATE_REFERENCE = the graph the reference RUNS (ops.py:33 overwrites the gate conv's
+// result: c = z * sigmoid(z), z = tanh(f); g is not read) / SRWN_GATE_WAVENET = the canonical unit ops.py:31-32 builds and
+// discards: c = tanh(f) * sigmoid(g), g = the gate conv's output
+__global__ void gated_activation_kernel(const float* __restrict__ f, const float* __restrict__ g, float* __restrict__ z,
+                                        float* __restrict__ c, int64_t n, int wavenet) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float zz = tanhf(f[i]);
+  z[i] = zz;
+  c[i] = zz * sigmoidf_(wavenet ? g[i] : zz);
+}
+
 // dense = (inputs + residual) * sqrt(.5) (ops.py:40); inputs [rows, cin] broadcasts over channels when cin == 1
 __global__ void residual_combine_kernel(const float* __restrict__ x, int cin, const float* __restrict__ res, int R,
                                         float* __restrict__ out, int64_t n) {
@@ -168,6 +180,18 @@ extern "C" int srwn_probs_logistic(const float* scale, const float* mu, const fl
   hipLaunchKernelGGL(probs_logistic_kernel, grid1(n), dim3(256), 0, (hipStream_t)stream, scale, mu, y, out, n,
                      1.0f / (float)(num_classes - 1), expf(log_scale_min));
   return check_launch("probs_logistic");
+}
+
+extern "C" int srwn_gated_activation(const float* f, const float* g, float* z, float* c, int64_t n, int32_t gate_mode,
+                                     void* stream) {
+  if (n == 0) return 0;
+  if (gate_mode != SRWN_GATE_REFERENCE && gate_mode != SRWN_GATE_WAVENET)
+    return set_error(SRWN_E_UNSUPPORTED, "gated_activation: gate_mode %d", gate_mode);
+  if (!f || !z || !c || (gate_mode == SRWN_GATE_WAVENET && !g)) return set_error(SRWN_E_NULL, "gated_activation: null pointer");
+  if (n < 0) return set_error(SRWN_E_SHAPE, "gated_activation: n=%lld", (long long)n);
+  hipLaunchKernelGGL(gated_activation_kernel, grid1(n), dim3(256), 0, (hipStream_t)stream, f, g, z, c, n,
+                     gate_mode == SRWN_GATE_WAVENET ? 1 : 0);
+  return check_launch("gated_activation");
 }
 
 extern "C" int srwn_tanh_gate(const float* f, float* z, float* c, int64_t n, void* stream) {

@@ -54,20 +54,30 @@ def DilatedCausalConv1d(inputs, kernel_size, channels, dilation_rate=1, name="",
     return K.causal_conv1d_fwd(x, filters, bias, dilation_rate)
 
 
-def _layer_variables(name, kernel_size, cin, R, skip_channels):
+def _layer_variables(name, kernel_size, cin, R, skip_channels, with_gate=False):
     wf = get_variable(name + "_filter/" + name + "_Kernel", (kernel_size, cin, R))
     bf = get_variable(name + "_filter/" + name + "_Bias", (1, 1, R), init="zeros").reshape(-1)
-    get_variable(name + "_gate/" + name + "_Kernel", (kernel_size, cin, R))       # dead (ops.py:32-33)
-    get_variable(name + "_gate/" + name + "_Bias", (1, 1, R), init="zeros")
+    wg = get_variable(name + "_gate/" + name + "_Kernel", (kernel_size, cin, R))       # dead in the reference's graph (ops.py:32-33)
+    bg = get_variable(name + "_gate/" + name + "_Bias", (1, 1, R), init="zeros").reshape(-1)
     wr = get_variable(name + "/residual/kernel", (1, R, R)); br = get_variable(name + "/residual/bias", (R,), "zeros")
     ws = get_variable(name + "/skip/kernel", (1, R, skip_channels))
     bs = get_variable(name + "/skip/bias", (skip_channels,), "zeros")
+    if with_gate:
+        return wf, bf, wr, br, ws, bs, wg, bg
     return wf, bf, wr, br, ws, bs
 
 
+GATE_MODES = {"reference": 0, "wavenet": 1}      # include/srwn.h: SRWN_GATE_REFERENCE / SRWN_GATE_WAVENET
+
+
 def ResidualDilationLayer(inputs, kernel_size, dilation_channels, skip_channels, dilation_rate=1, name="",
-                          dtype=None, use_bias=True):
+                          dtype=None, use_bias=True, gate_mode="reference"):
     """ops.py:23-46 -> (dense, skip).
+
+    gate_mode (no reference counterpart): "reference" (default) is the graph the reference RUNS -- ops.py:33
+    overwrites the gate conv's result, so combined = z * sigmoid(z) with z = tanh(filter conv); "wavenet" is the canonical
+    unit ops.py:31-32 builds and discards, tanh(filter conv) * sigmoid(gate conv) with the `_gate` variables (forward,
+    fp32, on the generic kernels; the fused training kernels implement "reference" only).
 
     Like ops.py:33 the gate conv is created but its result is discarded (kept for checkpoint parity).
     The stack's shape (input channels == dilation_channels in {32, 64}, kernel_size 2, skip_channels a multiple of 32)
@@ -78,10 +88,12 @@ def ResidualDilationLayer(inputs, kernel_size, dilation_channels, skip_channels,
     x = _dev(inputs)
     B, T, cin = x.shape
     R = dilation_channels
-    wf, bf, wr, br, ws, bs = _layer_variables(name, kernel_size, cin, R, skip_channels)
+    if gate_mode not in GATE_MODES:
+        raise ValueError("gate_mode %r: 'reference' or 'wavenet'" % (gate_mode,))
+    wf, bf, wr, br, ws, bs, wg, bg = _layer_variables(name, kernel_size, cin, R, skip_channels, with_gate=True)
     if not use_bias:
-        bf = torch.zeros_like(bf)
-    if cin != R or R not in (32, 64) or kernel_size != 2 or skip_channels % 32:
+        bf = torch.zeros_like(bf); bg = torch.zeros_like(bg)
+    if gate_mode == "wavenet" or cin != R or R not in (32, 64) or kernel_size != 2 or skip_channels % 32:
         if cin not in (1, R):
             raise ValueError("ResidualDilationLayer: inputs with %d channels cannot be added to a %d-channel residual "
                              "(ops.py:40)" % (cin, R))
@@ -89,7 +101,9 @@ def ResidualDilationLayer(inputs, kernel_size, dilation_channels, skip_channels,
         st = K._stream()
         f = K.causal_conv1d_fwd(x, wf, bf, dilation_rate)                                   # ops.py:27
         z = torch.empty_like(f); c = torch.empty_like(f)
-        call("srwn_tanh_gate", f.data_ptr(), z.data_ptr(), c.data_ptr(), f.numel(), st)     # ops.py:28,33,36
+        g = K.causal_conv1d_fwd(x, wg, bg, dilation_rate) if gate_mode == "wavenet" else None   # ops.py:32
+        call("srwn_gated_activation", f.data_ptr(), None if g is None else g.data_ptr(), z.data_ptr(), c.data_ptr(),
+             f.numel(), GATE_MODES[gate_mode], st)                                          # ops.py:28,33,36
         res = K.causal_conv1d_fwd(c, wr, br.reshape(-1), 1)                                 # ops.py:39
         dense = torch.empty_like(res)
         call("srwn_residual_combine", x.data_ptr(), cin, res.data_ptr(), R, dense.data_ptr(), B * T, st)   # ops.py:40

@@ -169,3 +169,34 @@ def test_probs_logistic():
         ref = O.probs_logistic(scale, mu, y, nc, lsm)
         assert np.abs(got - ref).max() < 2e-6
     assert tuple(ops.probs_logistic(scale[:1], mu, y[:, :1]).shape) == (4, 100)     # broadcasting like the TF ops
+
+
+@pytest.mark.parametrize("K,cin,R,S,d,T", [(2, 64, 64, 256, 4, 90), (3, 32, 32, 40, 2, 50), (2, 1, 8, 4, 4, 16)])
+def test_residual_dilation_layer_gate_modes(K, cin, R, S, d, T):
+    """gate_mode: "reference" = the graph the reference runs (ops.py:33: the gate conv's result is overwritten,
+    c = z sigmoid(z)); "wavenet" = the canonical unit ops.py:31-32 builds and discards, tanh(filter conv) * sigmoid(gate
+    conv) with the `_gate` variables -- both against the oracle's restatement of the same two graphs (fp32, 1e-3).  On the
+    stack's own shape the "reference" mode runs the fused MFMA kernel, "wavenet" the generic ones."""
+    ops = sub("ops")
+    rng = np.random.default_rng(K + R + d)
+    x = rng.standard_normal((2, T, cin)).astype(np.float32)
+    name = "gm_%d_%d_%d_%d" % (K, cin, R, S)
+    ops.ResidualDilationLayer(x, K, R, S, dilation_rate=d, name=name)
+    V = ops.VARIABLES
+    for k in (name + "_filter/" + name + "_Bias", name + "_gate/" + name + "_Bias", name + "/residual/bias", name + "/skip/bias"):
+        V[k].copy_(torch.tensor(0.2 * rng.standard_normal(tuple(V[k].shape)), dtype=torch.float32))
+    f = lambda k: V[k].cpu().numpy().astype(np.float64)
+    lp = _lp(V, name, K)
+    lp.wg, lp.bg = f(name + "_gate/" + name + "_Kernel"), f(name + "_gate/" + name + "_Bias").reshape(-1)
+    out = {}
+    for mode in ("reference", "wavenet"):
+        dense, skip = ops.ResidualDilationLayer(x, K, R, S, dilation_rate=d, name=name, gate_mode=mode)
+        d_ref, s_ref, _ = O.residual_dilation_layer(x.astype(np.float64), lp, d, gate_mode=mode)
+        assert rel_err(dense.cpu().numpy(), d_ref) < 1e-3 and rel_err(skip.cpu().numpy().reshape(s_ref.shape), s_ref) < 1e-3, mode
+        out[mode] = dense.cpu().numpy()
+    assert rel_err(out["wavenet"], out["reference"]) > 1e-2          # two different graphs
+    with pytest.raises(ValueError):
+        ops.ResidualDilationLayer(x, K, R, S, dilation_rate=d, name=name, gate_mode="glu")
+    L = sub("_lib")
+    assert L.load().srwn_gated_activation(1, None, 1, 1, 8, 1, None) == -3        # wavenet mode needs g
+    assert L.load().srwn_gated_activation(1, 1, 1, 1, 8, 2, None) == -4           # unknown mode
