@@ -811,7 +811,8 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) acc[bb][rr] += (float)o[rr];
               }
-              if (!(WT_DBG(a) & 16)) *reinterpret_cast<p4*>(pl + bb * 256) = Raw4g<bf16_t>::pack(acc[bb][0], acc[bb][1], acc[bb][2], acc[bb][3]);
+              // (non-temporal: nobody reads a partial before the reduction launch; A/B -3..-6 us per step, inside the noise)
+              if (!(WT_DBG(a) & 16)) __builtin_nontemporal_store(Raw4g<bf16_t>::pack(acc[bb][0], acc[bb][1], acc[bb][2], acc[bb][3]), reinterpret_cast<p4*>(pl + bb * 256));
             }
           } else {
           float* pl = reinterpret_cast<float*>(a.part_r) + pslab * (R * R) + (size_t)(16 * ib + 4 * (lw >> 4)) * R + 16 * ob0 + (lw & 15);
@@ -1006,7 +1007,8 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) acc[bb][rr] += (float)o[rr];
               }
-              if (!(WT_DBG(a) & 16)) *reinterpret_cast<p4*>(pl + bb * 256) = Raw4g<bf16_t>::pack(acc[bb][0], acc[bb][1], acc[bb][2], acc[bb][3]);
+              // (non-temporal: nobody reads a partial before the reduction launch; A/B -3..-6 us per step, inside the noise)
+              if (!(WT_DBG(a) & 16)) __builtin_nontemporal_store(Raw4g<bf16_t>::pack(acc[bb][0], acc[bb][1], acc[bb][2], acc[bb][3]), reinterpret_cast<p4*>(pl + bb * 256));
             }
           } else {
           float* pl = reinterpret_cast<float*>(a.part_f) + pslab * (2 * R * R) + (size_t)tap * R * R + (size_t)(16 * ib + 4 * (lw >> 4)) * R + 16 * ob0 + (lw & 15);
