@@ -679,6 +679,8 @@ __global__ __launch_bounds__(256) void reduce_partials_wide_kernel(const float* 
 // Several reductions in one launch (a training step finishes eleven partial buffers; launched one by one they cost
 // ~6 us each plus a dependent-launch boundary).  A block finds its job by its index and does exactly what the
 // single-job kernels do: the same slab order, the same bits.
+// (the partial slabs are read exactly once: non-temporal loads)
+#define SRWN_NT_LOAD(p) __builtin_nontemporal_load(p)
 constexpr int kRpMaxJobs = 16;
 struct RpJob {
   const float* partials; float* out; int64_t n; int64_t out_batch_stride;
@@ -727,7 +729,7 @@ __global__ __launch_bounds__(256) void reduce_partials_multi_kernel(RpMulti m) {
     for (; k + 8 <= nslabs; k += 8) {
       srwn::bf16x8 v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const srwn::bf16x8*>(p + (int64_t)(k + j) * n);
+      for (int j = 0; j < 8; ++j) v[j] = SRWN_NT_LOAD(reinterpret_cast<const srwn::bf16x8*>(p + (int64_t)(k + j) * n));
 #pragma unroll
       for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -771,7 +773,7 @@ __global__ __launch_bounds__(256) void reduce_partials_multi_kernel(RpMulti m) {
     for (; q + 8 <= nslabs; q += 8) {
       srwn::f32x4 v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const srwn::f32x4*>(p + (int64_t)(q + j) * n);
+      for (int j = 0; j < 8; ++j) v[j] = SRWN_NT_LOAD(reinterpret_cast<const srwn::f32x4*>(p + (int64_t)(q + j) * n));
 #pragma unroll
       for (int j = 0; j < 8; ++j) { s0 += (double)v[j][0]; s1 += (double)v[j][1]; s2 += (double)v[j][2]; s3 += (double)v[j][3]; }
     }

@@ -171,7 +171,10 @@ __device__ __forceinline__ void store_rows_via_lds(T* stage, T* gtile, int64_t g
     int r = i * RPI + rsub;
     if (DUP) r = r < rows_valid ? r : rows_valid - 1;
     const f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * LS + piece * VEC);
-    if (DUP || r < rows_valid) *reinterpret_cast<f32x4*>(gtile + (int64_t)r * grow_stride + piece * VEC) = v;
+    // (non-temporal: every caller streams rows that a LATER launch reads -- the skip sum's r0, the skip data gradient's
+    // dcs ...; round 4 A/B with the reduction's non-temporal loads: -22 us per step, most of it in the kernels that read
+    // those rows next)
+    if (DUP || r < rows_valid) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(gtile + (int64_t)r * grow_stride + piece * VEC));
   }
 }
 

@@ -148,8 +148,11 @@ __device__ __forceinline__ float frag_dot(float acc, const Frag<float>& f, const
 template <typename T> __device__ __forceinline__ Frag<T> wt_load(const T* tile, int c0, int lane) {
   return load_nat(tile + (size_t)(c0 >> 4) * 512 + lane * 8);
 }
+// (non-temporal, like the z rows and the head's outputs: round 4 A/B on one box, -52 us per step for the three together --
+// tiles -16, head outputs -12, z rows -5 alone -- the write-allocated lines of streams nobody reads for a long while had been
+// pushing the operands of the kernels that DO run next out of the L2 / Infinity Cache: the skip sum alone -17 us)
 __device__ __forceinline__ void wt_store(bf16_t* tile, int c0, int lane, const Frag<bf16_t>& f) {
-  *reinterpret_cast<bf16x8*>(tile + (size_t)(c0 >> 4) * 512 + lane * 8) = f.v;
+  __builtin_nontemporal_store(f.v, reinterpret_cast<bf16x8*>(tile + (size_t)(c0 >> 4) * 512 + lane * 8));
 }
 __device__ __forceinline__ void wt_store(float* tile, int c0, int lane, const Frag<float>& f) {
   float* p = tile + (size_t)(c0 >> 4) * 512 + lane * 8;

@@ -344,7 +344,7 @@ __global__ __launch_bounds__(64 * NWV) void group_fwd_kernel(GroupFwdArgs a) {
               int rr = i * RPI + rsub;
               rr = rr < lo ? lo : (rr < hi ? rr : hi - 1);
               const f32x4 v = *reinterpret_cast<const f32x4*>(trow + (size_t)rr * LS + piece * VEC);
-              *reinterpret_cast<f32x4*>(zg + grow(jbase + 32 * q + rr) * R + piece * VEC) = v;
+              __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(zg + grow(jbase + 32 * q + rr) * R + piece * VEC));
             }
           }
         }

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(64 * kHcWaves) void headchain_kernel(HcArgs a) {
           for (int e = 0; e < 4; ++e)
             v[e] &= __builtin_amdgcn_perm((unsigned)__builtin_amdgcn_sbfe(b, 2 * e + 1, 1), (unsigned)__builtin_amdgcn_sbfe(b, 2 * e, 1), 0x05040100u);
         }
-        if (rv > 0) *reinterpret_cast<u32x4*>(ytile + r * C + 64 * j + piece * 8) = v;
+        if (rv > 0) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(ytile + r * C + 64 * j + piece * 8));
       }
       if (frags) {
 #pragma unroll

@@ -50,7 +50,9 @@ typedef bf16_t T;
 
 __device__ __forceinline__ f32x4 gload16_untracked(const void* p) {
   f32x4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  // (nt: the c tiles are read once here; round 4 A/B -7 us.  The same hint on the backward group kernel's and the skip
+  // sum's streams cost +44 and +20 us: their neighbouring workgroups re-read halo rows / rows of the same lines)
+  asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
   return v;
 }
 
@@ -225,8 +227,8 @@ __global__ __launch_bounds__(512) void wgrad_skip_wt_kernel(WtSkipArgs a) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const size_t blk = (size_t)(layer * 4 + mb) * 16 + 8 * nh + i;
-        *reinterpret_cast<bf16x4*>(pb + (blk * 64 + lane) * 4) =
-            bf16x4{(bf16_t)acc[mb][i][0], (bf16_t)acc[mb][i][1], (bf16_t)acc[mb][i][2], (bf16_t)acc[mb][i][3]};
+        __builtin_nontemporal_store(bf16x4{(bf16_t)acc[mb][i][0], (bf16_t)acc[mb][i][1], (bf16_t)acc[mb][i][2], (bf16_t)acc[mb][i][3]},
+                                    reinterpret_cast<bf16x4*>(pb + (blk * 64 + lane) * 4));
       }
   } else if (live) {
     float* pb = reinterpret_cast<float*>(a.partials) + ((size_t)slab * a.mtotal + (size_t)layer * 64) * 256 + 128 * nh + (lane & 15);
