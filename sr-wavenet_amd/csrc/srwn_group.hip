@@ -64,6 +64,14 @@ template <bool STAMP> struct Stamper {
   unsigned long long* p; int n;
   __device__ __forceinline__ void operator()(int) {}
 };
+
+// Which segment a workgroup takes.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one, and its
+// L2), neighbouring segments of a clip share their halo rows: with the identity map a halo row is fetched into two L2s.
+// XCD k takes a contiguous run of segments (speed only -- any bijection is correct; round 4 A/B: -3..-5 us per step).
+__device__ __forceinline__ int xcd_segment(int blk, int nseg) {
+  if ((nseg & 7) == 0) return (blk & 7) * (nseg >> 3) + (blk >> 3);
+  return blk;
+}
 template <> struct Stamper<true> {
   unsigned long long* p; int n;
   __device__ __forceinline__ void operator()(int tag) {
@@ -145,7 +153,8 @@ __global__ __launch_bounds__(64 * NWV) void group_fwd_kernel(GroupFwdArgs a) {
     if (tid < 2 * R / 4) *reinterpret_cast<f32x4*>(bbuf + buf * 2 * R + 4 * tid) = breg;
   };
 
-  for (int seg = blockIdx.x; seg < a.nseg; seg += gridDim.x) {
+  for (int sblk = blockIdx.x; sblk < a.nseg; sblk += gridDim.x) {
+    const int seg = xcd_segment(sblk, a.nseg);
     // segment -> (clip b, residue r, first position j0); consecutive ids = neighbouring memory
     const int per_clip = a.st * a.nsub;
     const int b = seg / per_clip;
@@ -518,7 +527,8 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
   const int ntw = (a.NT - wave + NWV - 1) / NWV;  // tiles this wave owns: q = wave + NWV*m, m < ntw
 
   int sit = -1;                                   // segments this workgroup has finished (WT: later ones add to its partial slab)
-  for (int seg = blockIdx.x; seg < a.nseg; seg += gridDim.x) {
+  for (int sblk = blockIdx.x; sblk < a.nseg; sblk += gridDim.x) {
+    const int seg = xcd_segment(sblk, a.nseg);
     ++sit;
     const int per_clip = a.st * a.nsub;
     const int b = seg / per_clip;
