@@ -156,8 +156,9 @@ int srwn_residual_group_bwd(const void* g_top, void* g_out, void* df_out, const 
  * ic_audio != NULL (the stack's FIRST group, dcs given; bf16 mode: with part16): the launch also leaves the partial sums
  * of the input conv's kernel and bias gradient (model.py:40; what srwn_init_conv_wgrad's first stage forms from g_out in a
  * launch of its own) -- ic_partials[slab][3 R] = [sum_t audio[t-1-ic_shift] G_0[t,:] | sum_t audio[t-ic_shift] G_0[t,:] |
- * sum_t G_0[t,:]] over the rows the workgroup's segments own, fp32, one slab per workgroup (`nslabs`); the audio enters
- * the bf16 MFMA as a high and a low bf16 part (exact to 2^-17).  audio [B,T] fp32. */
+ * sum_t G_0[t,:]] over rows the workgroup's segments own, fp32, 8 / (R/16) slabs per workgroup (the launch's waves split
+ * the tiles between them): ic_partials holds nslabs * 8 / (R/16) slabs of 3 R floats, to be summed; the audio enters the
+ * bf16 MFMA as a high and a low bf16 part (exact to 2^-17).  audio [B,T] fp32. */
 int srwn_group_wt_geometry(const int32_t* dilations, int32_t nlayers, int32_t B, int32_t T, int32_t R, int32_t dtype,
                            int32_t seg_rows_in, int32_t* seg_rows, int32_t* tiles_per_seg, int64_t* elems_per_layer,
                            int32_t* nslabs);

@@ -186,17 +186,31 @@ __global__ __launch_bounds__(64 * NWV) void group_fwd_kernel(GroupFwdArgs a) {
 #pragma unroll
       for (int e = 0; e < VEC; ++e) { w0[e] = a.ic_w[c0 + e]; w1[e] = a.ic_w[R + c0 + e]; bb[e] = a.ic_b[c0 + e]; }
       const float* au = a.ic_audio + clip;
-      for (int i = tid / LPR; i < nrows; i += RPP) {
+      constexpr int UN = (MAXT * NWV * 32 + RPP - 1) / RPP;   // all of the image's rows in one batch of loads (one round trip)
+      float x1[UN], x0v[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        int i = u * RPP + tid / LPR;
+        i = i < nrows ? i : nrows - 1;
         const int t = (int)(grow(jbase + i) - clip);        // (rows beyond the clip are clamped re-computations, as the loads were)
         const int t1 = t - a.ic_shift, t0 = t1 - 1;
-        const float x1 = (t1 >= 0 && t1 < a.Tlen) ? au[t1] : 0.0f;
-        const float x0v = (t0 >= 0 && t0 < a.Tlen) ? au[t0] : 0.0f;
-        float v[VEC];
+        const bool ok1 = t1 >= 0 && t1 < a.Tlen, ok0 = t0 >= 0 && t0 < a.Tlen;
+        x1[u] = au[ok1 ? t1 : 0];
+        x0v[u] = au[ok0 ? t0 : 0];
+        x1[u] = ok1 ? x1[u] : 0.0f;
+        x0v[u] = ok0 ? x0v[u] : 0.0f;
+      }
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) v[e] = fmaf(x1, w1[e], fmaf(x0v, w0[e], bb[e]));
-        T* dst = img + (size_t)i * LS + c0;
+      for (int u = 0; u < UN; ++u) {
+        const int i = u * RPP + tid / LPR;
+        if (i < nrows) {
+          float v[VEC];
 #pragma unroll
-        for (int e = 0; e < VEC; e += 4) store4(dst + e, v[e], v[e + 1], v[e + 2], v[e + 3]);
+          for (int e = 0; e < VEC; ++e) v[e] = fmaf(x1[u], w1[e], fmaf(x0v[u], w0[e], bb[e]));
+          T* dst = img + (size_t)i * LS + c0;
+#pragma unroll
+          for (int e = 0; e < VEC; e += 4) store4(dst + e, v[e], v[e + 1], v[e + 2], v[e + 3]);
+        }
       }
     } else {
       const T* x0 = reinterpret_cast<const T*>(a.x0);
@@ -479,7 +493,8 @@ struct GroupBwdArgs {
   // ICG instantiations (the stack's FIRST group): the input conv's kernel + bias gradient (model.py:40; tf.gradients of
   // ops.py:6-20 for the 1 -> R conv) from the group's bottom gradient while it is in the image:
   //   ic_part[slab][k*R + c] = sum_t audio[t - (1-k) - shift] G_0[t][c],   ic_part[slab][2R + c] = sum_t G_0[t][c]
-  // over the rows the workgroup's segments own (srwn_init_conv_wgrad's stage-1 layout, one slab per workgroup)
+  // over the rows the workgroup's segments own (srwn_init_conv_wgrad's stage-1 layout; 8 / (R/16) slabs per workgroup:
+  // slab (workgroup, h) sums the tiles k = h mod that many)
   const float* ic_audio; float* ic_part; int ic_shift;
   unsigned long long* stamps;     // diagnostic instantiation only (srwn_debug_stamp_buffer): waves 0 and 4 of workgroup 0
   int dbg;                        // diagnostic build only (SRWN_WT_DEBUG): 1 = skip the dWr contraction, 2 = skip the dWf one
@@ -1111,28 +1126,31 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
       // A fragment built from the audio -- row 0 / 1: audio[t-1-shift] as bf16 high / low part (fp32 mode: the value / 0),
       // row 2 / 3: audio[t-shift] likewise, row 4: ones, time steps in the tiles' order kordW -- one transposing read, one
       // MFMA.  It was a launch of its own reading the 2R bytes per sample this kernel has just written.
-      if (wave < R / 16) {
+      {
+        // every wave works: column block cblk (16 channels), tiles k = h, h + NH, ... (NH subsets, each with a partial slab
+        // of its own: ic_part holds NH slabs per workgroup); four tiles per trip so that their audio loads fly together
+        constexpr int NCB = R / 16, NH = NWV / NCB;
+        static_assert(NWV % NCB == 0, "waves split evenly over the column blocks");
         int lw = lane;
         asm volatile("" : "+v"(lw));
-        const T* cb = LdT16p<T>::base(img, LS, lw) + 16 * wave;
+        const int cblk = wave % NCB, h = wave / NCB;
+        const T* cb = LdT16p<T>::base(img, LS, lw) + 16 * cblk;
         const int arow = lw & 15, kg = lw >> 4;
         const float* au = a.ic_audio + clip;
         const int ktn = (Wseg + 31) / 32;
+        const int tb = jbase * a.st + r - a.ic_shift - (arow < 2 ? 1 : 0);      // time of position 0 under this row's tap
+        const bool tap_row = arow < 4, one_row = arow == 4;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-        for (int k = 0; k < ktn; ++k) {
+#pragma unroll 4
+        for (int k = h; k < ktn; k += NH) {
           Frag<T> af;
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const int pos = 32 * k + kordW(kg, e);
             const bool own = pos < Wseg;
-            const long long t = (long long)(jbase + pos) * a.st + r;
-            const long long t1 = t - a.ic_shift, t0 = t1 - 1;
-            float x = 0.0f;
-            if (arow < 4 && own) {
-              const long long tt = arow < 2 ? t0 : t1;
-              if (tt >= 0 && tt < a.Tlen) x = au[tt];
-            }
+            const int tt = tb + pos * a.st;
+            const bool ld = tap_row && own && tt >= 0 && tt < a.Tlen;
+            const float x = ld ? au[ld ? tt : 0] : 0.0f;
             float val;
             if (sizeof(T) == 2) {
               const float hi_ = (float)(bf16_t)x;
@@ -1140,15 +1158,14 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
             } else {
               val = (arow & 1) ? 0.0f : x;
             }
-            if (arow == 4) val = own ? 1.0f : 0.0f;
-            if (arow > 4) val = 0.0f;
+            if (one_row) val = own ? 1.0f : 0.0f;
             af.set(e, val);
           }
           const Frag<T> bfv = LdT16p<T>::template load<LS>(cb + (size_t)(32 * k) * LS, 0);
           mma16(acc, af, bfv);
         }
         // D: lane l holds rows 4 (l >> 4) + 0..3 of column l & 15
-        float* pp = a.ic_part + (size_t)blockIdx.x * (3 * R) + 16 * wave + (lw & 15);
+        float* pp = a.ic_part + ((size_t)blockIdx.x * NH + h) * (3 * R) + 16 * cblk + (lw & 15);
         if (lw < 16) {
           pp[0] = (sit > 0 ? pp[0] : 0.0f) + (acc[0] + acc[1]);
           pp[R] = (sit > 0 ? pp[R] : 0.0f) + (acc[2] + acc[3]);

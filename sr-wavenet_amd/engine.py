@@ -476,7 +476,7 @@ class WaveNetEngine:
         self.fuse_icg = (self.fused_wt and self.fuse_ic and not self.E and self.Kw == 2 and self.use_dcs
                          and (self.part16 or self.dt == torch.float32))
         self.ic_ws = z(max(int(_lib.load().srwn_init_conv_wgrad_partials(B, T, R, self.Kw)),
-                           self.nslabs * (self.Kw + 1) * R if self.fuse_icg else 0), dt=torch.float32)
+                           self.nslabs * (8 // (R // 16)) * (self.Kw + 1) * R if self.fuse_icg else 0), dt=torch.float32)
         if self.E:
             self.cond_in = z(B * self.frames, self.Ep)
             self.cond_all = z(L, B * self.frames, R)      # cb of every layer, layer by layer: a layer's frame rows are dense
@@ -836,7 +836,8 @@ class WaveNetEngine:
         if l0 == 0 and self.fuse_icg:      # the stack's first group: the input conv's weight-gradient partials ride along
             ic = (self.audio, self.ic_ws, 1 if self.cfg.shift_input else 0)
             sec = self.sections
-            self._ic_job = (self.ic_ws, ns, (self.Kw + 1) * R, 1, True, 1.0, self.grads.data_ptr() + 4 * sec["init_w"].offset, 0)
+            self._ic_job = (self.ic_ws, ns * (8 // (R // 16)), (self.Kw + 1) * R, 1, True, 1.0,
+                            self.grads.data_ptr() + 4 * sec["init_w"].offset, 0)
         with _Span(self, "group_bwd_wt"):
             K.residual_group_bwd_wt(g_top, self.gs[l0:l1], self.zs[l0:l1], None if flow else self.dcs[l0:l1],
                                     self.xTs[l0:l1], self.cTs[l0:l1],

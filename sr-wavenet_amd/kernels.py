@@ -351,7 +351,7 @@ def residual_group_bwd_wt(g_top: Optional[torch.Tensor], g_out: torch.Tensor, z:
     part_*: partial buffers starting at the group's first layer, [n][nslabs][2RR | RR | R | R]; part_f / part_r fp32, or in
     the compute type bf16 -- the kernel then writes them as 16 x 16 blocks in lane order (reduce with layout BLK16).
     ic = (audio [B,T] fp32, partials fp32 [nslabs * 3R], shift): the stack's first group also leaves the input conv's
-    kernel + bias gradient partials (one slab per workgroup, srwn_init_conv_wgrad's stage-1 layout)."""
+    kernel + bias gradient partials (8 / (R/16) slabs per workgroup, srwn_init_conv_wgrad's stage-1 layout)."""
     import ctypes as C
     n = len(dilations)
     _, B, T, R = z.shape
@@ -377,8 +377,8 @@ def residual_group_bwd_wt(g_top: Optional[torch.Tensor], g_out: torch.Tensor, z:
         _chk(t, name, torch.bfloat16 if (part16 and name in ("part_f", "part_r")) else torch.float32)
         if t.numel() < n * nslabs * per:
             raise ValueError("%s: %d elements, needs %d" % (name, t.numel(), n * nslabs * per))
-    if ic is not None and ic[1].numel() < nslabs * 3 * R:
-        raise ValueError("ic partials: %d floats, needs %d" % (ic[1].numel(), nslabs * 3 * R))
+    if ic is not None and ic[1].numel() < nslabs * (8 // (R // 16)) * 3 * R:
+        raise ValueError("ic partials: %d floats, needs %d" % (ic[1].numel(), nslabs * (8 // (R // 16)) * 3 * R))
     pg = _opt(g_top, "g_top", z.dtype, (B, T, R))
     dl = (C.c_int32 * n)(*[int(d) for d in dilations])
     call("srwn_residual_group_bwd_wt", pg, g_out.data_ptr(), 1 if write_all_g else 0, z.data_ptr(),
