@@ -206,6 +206,31 @@ template <> struct Math<bf16_t> {
 // the reference's gate (ops.py:28-36, incl. the discarded-gate-conv behaviour of line 33):
 //   z = tanh(f); c = z * sigmoid(z)
 template <typename T> __device__ __forceinline__ float gate_of_z(float z) { return z * Math<T>::sigmoid_(z); }
+// The gate of a whole fragment.  bf16: written on register pairs (v_pk_mul_f32 / v_pk_fma_f32: two lanes of fp32 per
+// instruction, the same IEEE operations in the same order as gate_of_z<bf16_t>, so the results are bit-identical) -- 33
+// VALU instructions per fragment.  Inside the skip sum's scheduled chunk loop hipcc's SLP pass gave up on the per-element
+// form: 76 per fragment, half of them unpaired, and the VALU port -- not the matrix pipe -- bounded the loop.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <typename T> __device__ __forceinline__ void gate_frag(Frag<T>& f) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f.set(j, gate_of_z<T>(f.get(j)));
+}
+__device__ __forceinline__ uint32_t gate_pair(uint32_t zz) {      // two bf16 z in one register -> their two gated values
+  const f32x2 z = {__builtin_bit_cast(float, zz << 16), __builtin_bit_cast(float, zz & 0xffff0000u)};
+  const f32x2 u = z * z;
+  f32x2 t = __builtin_elementwise_fma(u, f32x2{0.00175846f, 0.00175846f}, f32x2{-0.02067844f, -0.02067844f});
+  t = __builtin_elementwise_fma(u, t, f32x2{0.24998121f, 0.24998121f});
+  const f32x2 s = __builtin_elementwise_fma(z, t, f32x2{0.5f, 0.5f});
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(z * s, bf16x2));
+}
+template <> __device__ __forceinline__ void gate_frag<bf16_t>(Frag<bf16_t>& f) {
+  u32x4 r = __builtin_bit_cast(u32x4, f.v);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = gate_pair(r[i]);
+  f.v = __builtin_bit_cast(bf16x8, r);
+}
 // d c / d f  = (s + z s (1-s)) * (1 - z^2)
 template <typename T> __device__ __forceinline__ float dgate_df(float z) {
   float s = Math<T>::sigmoid_(z);

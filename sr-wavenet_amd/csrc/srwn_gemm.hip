@@ -111,14 +111,38 @@ __global__ __launch_bounds__(64 * rg_waves(EPI, NT), (EPI == SRWN_EPI_SOFTMAX_CE
       glds16_untracked(g, __builtin_amdgcn_readfirstlane(l));
     }
   };
+  // The load cursor: (source chunk, offset inside it, element offset) of the k-steps of the next chunk to request.
+  // Chunks are requested in order, the last one again once the end is reached (a re-fetch that keeps the counted waits
+  // fixed), so the cursor only ever steps by 16.  The division kg / chunk_len it replaces was 4 x 30 scalar instructions
+  // at the head of every chunk, all waves at once, in a loop that is bound by the instructions a wave can issue (one per
+  // ~5 cycles: in-kernel stamps of a one-wave-per-SIMD variant, profiles/r04_j_skipsum_stamps.txt): skip sum -5.6 us.
+  // (chunk_len % 16 == 0: host check.)
+  int cur_chunk = 0, cur_within = 0, cur_next = 0;
+  int64_t cur_off = 0;      // = cur_chunk * x_chunk_stride + cur_within, in elements
+  const int64_t chunk_step = a.x_chunk_stride - a.chunk_len + 16;
+  auto cursor = [&](int (&chunk)[KSC], int (&within)[KSC], int64_t (&off)[KSC]) {
+    int cc = cur_chunk, ww = cur_within;
+    int64_t oo = cur_off;
+#pragma unroll
+    for (int ks = 0; ks < KSC; ++ks) {
+      chunk[ks] = cc; within[ks] = ww; off[ks] = oo;
+      const bool wrap = ww + 16 >= a.chunk_len;
+      ww = wrap ? 0 : ww + 16;
+      oo += wrap ? chunk_step : (int64_t)16;
+      cc += wrap ? 1 : 0;
+    }
+    if (cur_next + 1 < nchunks) { cur_chunk = cc; cur_within = ww; cur_off = oo; ++cur_next; }
+  };
   // unconditional (clamped) activation loads; rows beyond the end produce values that are never stored
-  auto load_b = [&](int c, Frag<T> (&dst)[NT][KSC], bool (&ok)[NT][KSC]) {
+  auto load_b = [&](Frag<T> (&dst)[NT][KSC], bool (&ok)[NT][KSC]) {
+    int chunks[KSC], withins[KSC];
+    int64_t offs[KSC];
+    cursor(chunks, withins, offs);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int ks = 0; ks < KSC; ++ks) {
-        const int kg = 16 * (c * KSC + ks);
-        const int chunk = kg / a.chunk_len, within = kg - chunk * a.chunk_len;
+        const int chunk = chunks[ks], within = withins[ks];
         const int64_t rbase = valid[nt] ? rowv[nt] : (a.rows - 1);
         if (TAPS) {
           const int tp = tclip[nt] + chunk * a.tap_step;
@@ -128,8 +152,7 @@ __global__ __launch_bounds__(64 * rg_waves(EPI, NT), (EPI == SRWN_EPI_SOFTMAX_CE
           dst[nt][ks] = load_nat(p);
         } else {
           ok[nt][ks] = true;
-          const T* p = reinterpret_cast<const T*>(a.x) + (int64_t)chunk * a.x_chunk_stride + rbase * a.x_row_stride +
-                       within + 8 * half;
+          const T* p = reinterpret_cast<const T*>(a.x) + offs[ks] + rbase * a.x_row_stride + 8 * half;
           dst[nt][ks] = load_nat(p);
         }
       }
@@ -169,21 +192,18 @@ __global__ __launch_bounds__(64 * rg_waves(EPI, NT), (EPI == SRWN_EPI_SOFTMAX_CE
   if constexpr (PIPE) {
     Frag<T> bX[KSC], bY[KSC], bZ[KSC];
     const int64_t rbase = valid[0] ? rowv[0] : (a.rows - 1);
-    auto loadp = [&](int c, Frag<T> (&dst)[KSC]) {
+    auto loadp = [&](Frag<T> (&dst)[KSC]) {
+      int chunks[KSC], withins[KSC];
+      int64_t offs[KSC];
+      cursor(chunks, withins, offs);
+      const T* rp = reinterpret_cast<const T*>(a.x) + rbase * a.x_row_stride + 8 * half;
 #pragma unroll
-      for (int ks = 0; ks < KSC; ++ks) {
-        const int kg = 16 * (c * KSC + ks);
-        const int chunk = kg / a.chunk_len, within = kg - chunk * a.chunk_len;
-        dst[ks] = load_nat(reinterpret_cast<const T*>(a.x) + (int64_t)chunk * a.x_chunk_stride + rbase * a.x_row_stride + within + 8 * half);
-      }
+      for (int ks = 0; ks < KSC; ++ks) dst[ks] = load_nat(rp + offs[ks]);
     };
-    auto gate = [&](Frag<T>& f) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) f.set(j, gate_of_z<T>(f.get(j)));
-    };
+    auto gate = [&](Frag<T>& f) { gate_frag<T>(f); };
     stage(0, 0);
-    loadp(0, bX);
-    loadp(nchunks > 1 ? 1 : 0, bY);
+    loadp(bX);
+    loadp(bY);
     init_acc();                 // (behind the first requests: the bias comes from the L2 while they cross the HBM)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -193,11 +213,14 @@ __global__ __launch_bounds__(64 * rg_waves(EPI, NT), (EPI == SRWN_EPI_SOFTMAX_CE
       stamp(10);
       // nxt (requested a chunk ago) has to be in before anything younger is issued: the compiler's counted wait for it
       // would otherwise cover this chunk's DMA pieces as well (it does not count them)
+      if constexpr (KSC == 4) asm volatile("" : "+v"(nxt[0].v), "+v"(nxt[1].v), "+v"(nxt[2].v), "+v"(nxt[3].v));   // (one wait)
+      else {
 #pragma unroll
-      for (int ks = 0; ks < KSC; ++ks) asm volatile("" : "+v"(nxt[ks].v));
+        for (int ks = 0; ks < KSC; ++ks) asm volatile("" : "+v"(nxt[ks].v));
+      }
       stamp(11);
       if (c + 1 < nchunks) stage(c + 1, (c + 1) & 1);
-      loadp(c + 2 < nchunks ? c + 2 : nchunks - 1, ld);
+      loadp(ld);
       stamp(12);
       const Frag<T>* lw = reinterpret_cast<const Frag<T>*>(smem + (c & 1) * CHUNK_B) + lane;
       Frag<T> af[2][MT];
@@ -242,8 +265,8 @@ __global__ __launch_bounds__(64 * rg_waves(EPI, NT), (EPI == SRWN_EPI_SOFTMAX_CE
   Frag<T> bcur[NT][KSC], bA[NT][KSC], bB[NT][KSC];
   bool okA[NT][KSC], okB[NT][KSC];
   stage(0, 0);
-  load_b(0, bA, okA);
-  load_b(nchunks > 1 ? 1 : 0, bB, okB);
+  load_b(bA, okA);
+  load_b(bB, okB);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   auto chunk = [&](int c, Frag<T> (&bthis)[NT][KSC], bool (&okthis)[NT][KSC]) {
@@ -254,14 +277,11 @@ __global__ __launch_bounds__(64 * rg_waves(EPI, NT), (EPI == SRWN_EPI_SOFTMAX_CE
       for (int ks = 0; ks < KSC; ++ks) {
         bcur[nt][ks] = bthis[nt][ks];   // rows past the end are clamped re-reads: computed, never stored
         if (TAPS) bcur[nt][ks] = okthis[nt][ks] ? bcur[nt][ks] : zero_frag<T>();   // taps outside the clip
-        if (PRO == SRWN_PRO_GATE) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) bcur[nt][ks].set(j, gate_of_z<T>(bcur[nt][ks].get(j)));
-        }
+        if (PRO == SRWN_PRO_GATE) gate_frag<T>(bcur[nt][ks]);
       }
     if (STAMP) { asm volatile("" :: "v"(bcur[0][0].get(0)), "v"(bcur[0][KSC - 1].get(7))); stamp(11); }   // activations arrived, first gate values
     if (c + 1 < nchunks) stage(c + 1, (c + 1) & 1);
-    load_b(c + 2 < nchunks ? c + 2 : nchunks - 1, bthis, okthis);   // (past the end: a re-fetch that keeps the count fixed)
+    load_b(bthis, okthis);   // (past the end: a re-fetch that keeps the count fixed)
     stamp(12);
     const Frag<T>* lw = reinterpret_cast<const Frag<T>*>(smem + (c & 1) * CHUNK_B) + lane;
     // weight fragments one k-step ahead in registers: left to itself hipcc emits ds_read -> s_waitcnt lgkmcnt(0) ->
@@ -646,7 +666,7 @@ int rowgemm_dispatch(const void* x, int64_t x_row_stride, int64_t x_chunk_stride
                      int cout_valid, int64_t rows, const void* aux, int64_t aux_row_stride, const int32_t* targets,
                      float* loss_partials, float* logits_out, float grad_scale, int pro, int epi, int dtype,
                      hipStream_t st, int* rc) {
-  if ((cout_pad != 256 && cout_pad != 128) || (Cin % 64) != 0 || rows < 1) return 0;
+  if ((cout_pad != 256 && cout_pad != 128) || (Cin % 64) != 0 || rows < 1 || chunk_len < 16 || (chunk_len % 16) != 0) return 0;
   if (epi != SRWN_EPI_SOFTMAX_CE && (cout_valid % 64) != 0) return 0;
   if (cout_pad == 128) {   // 128-wide products (the reference scripts' skip_channels=128): 4 row tiles per wave
     if (epi == SRWN_EPI_SOFTMAX_CE) return 0;

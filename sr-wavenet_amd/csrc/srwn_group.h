@@ -146,6 +146,8 @@ __device__ __forceinline__ float frag_dot(float acc, const Frag<float>& f, const
 // KiB, but consecutive lanes 64 bytes apart -- four address-coalescer cycles per quad of lanes instead of one, on every
 // fragment of the forward kernel's stores and of the backward kernels' contraction loops.)
 template <typename T> __device__ __forceinline__ Frag<T> wt_load(const T* tile, int c0, int lane) {
+  // (plain loads: two waves of a workgroup read every fragment -- the output blocks of a 16-channel slice are split over
+  // a wave pair -- and the second read has to find the line; non-temporal here: backward group kernels +44 us per step)
   return load_nat(tile + (size_t)(c0 >> 4) * 512 + lane * 8);
 }
 // (non-temporal, like the z rows and the head's outputs: round 4 A/B on one box, -52 us per step for the three together --
