@@ -62,6 +62,8 @@ struct HcArgs {
   int64_t rows;
   unsigned long long* stamps;   // diagnostic builds only (srwn_debug_stamp_buffer)
   int safe_wait;                // SRWN_SAFE_WAIT: vmcnt(0) instead of the counted wait
+  int stagger;                  // first-round workgroups start (blockIdx / 8) % 8 x stagger x ~1k cycles late
+  int first_round;              // workgroups that start at once (= CUs)
 };
 
 constexpr int kHcWaves = 8;
@@ -98,6 +100,13 @@ __global__ __launch_bounds__(64 * kHcWaves) void headchain_kernel(HcArgs a) {
   HcStamper<STAMP> stamp{nullptr, 0};
   if (STAMP && blockIdx.x == 0 && lane == 0 && wave < 2) stamp.p = a.stamps + wave * 512;
   stamp(1);
+  // Every workgroup is load burst -> 16 chunk steps -> four store bursts, and the first round of them starts in the same
+  // cycle on every CU: HBM and the matrix pipes took turns chip-wide (profiles/r03_w: the prologue's 128-KB tile 24.6 k
+  // cycles, an epilogue's stores up to 12.5 k, of a workgroup's 98 k).  A start offset per CU smears the bursts.
+  if (a.stagger > 0 && (int)blockIdx.x < a.first_round) {
+    const int d = (int)((blockIdx.x >> 3) & 7) * a.stagger;
+    for (int i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(16);      // ~1k cycles each
+  }
 
   auto stage = [&](int g, int buf) __attribute__((always_inline)) {      // chunk c = g % 4 of image g / 4 -> weight buffer `buf`
     const char* wbase = reinterpret_cast<const char*>(a.w[g / NCH]);
@@ -116,6 +125,8 @@ __global__ __launch_bounds__(64 * kHcWaves) void headchain_kernel(HcArgs a) {
   Frag<T> bfr[KS];
   stage(0, 0);
   if (kHcBufs > 2) stage(1, 1);
+  // (whole 128-byte row pieces through the wave's row stage instead -- 8 lines per load instruction, not 32 -- measured the
+  // same 97.5 / 97.9 us: the prologue is the chip-wide burst and its latency, not the address path)
   {
     const T* xr = reinterpret_cast<const T*>(a.r0) + rowc * C + 8 * half;
 #pragma unroll
@@ -297,6 +308,15 @@ __global__ __launch_bounds__(64 * kHcWaves) void headchain_kernel(HcArgs a) {
 
 }  // namespace
 
+static int num_cus_hc() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+  }
+  return cus;
+}
+
 extern "C" int srwn_head_chain(const void* r0, const void* w1, const void* w2_perm, const void* w2T_perm,
                                const void* w1T_perm, const float* b1, const float* b2, const int32_t* targets,
                                float* loss_partials, void* r1, void* dlogits, void* da1, void* dtotal, int32_t S,
@@ -311,7 +331,12 @@ extern "C" int srwn_head_chain(const void* r0, const void* w1, const void* w2_pe
   if (rows < 0 || cout_valid < 1 || cout_valid > 256 || (rows + 31) / 32 / kHcWaves + 1 > 0x7fffffffLL)
     return set_error(SRWN_E_SHAPE, "head_chain: rows=%lld cout_valid=%d", (long long)rows, cout_valid);
   HcArgs a{r0, {w1, w2_perm, w2T_perm, w1T_perm}, b1, b2, targets, loss_partials, grad_scale, cout_valid,
-           r1, dlogits, da1, dtotal, rows, debug_stamps(), safe_wait()};
+           r1, dlogits, da1, dtotal, rows, debug_stamps(), safe_wait(), 0, 0};
+  {
+    static const int stg = [] { const char* e = getenv("SRWN_HC_STAGGER"); return e ? atoi(e) : 2; }();
+    a.stagger = stg;
+    a.first_round = num_cus_hc();
+  }
   const int64_t tiles = (rows + 31) / 32;
   const size_t sh = kHcBufs * (size_t)(8 * 4 * 1024) + (size_t)kHcWaves * 32 * RowStage<bf16_t>::stride(64) * sizeof(bf16_t) + 2 * 256 * sizeof(float) + (size_t)kHcWaves * 32 * 33;
   auto kfn = headchain_kernel<bf16_t, false>;
