@@ -249,4 +249,18 @@ template <> __device__ __forceinline__ float dgate_df<bf16_t>(float z) {
   return fmaf(z, r, fmaf(u, -0.5f, 0.5f));
 }
 
+// dgate_df of four values at once (bf16 mode): the same operations on two register pairs side by side.  Written per value
+// the compiler pairs the lanes but schedules ONE Horner chain at a time (live ranges first: the kernels that use it run at
+// 256 registers), and every link of a chain of packed fp32 needs a wait state behind the one before: 6 s_nop per pair,
+// a third of the instruction slots of the chain.  Two chains interleaved need none.
+__device__ __forceinline__ f32x4 dgate_df4(f32x4 z) {
+  const f32x4 u = z * z;
+  f32x4 r = __builtin_elementwise_fma(u, f32x4{0.00142598f, 0.00142598f, 0.00142598f, 0.00142598f}, f32x4{-0.01381972f, -0.01381972f, -0.01381972f, -0.01381972f});
+  r = __builtin_elementwise_fma(u, r, f32x4{0.0957148f, 0.0957148f, 0.0957148f, 0.0957148f});
+  r = __builtin_elementwise_fma(u, r, f32x4{-0.5833199f, -0.5833199f, -0.5833199f, -0.5833199f});
+  r = __builtin_elementwise_fma(u, r, f32x4{0.49999976f, 0.49999976f, 0.49999976f, 0.49999976f});
+  const f32x4 ev = __builtin_elementwise_fma(u, f32x4{-0.5f, -0.5f, -0.5f, -0.5f}, f32x4{0.5f, 0.5f, 0.5f, 0.5f});
+  return __builtin_elementwise_fma(z, r, ev);
+}
+
 }  // namespace srwn

@@ -637,27 +637,31 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
       for (int e = 0; e < 8; ++e) ones.set(e, 1.0f);
       f32x4 accb = {0.f, 0.f, 0.f, 0.f};
       const int kfull = Wseg >> 5;
+      // tiles the segment owns whole first (plain ones, no per-value selects in the loop: with them this loop, which only four
+      // waves run, was 170 instructions per four tiles against 55 -- longer than those waves' share of the dWf contraction
+      // that follows it), then the one tile it may own in part
+      const int nfull = mask ? (kfull < ntiles ? kfull : ntiles) : ntiles;
       constexpr int CU = 4;      // tiles per batch of transposing reads (one LDS round trip per batch, not per tile)
 #pragma unroll 1
-      for (int k0 = 0; k0 < ntiles; k0 += CU) {
+      for (int k0 = 0; k0 < nfull; k0 += CU) {
         Frag<T> bf[CU];
 #pragma unroll
         for (int u = 0; u < CU; ++u) {
-          const int k = k0 + u < ntiles ? k0 + u : ntiles - 1;
+          const int k = k0 + u < nfull ? k0 + u : nfull - 1;
           bf[u] = LdT16p<T>::template load<LS>(cb + (size_t)(32 * k) * LS, 0);
         }
 #pragma unroll
         for (int u = 0; u < CU; ++u) {
-          const int k = k0 + u;
-          Frag<T> ok = ones;
-          if (k >= ntiles) ok = zero_frag<T>();
-          else if (mask && k >= kfull) {
-            const int hik = Wseg - 32 * k;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) ok.set(e, kordW(lw >> 4, e) < hik ? 1.0f : 0.0f);
-          }
-          mma16(accb, ok, bf[u]);
+          if (k0 + u < nfull) mma16(accb, ones, bf[u]);      // (wave-uniform)
         }
+      }
+      if (mask && nfull < ntiles) {
+        const int hik = Wseg - 32 * nfull;
+        Frag<T> ok;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ok.set(e, kordW(lw >> 4, e) < hik ? 1.0f : 0.0f);
+        const Frag<T> bfl = LdT16p<T>::template load<LS>(cb + (size_t)(32 * nfull) * LS, 0);
+        mma16(accb, ok, bfl);
       }
       if (lw < 16) {      // (row 0 of the 16 x 16 result: every row holds the sums)
         float* pb = pb_slab + 16 * wave + lw;
@@ -881,16 +885,33 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
           else if (g > 0) issue(g - 1, wave < a.NT ? wave : a.NT - 1);
         }
         f32x16 accC[RT];
+        if (DCS && !ok) {      // (rows beyond the clip: the select on the packed words, not on every value)
+#pragma unroll
+          for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) dc0[mt][gq] = Raw4g<T>::zero();
+        }
 #pragma unroll
         for (int mt = 0; mt < RT; ++mt)
 #pragma unroll
           for (int gq = 0; gq < 4; ++gq)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) accC[mt][4 * gq + e] = (DCS && ok) ? Raw4g<T>::get(dc0[mt][gq], e) : 0.0f;
+            for (int e = 0; e < 4; ++e) accC[mt][4 * gq + e] = DCS ? Raw4g<T>::get(dc0[mt][gq], e) : 0.0f;
         if (haveg) {
 #pragma unroll
           for (int s = 0; s < KS; ++s) {
             Frag<T> bfr;
+            if constexpr (WT && sizeof(T) == 2) {
+              bf16x4 hv[2];
+#pragma unroll
+              for (int h2 = 0; h2 < 2; ++h2) {
+                const raw4& gr = G[m][s >> 1][2 * (s & 1) + h2];
+                f32x4 g4 = {Raw4g<T>::get(gr, 0), Raw4g<T>::get(gr, 1), Raw4g<T>::get(gr, 2), Raw4g<T>::get(gr, 3)};
+                g4 = g4 * f32x4{kSqrtHalf, kSqrtHalf, kSqrtHalf, kSqrtHalf};
+                hv[h2] = Raw4g<bf16_t>::pack(g4[0], g4[1], g4[2], g4[3]);
+              }
+              bfr.v = __builtin_shufflevector(hv[0], hv[1], 0, 1, 2, 3, 4, 5, 6, 7);
+            } else
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj)
               bfr.set(jj, ((WT || ok) ? Raw4g<T>::get(G[m][s >> 1][2 * (s & 1) + (jj >> 2)], jj & 3) : 0.0f) * kSqrtHalf);   // (WT: G is 0 beyond the clip, see phase B)
@@ -899,6 +920,19 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
           }
         }
         float dv[RT][16];
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+          for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+              const f32x4 z4 = {Raw4g<T>::get(zz[mt][gq], 0), Raw4g<T>::get(zz[mt][gq], 1), Raw4g<T>::get(zz[mt][gq], 2), Raw4g<T>::get(zz[mt][gq], 3)};
+              const f32x4 a4 = {accC[mt][4 * gq], accC[mt][4 * gq + 1], accC[mt][4 * gq + 2], accC[mt][4 * gq + 3]};
+              const f32x4 d4 = a4 * dgate_df4(z4);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) dv[mt][4 * gq + e] = d4[e];
+            }
+        } else
+        {
 #pragma unroll
         for (int mt = 0; mt < RT; ++mt)
 #pragma unroll
@@ -906,6 +940,7 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
               dv[mt][4 * gq + e] = accC[mt][4 * gq + e] * dgate_df<T>(Raw4g<T>::get(zz[mt][gq], e));
+        }
         tile_store(trow, dfg, q, WT ? 0 : hi, dv);     // (WT: into the image only; its readers are all on the chip)
         __builtin_amdgcn_sched_barrier(0);   // keep the tile bodies apart: interleaving them only lengthens live ranges
       }
@@ -944,11 +979,24 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
                                                                     // past the image reads zeros -- clamped it would read the last row,
                                                                     // which only the select on ok_d kept out)
         f32x16 accG[RT];
+        if constexpr (WT) {      // (no select: without a gradient from above G is still the zeros it was initialised with)
+#pragma unroll
+          for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+              f32x4 g4 = {Raw4g<T>::get(G[m][mt][gq], 0), Raw4g<T>::get(G[m][mt][gq], 1), Raw4g<T>::get(G[m][mt][gq], 2), Raw4g<T>::get(G[m][mt][gq], 3)};
+              g4 = g4 * f32x4{kSqrtHalf, kSqrtHalf, kSqrtHalf, kSqrtHalf};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) accG[mt][4 * gq + e] = g4[e];
+            }
+        } else
+        {
 #pragma unroll
         for (int mt = 0; mt < RT; ++mt)
 #pragma unroll
           for (int e = 0; e < 16; ++e)
             accG[mt][e] = (haveg && (WT || ok)) ? Raw4g<T>::get(G[m][mt][e >> 2], e & 3) * kSqrtHalf : 0.0f;
+        }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const Frag<T> f0 = load_nat(img + (size_t)src * LS + 16 * ks + 8 * half);
