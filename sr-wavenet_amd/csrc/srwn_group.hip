@@ -796,12 +796,13 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
 #pragma unroll
               for (int j = 0; j < 8; ++j) av[j] = wt_load(ct + (size_t)(j < ktn ? j : (ktn > 0 ? ktn - 1 : 0)) * (R * 32), 16 * ib, lw);
             }
-#pragma unroll 1
-            for (int k0 = 0; k0 < ktn; k0 += 8) {
+            // (two groups of eight per trip, the two register sets swapping roles: copying the set that arrived into the set in
+            // use was 16 moves + 7 waits per group -- a tenth of this loop's instructions, and instructions are its time)
+            auto group8 = [&](int k0, Frag<T> (&cur)[8], Frag<T> (&nxt)[8]) __attribute__((always_inline)) {
 #pragma unroll
               for (int j = 0; j < 8; ++j) {
                 const int kn = k0 + 8 + j;
-                bv[j] = wt_load(ct + (size_t)(kn < ktn ? kn : ktn - 1) * (R * 32), 16 * ib, lw);
+                nxt[j] = wt_load(ct + (size_t)(kn < ktn ? kn : ktn - 1) * (R * 32), 16 * ib, lw);
               }
 #pragma unroll
               for (int j = 0; j < 8; ++j) {
@@ -815,13 +816,16 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
                   __builtin_amdgcn_sched_group_barrier(0x008 | 0x002, 64, 0);
 #pragma unroll
                   for (int bb = 0; bb < NBW; ++bb) {
-                    mma16(acc[bb], av[j], bfv[bb]);
+                    mma16(acc[bb], cur[j], bfv[bb]);
                   }
                 }
                 __builtin_amdgcn_sched_barrier(0);   // (left alone, the scheduler hoists all the transposing reads of the chunk: spills)
               }
-#pragma unroll
-              for (int j = 0; j < 8; ++j) av[j] = bv[j];
+            };
+#pragma unroll 1
+            for (int k0 = 0; k0 < ktn; k0 += 16) {
+              group8(k0, av, bv);
+              if (k0 + 8 < ktn) group8(k0 + 8, bv, av);
             }
           }
           stamp(22);
@@ -1041,12 +1045,11 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
           Frag<T> av[8], bv[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) av[j] = wt_load(xt + (size_t)(j < ktn ? j : (ktn > 0 ? ktn - 1 : 0)) * (R * 32), 16 * ibl, lw);
-#pragma unroll 1
-          for (int k0 = 0; k0 < ktl; k0 += 8) {
+          auto group8 = [&](int k0, Frag<T> (&cur)[8], Frag<T> (&nxt)[8]) __attribute__((always_inline)) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
               const int kn = k0 + 8 + j;
-              bv[j] = wt_load(xt + (size_t)(kn < ktn ? kn : ktn - 1) * (R * 32), 16 * ibl, lw);
+              nxt[j] = wt_load(xt + (size_t)(kn < ktn ? kn : ktn - 1) * (R * 32), 16 * ibl, lw);
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -1062,13 +1065,16 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
                 __builtin_amdgcn_sched_group_barrier(0x008 | 0x002, 64, 0);   // ... then the products and the column sums
 #pragma unroll
                 for (int bb = 0; bb < NBF; ++bb) {
-                  mma16(acc[bb], av[j], bfv[bb]);
+                  mma16(acc[bb], cur[j], bfv[bb]);
                 }
               }
               __builtin_amdgcn_sched_barrier(0);
             }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) av[j] = bv[j];
+          };
+#pragma unroll 1
+          for (int k0 = 0; k0 < ktl; k0 += 16) {      // (two groups per trip, the register sets swapping roles: see dWr)
+            group8(k0, av, bv);
+            if (k0 + 8 < ktl) group8(k0 + 8, bv, av);
           }
           if constexpr (P16) {      // (the [2 R, R] matrix of both taps: row block tap * R/16 + ib)
             typedef typename Raw4g<bf16_t>::type p4;
