@@ -8,8 +8,14 @@ sys.path.insert(0, __import__("os").path.dirname(__file__))
 from rocpd_summary import load
 
 rows = load(sys.argv[1])
-mark = sys.argv[2] if len(sys.argv) > 2 else "causal_conv_cin1"
-starts = [i for i, r in enumerate(rows) if mark in r[0]]
+# the step's first kernel: the input conv of its own launch (rounds 1-3), or -- fused into the first forward group kernel
+# (round 4) -- whatever follows the re-pack that ends the previous step
+if len(sys.argv) > 2:
+    starts = [i for i, r in enumerate(rows) if sys.argv[2] in r[0]]
+else:
+    starts = [i for i, r in enumerate(rows) if "causal_conv_cin1" in r[0]]
+    if len(starts) < 3:
+        starts = [i + 1 for i, r in enumerate(rows) if "pack_gather_kernel" in r[0] and i + 1 < len(rows)]
 # the last complete step
 if len(starts) < 3:
     raise SystemExit("not enough steps")
