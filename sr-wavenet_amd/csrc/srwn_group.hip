@@ -328,11 +328,15 @@ __global__ __launch_bounds__(64 * NWV) void group_fwd_kernel(GroupFwdArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) accF[mt][4 * gq + e] = bv[e];
           }
+        // (the causal zero padding only exists in a clip's first tiles: the select on every fragment register only there)
+        if (__builtin_amdgcn_ballot_w64(!ok0) != 0ull) {
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) tap0[m][ks] = ok0 ? tap0[m][ks] : zero_frag<T>();
+        }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          const Frag<T> bfr = ok0 ? tap0[m][ks] : zero_frag<T>();
 #pragma unroll
-          for (int mt = 0; mt < RT; ++mt) mma(accF[mt], lds_conv[(mt * (K * KS) + ks) * 64 + lane], bfr);
+          for (int mt = 0; mt < RT; ++mt) mma(accF[mt], lds_conv[(mt * (K * KS) + ks) * 64 + lane], tap0[m][ks]);
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
@@ -344,6 +348,19 @@ __global__ __launch_bounds__(64 * NWV) void group_fwd_kernel(GroupFwdArgs a) {
         Frag<T> cf[KS];
         {
           float zz[RT][16];
+          if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int mt = 0; mt < RT; ++mt)
+#pragma unroll
+              for (int gq = 0; gq < 4; ++gq) {
+                const f32x4 z4 = tanh4_bf16(f32x4{accF[mt][4 * gq], accF[mt][4 * gq + 1], accF[mt][4 * gq + 2], accF[mt][4 * gq + 3]});
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  zz[mt][4 * gq + e] = z4[e];
+                  cf[2 * mt + (gq >> 1)].set(4 * (gq & 1) + e, gate_of_z<T>(z4[e]));
+                }
+              }
+          } else
 #pragma unroll
           for (int mt = 0; mt < RT; ++mt)
 #pragma unroll
