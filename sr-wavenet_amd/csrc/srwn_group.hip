@@ -495,6 +495,7 @@ struct GroupBwdArgs {
   const void* wconvT[kMaxGroup];  // packed [R/32][K*R/16] natural (rows = in channel), as srwn_residual_layer_bwd takes them
   const void* wresT[kMaxGroup];   // packed [R/32][R/16] permuted
   int sub[kMaxGroup];
+  int hb[kMaxGroup];              // sum of sub[0 .. g-1]: how far the layers below layer g reach beyond the segment (host: no scalar-load loop per layer)
   int nl, st, Tlen, B;
   int W, H, NT, nsub, nseg;
   // WT instantiations (layer weight gradients summed in this launch): the forward kernel's weight-gradient tiles (layer g at
@@ -743,8 +744,7 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
       // so G_g is needed for positions < Wseg + hb and df_g for positions < Wseg + hb + sub_g.  Tiles beyond that are
       // skipped (for 500 + 31 positions the 17th tile is live in three of the ten phases of a 1..16 group only --
       // with eight waves it is a whole third round of its phase).
-      int hb = 0;
-      for (int h = 0; h < g; ++h) hb += a.sub[h];
+      const int hb = a.hb[g];
       int ntA = (Wseg + hb + d + 31) / 32, ntB = (Wseg + hb + 31) / 32;
       ntA = (a.H == 0 || ntA > a.NT) ? a.NT : ntA;
       ntB = (a.H == 0 || ntB > a.NT) ? a.NT : ntB;
@@ -1413,6 +1413,7 @@ static int group_bwd_impl(const void* g_top, void* g_out, void* df_out, const vo
   a.nl = nlayers; a.Tlen = T; a.B = B;
   if (group_geometry(dilations, nlayers, &a.st, a.sub, &a.H) != 0)
     return set_error(SRWN_E_SHAPE, "residual_group_bwd: dilations must be >= 1");
+  for (int g = 0, acc = 0; g < kMaxGroup; ++g) { a.hb[g] = acc; acc += g < nlayers ? a.sub[g] : 0; }
   if (a.H > 31) return set_error(SRWN_E_UNSUPPORTED, "residual_group_bwd: halo %d > 31 (sum of dilations / their gcd)", a.H);
   hipStream_t st = (hipStream_t)stream;
   if (wt) {
