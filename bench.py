@@ -201,9 +201,11 @@ def main():
 
     use_graph = bool(args.graph)
     step_fn = eng.train_step
-    for _ in range(max(args.warmup, 1 if use_graph else 0)):
-        eng.train_step()
     if use_graph:
+        # one eager step (allocations, lazy initialisation), the capture, THEN the W warm-up steps as replays of the
+        # captured step: the capture is tens of ms of host work with the GPU idle, and warm-up steps taken before it
+        # leave the timed region to start on a card that has clocked down (20 timed steps are 33 ms)
+        eng.train_step()
         try:   # {fwd,bwd} and {Adam,pack} as two hipGraphs; the RCCL all-reduce stays between them
             eng.capture_graphs()
             step_fn = eng.train_step_graphed
@@ -211,7 +213,9 @@ def main():
         except Exception as e:   # fall back to eager launches, and say so
             print("hipGraph capture failed (%s); running eager" % e, file=sys.stderr)
             use_graph, step_fn = False, eng.train_step
-        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step_fn()
+    torch.cuda.synchronize()
 
     def sync():
         if dist is not None:
@@ -229,6 +233,19 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt_s = float(tt.item())
     loss = float(eng.loss.item())
+
+    # ---- outside the timed region, not `value`: the same step over a longer window.  The K timed steps (33 ms at K = 20)
+    # start a few ms after the card was idle (graph capture, barrier); A/Bs on one box (tools/ab_step.py: 200-step
+    # windows after 20 warm-up replays) read 3-4 % lower than a 20-step window there, so both are reported.
+    ms_steady = None
+    if use_graph and not args.no_extras:
+        nst = 200
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(nst):
+            step_fn()
+        sync()
+        ms_steady = (time.perf_counter() - t1) / nst * 1e3
 
     # ---- multi-rank only, outside the timed region: how much of the gradient all-reduce the schedule leaves EXPOSED --
     # the time the launch stream spends in the collectives after the lower backward graph has finished (all of bucket B
@@ -347,8 +364,10 @@ def main():
             with torch.cuda.graph(cg, stream=cs):
                 for _ in range(reps):
                     chain()
+            for _ in range(4):      # (untimed: a replay is 2.4 ms, and the first ones after the idle capture run 10 % long)
+                cg.replay()
             ts = []
-            for _ in range(5):
+            for _ in range(11):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(cs)
                 cg.replay()
@@ -388,7 +407,7 @@ def main():
         out = {
             "metric": "audio samples/sec (fwd+bwd) 30-layer teacher WaveNet",
             "value": world * N * args.steps / dt_s, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * dt_s / args.steps, "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt_s / args.steps, "ms_per_step_200_more_steps": ms_steady, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "30-layer teacher WaveNet (3x[1..512] dilations, 64 res / 256 skip ch, 256-way "
                                    "mu-law softmax), fwd+bwd+Adam, batch %dx%d samples per GPU" % (B, T),
