@@ -526,6 +526,10 @@ struct GroupBwdArgs {
 constexpr int kWtPadRows = 64;
 // Two ways of hiding the weight-gradient fragment loads behind the chain, both built and measured, both off: they need
 // registers the R = 64 kernels do not have (256 of 256 in use: every extra live value is a scratch access in a hot loop).
+// the dWr loop's first eight c^T fragments are requested before G is parked (one HBM round trip under the parking and its
+// barrier: six launches -6.7 us, step -4 us on one box; no spills in the two-tile kernel, 13 more dwords in the three-tile
+// one).  The same for the dWf loop's x^T fragments ahead of phase B: -1.5 us, inside the noise, not kept.
+constexpr bool kWtEarlyR = true;      // (bf16 kernels: an fp32 fragment set is 64 registers)
 constexpr bool kWtStagger = false;   // half of the waves contract dWf before their taps, half after
 constexpr bool kWtEarlyC = false;    // the next layer's first c^T fragments requested a phase early   // finite (zero) rows behind the image: the shifted tap of the last weight-gradient tile reads past it
 
@@ -768,6 +772,11 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
         for (int bb = 0; bb < NBW; ++bb) acc[bb] = f32x4{0.f, 0.f, 0.f, 0.f};
         int lw = lane;      // (opaque copy: keeps this block's lane-dependent addresses from being hoisted over the chain,
         asm volatile("" : "+v"(lw));   //  where every register counts)
+        if (kWtEarlyR && sizeof(T) == 2 && haveg && active && !(WT_DBG(a) & 1)) {
+          const T* ct0 = reinterpret_cast<const T*>(a.cT) + (size_t)g * a.wt_stride + (size_t)seg * a.KT * (R * 32);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acn[j] = wt_load(ct0 + (size_t)(j < ktn ? j : (ktn > 0 ? ktn - 1 : 0)) * (R * 32), 16 * ib, lw);
+        }
         if (haveg) {
 #pragma unroll
           for (int m = 0; m < MAXT; ++m) {
@@ -806,7 +815,7 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
             // whole chain).  No branches inside: tiles beyond the segment's contribute a zero fragment.
             const T* gbase = LdT16p<T>::base(img, LS, lw) + 16 * ob0;
             Frag<T> av[8], bv[8];
-            if (kWtEarlyC && n > 0) {           // requested during the layer above
+            if ((kWtEarlyR && sizeof(T) == 2) || (kWtEarlyC && n > 0)) {           // requested before G was parked / during the layer above
 #pragma unroll
               for (int j = 0; j < 8; ++j) av[j] = acn[j];
             } else {
@@ -1130,7 +1139,9 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
       // (Measured: the second copy of the two bodies and the longer live ranges cost 30-60 spilled registers in the R = 64
       // kernels, which are at 256 already -- 0.74 -> 0.98 ms per step; off.)
       if (kWtStagger && WT && wave < NWV / 2) { dwf(); phaseB(); }
-      else { phaseB(); stamp(27); if (WT) dwf(); }
+      else {
+        phaseB(); stamp(27); if (WT) dwf();
+      }
       stamp(28);
       if (NWB == 2 && g > 0) dma_wait();
       stamp(29);
