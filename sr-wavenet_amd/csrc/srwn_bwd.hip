@@ -669,7 +669,15 @@ __global__ __launch_bounds__(256) void reduce_partials_wide_kernel(const float* 
   double s = 0.0;
   if (i < n) {
     const float* p = partials + (int64_t)l * part_batch_mul * nslabs * n + i;
-    for (int k = sub; k < nslabs; k += 16) s += (double)p[(int64_t)k * n];
+    int k = sub;      // (eight loads in flight per lane, the same order of summation: see reduce_partials_multi_kernel)
+    for (; k + 16 * 7 < nslabs; k += 16 * 8) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = p[(int64_t)(k + 16 * j) * n];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += (double)v[j];
+    }
+    for (; k < nslabs; k += 16) s += (double)p[(int64_t)k * n];
   }
 #pragma unroll
   for (int w = 8; w > 0; w >>= 1) s += __shfl_xor(s, w, 64);
@@ -686,6 +694,7 @@ struct RpJob {
   const float* partials; float* out; int64_t n; int64_t out_batch_stride;
   int nslabs, nbatch, part_batch_mul; float scale; int wide; unsigned blocks_x, block0;
   int blk_cols;      // wide == 3: `partials` holds bf16 16 x 16 blocks in lane order (SRWN_PARTIALS_BLK16)
+  int sg;            // wide == 3: the slabs of an output are split over sg threads of a block (1, 2, 4 or 8)
 };
 struct RpMulti { RpJob j[kRpMaxJobs]; int njobs; };
 
@@ -716,30 +725,52 @@ __global__ __launch_bounds__(256) void reduce_partials_multi_kernel(RpMulti m) {
   }
   if (job.wide == 3) {
     // bf16 blocks in lane order: a thread takes two neighbouring lanes of one block (16 bytes per slab: four rows of two
-    // columns), eight slabs in flight; every output is summed slab by slab in order, in f64, like the fp32 bodies
-    const int64_t q = (int64_t)bx * 256 + threadIdx.x;      // (block, lane pair)
-    if (q * 8 >= n) return;
-    const int64_t blk = q >> 5;
-    const int pr = (int)(q & 31);
-    const bf16_t* p = reinterpret_cast<const bf16_t*>(job.partials) + (int64_t)l * job.part_batch_mul * nslabs * n + q * 8;
+    // columns), eight slabs in flight, f64 sums.  The slabs of an output are split over job.sg threads of the block whose
+    // f64 partial sums meet in LDS: one thread per 16 bytes of output and 256 slabs each was 720 waves on the chip -- 24 KB
+    // of loads in flight per CU, 4.3 TB/s, where a plain read stream reaches 6.3 (tools/micro/cuingest.hip).  Same bits
+    // for any sg: a sum of a few hundred bf16 values is exact in f64, so its association does not matter.
+    __shared__ double red[256 * 8];
+    const int sg = job.sg, qpb = 256 / sg;                    // (block-uniform) outputs per block
+    const int qi = (int)threadIdx.x % qpb, g = (int)threadIdx.x / qpb;
+    const int64_t q = (int64_t)bx * qpb + qi;      // (block, lane pair)
+    const bool live = q * 8 < n;
+    const int per = nslabs / sg, k0 = g * per, k1 = (g == sg - 1) ? nslabs : k0 + per;
     double s[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = 0.0;
-    int k = 0;
-    for (; k + 8 <= nslabs; k += 8) {
-      srwn::bf16x8 v[8];
+    if (live) {
+      const bf16_t* p = reinterpret_cast<const bf16_t*>(job.partials) + (int64_t)l * job.part_batch_mul * nslabs * n + q * 8;
+      int k = k0;
+      for (; k + 8 <= k1; k += 8) {
+        srwn::bf16x8 v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = SRWN_NT_LOAD(reinterpret_cast<const srwn::bf16x8*>(p + (int64_t)(k + j) * n));
+        for (int j = 0; j < 8; ++j) v[j] = SRWN_NT_LOAD(reinterpret_cast<const srwn::bf16x8*>(p + (int64_t)(k + j) * n));
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < 8; ++j)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s[e] += (double)(float)v[j][e];
+          for (int e = 0; e < 8; ++e) s[e] += (double)(float)v[j][e];
+      }
+      for (; k < k1; ++k) {
+        const srwn::bf16x8 v = *reinterpret_cast<const srwn::bf16x8*>(p + (int64_t)k * n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += (double)(float)v[e];
+      }
     }
-    for (; k < nslabs; ++k) {
-      const srwn::bf16x8 v = *reinterpret_cast<const srwn::bf16x8*>(p + (int64_t)k * n);
+    if (sg > 1) {
+      if (g > 0) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s[e] += (double)(float)v[e];
+        for (int e = 0; e < 8; ++e) red[(g * qpb + qi) * 8 + e] = s[e];
+      }
+      __syncthreads();
+      if (g > 0) return;
+      for (int gg = 1; gg < sg; ++gg) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += red[(gg * qpb + qi) * 8 + e];
+      }
     }
+    if (!live) return;
+    const int64_t blk = q >> 5;
+    const int pr = (int)(q & 31);
     const int nib = job.blk_cols / 16;
     const int lane = 2 * pr;
     const int64_t row0 = 16 * (blk / nib) + 4 * (lane >> 4);
@@ -757,7 +788,18 @@ __global__ __launch_bounds__(256) void reduce_partials_multi_kernel(RpMulti m) {
     double s = 0.0;
     if (i < n) {
       const float* p = job.partials + (int64_t)l * job.part_batch_mul * nslabs * n + i;
-      for (int q = sub; q < nslabs; q += 16) s += (double)p[(int64_t)q * n];
+      // eight loads in flight per lane, summed in the order they were always summed: one load per trip made a small job
+      // of many slabs (the input conv's 512 slabs of 192 floats: 32 trips, each a whole HBM round trip) the longest thing
+      // in a launch that moves 190 MB
+      int q = sub;
+      for (; q + 16 * 7 < nslabs; q += 16 * 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = p[(int64_t)(q + 16 * j) * n];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += (double)v[j];
+      }
+      for (; q < nslabs; q += 16) s += (double)p[(int64_t)q * n];
     }
 #pragma unroll
     for (int w = 8; w > 0; w >>= 1) s += __shfl_xor(s, w, 64);
@@ -823,19 +865,22 @@ extern "C" int srwn_reduce_partials_multi(const SrwnReduceJob* jobs, int32_t njo
     if (q.nslabs >= 128 && q.n >= 1024 && q.n % 4 == 0 && q.out_batch_stride % 4 == 0 &&
         (reinterpret_cast<uintptr_t>(q.partials) | reinterpret_cast<uintptr_t>(q.out)) % 16 == 0)
       j.wide = 2;
-    j.blk_cols = 0;
+    j.blk_cols = 0; j.sg = 1;
     if (q.layout == SRWN_PARTIALS_BLK16) {
       if (q.blk_cols < 16 || q.blk_cols % 16 || q.n % (16 * (int64_t)q.blk_cols) || q.out_batch_stride % 2 ||
           (reinterpret_cast<uintptr_t>(q.partials) % 16) || (reinterpret_cast<uintptr_t>(q.out) % 8))
         return set_error(SRWN_E_SHAPE, "reduce_partials_multi: job %d: BLK16 layout needs n = rows*blk_cols in whole 16 x 16 blocks (n=%lld, blk_cols=%d)", k, (long long)q.n, q.blk_cols);
       j.wide = 3; j.blk_cols = q.blk_cols;
+      // split the slabs of an output over up to 8 threads until the job brings ~16 waves per CU (groups of >= 8 slabs)
+      j.sg = 1;
+      while (j.sg < 8 && q.nslabs / (2 * j.sg) >= 8 && (q.n / 8) * (int64_t)q.nbatch * j.sg < (int64_t)256 * 16 * 64) j.sg *= 2;
     } else if (q.layout == SRWN_PARTIALS_SUM) {
       if (q.nbatch != 1) return set_error(SRWN_E_SHAPE, "reduce_partials_multi: job %d: SUM layout has one output", k);
       j.wide = 4;
     } else if (q.layout != SRWN_PARTIALS_F32) {
       return set_error(SRWN_E_UNSUPPORTED, "reduce_partials_multi: job %d: layout %d", k, q.layout);
     }
-    j.blocks_x = (unsigned)(j.wide == 4 ? 1 : j.wide == 3 ? (q.n / 8 + 255) / 256 : j.wide == 2 ? (q.n / 4 + 255) / 256 : j.wide ? (q.n + 15) / 16 : (q.n + 255) / 256);
+    j.blocks_x = (unsigned)(j.wide == 4 ? 1 : j.wide == 3 ? (q.n / 8 + 256 / j.sg - 1) / (256 / j.sg) : j.wide == 2 ? (q.n / 4 + 255) / 256 : j.wide ? (q.n + 15) / 16 : (q.n + 255) / 256);
     j.block0 = (unsigned)blocks;
     blocks += (uint64_t)j.blocks_x * (uint64_t)q.nbatch;
     if (blocks > 0x7fffffffull) return set_error(SRWN_E_SHAPE, "reduce_partials_multi: grid too large");
