@@ -43,6 +43,45 @@ __global__ __launch_bounds__(512) void k(const char* __restrict__ hbm, const cha
   if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) out[threadIdx.x] = acc[0];
 }
 
+// the same stream written instead of read (NT: non-temporal stores), optionally beside a read stream of RK KB per wave and step
+template <int SK, int RK, bool NT>
+__global__ __launch_bounds__(512) void kw(char* __restrict__ dst, const char* __restrict__ src, unsigned* out, int steps, size_t per_wg) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  char* dp = dst + (size_t)blockIdx.x * per_wg + (size_t)wave * SK * 1024 + lane * 16;
+  const char* sp = src + (size_t)blockIdx.x * per_wg + (size_t)wave * (RK > 0 ? RK : 1) * 1024 + lane * 16;
+  u32x4 acc = {1u + threadIdx.x, 2, 3, 4};
+  for (int s = 0; s < steps; ++s) {
+    u32x4 v[RK > 0 ? RK : 1];
+#pragma unroll
+    for (int i = 0; i < RK; ++i) v[i] = *reinterpret_cast<const u32x4*>(sp + (size_t)s * 8 * RK * 1024 + i * 1024);
+#pragma unroll
+    for (int i = 0; i < SK; ++i) {
+      u32x4* q = reinterpret_cast<u32x4*>(dp + (size_t)s * 8 * SK * 1024 + i * 1024);
+      if (NT) __builtin_nontemporal_store(acc, q); else *q = acc;
+    }
+#pragma unroll
+    for (int i = 0; i < RK; ++i) acc ^= v[i];
+    if ((s & 7) == 7) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  if ((acc[0] ^ acc[1]) == 0x12345678u) out[threadIdx.x] = acc[0];
+}
+
+template <int SK, int RK, bool NT> void runw(char* dst, const char* src, unsigned* out, int cus) {
+  const int steps = 1024;
+  const size_t per_wg = (size_t)steps * 8 * 4 * 1024;
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  float best = 1e30f;
+  for (int rep = 0; rep < 4; ++rep) {
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL((kw<SK, RK, NT>), dim3(cus), dim3(512), 0, 0, dst, src, out, steps, per_wg);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1); if (rep && ms < best) best = ms;
+  }
+  const double wb = (double)cus * steps * 8 * SK * 1024, rb = (double)cus * steps * 8 * RK * 1024;
+  printf("per wave and step: %d KB written (%s stores) + %d KB read from another stream: %7.3f ms  -> %5.2f TB/s chip (%5.2f written + %5.2f read)\n",
+         SK, NT ? "non-temporal" : "plain", RK, best, (wb + rb) / best / 1e9, wb / best / 1e9, rb / best / 1e9);
+}
+
 template <int HK, int WK> void run(const char* hbm, const char* img, size_t img_bytes, unsigned* out, int cus) {
   const int steps = 2048;
   const size_t per_wg = (size_t)steps * 8 * (HK > 0 ? HK : 1) * 1024;
@@ -75,5 +114,11 @@ int main() {
   run<2, 4>(hbm, img, img_bytes, out, cus);
   run<4, 2>(hbm, img, img_bytes, out, cus);
   run<0, 8>(hbm, img, img_bytes, out, cus);
+  char* dst = hbm + hbm_bytes / 2;      // (the write tests use the two halves of the buffer: 8 GiB each)
+  runw<4, 0, false>(dst, hbm, out, cus);
+  runw<4, 0, true>(dst, hbm, out, cus);
+  runw<4, 1, true>(dst, hbm, out, cus);
+  runw<2, 2, true>(dst, hbm, out, cus);
+  runw<1, 4, true>(dst, hbm, out, cus);
   return 0;
 }
