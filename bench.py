@@ -386,6 +386,9 @@ def main():
                 "bytes_per_launch": bwd_bytes_step / nlaunch, "operands": operands,
                 "bytes_per_launch_min_operands": min_bytes_step / nlaunch, "operands_min": operands_min,
                 "frac_min_operands": min_bytes_step / nlaunch / (bwd_launch_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                # what a streaming kernel with this kernel's mix of directions (87 % reads) reaches on this chip
+                # (tools/micro/cuingest.hip, profiles/r04_q_cu_ingest.txt: 1 KB written per 4 KB read); not a peak
+                "stream_rate_same_mix_GBs": 5370.0,
                 "launch_us": 1e3 * bwd_launch_ms,
                 "launch_us_eager_with_span_events": eager_launch_us,
                 # the same launches timed inside the schedule the timed region replays (weight-gradient passes running
