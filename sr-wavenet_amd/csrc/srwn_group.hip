@@ -515,7 +515,8 @@ struct GroupBwdArgs {
   // slab (workgroup, h) sums the tiles k = h mod that many)
   const float* ic_audio; float* ic_part; int ic_shift;
   unsigned long long* stamps;     // diagnostic instantiation only (srwn_debug_stamp_buffer): waves 0 and 4 of workgroup 0
-  int dbg;                        // diagnostic build only (SRWN_WT_DEBUG): 1 = skip the dWr contraction, 2 = skip the dWf one
+  int dbg;                        // diagnostic build only (SRWN_WT_DEBUG): 1 = skip the dWr contraction, 2 = skip the dWf one,
+                                  // 128 = the second wave of every pair that shares tile fragments loads none (timing only)
 };
 #ifdef SRWN_DIAG
 #define WT_DBG(a) ((a).dbg)
@@ -828,6 +829,8 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
 #pragma unroll
               for (int j = 0; j < 8; ++j) {
                 const int kn = k0 + 8 + j;
+                if ((WT_DBG(a) & 128) && (wave & 1)) nxt[j] = zero_frag<T>();      // (timing experiment: the second wave of a pair loads nothing)
+                else
                 nxt[j] = wt_load(ct + (size_t)(kn < ktn ? kn : ktn - 1) * (R * 32), 16 * ib, lw);
               }
 #pragma unroll
@@ -1075,6 +1078,8 @@ __global__ __launch_bounds__(64 * NWV) void group_bwd_kernel(GroupBwdArgs a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
               const int kn = k0 + 8 + j;
+              if ((WT_DBG(a) & 128) && wave >= NWV / 2) nxt[j] = zero_frag<T>();      // (timing experiment: see dWr)
+              else
               nxt[j] = wt_load(xt + (size_t)(kn < ktn ? kn : ktn - 1) * (R * 32), 16 * ibl, lw);
             }
 #pragma unroll

@@ -35,7 +35,7 @@ for _ in range(7):
 print("FENCE %%s %%.2f %%.2f" %% (os.environ.get("SRWN_WT_DEBUG", "0"), float(np.median(ts)), min(ts)))
 """
 for rnd in range(2):
-    for dbg in ("0", "32", "96"):
+    for dbg in (sys.argv[1:] or ["0", "32", "96"]):
         env = dict(os.environ, SRWN_WT_DEBUG=dbg, SRWN_LIB_PATH=os.path.join(ROOT, "sr-wavenet_amd", "libsrwn_diag.so"))
         r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
         out = [l for l in r.stdout.splitlines() if l.startswith("FENCE")]
