@@ -111,6 +111,12 @@ def build(force: bool = False, verbose: bool = False, diag: bool = False, varian
     SRWN_LIB_PATH (ctypes binding, no manifest).  variant="name" + extra_flags: an A/B build of the same sources with
     extra compiler flags -> ab/libsrwn_<name>.so (git-ignored; objects under csrc/ab_<name>/), also for SRWN_LIB_PATH."""
     import json
+    per_src = {}      # "srwn_x.hip:-flag" in extra_flags: that source only (A/B builds of one translation unit's options)
+    for f in list(extra_flags):
+        if ".hip:" in f:
+            name, fl = f.split(":", 1)
+            per_src.setdefault(name, []).extend(fl.split("=", 1) if fl.startswith("-mllvm=") else [fl])
+    extra_flags = [f for f in extra_flags if ".hip:" not in f]
     flags = FLAGS + (["-DSRWN_DIAG"] if diag else []) + list(extra_flags)
     if variant:
         diag = True      # (same treatment: no pybind module, no product manifest)
@@ -137,10 +143,11 @@ def build(force: bool = False, verbose: bool = False, diag: bool = False, varian
     def cc(pair):
         src, obj = pair
         rel = os.path.basename(src)
-        key = _sha([src] + deps, " ".join(flags))
+        sflags = flags + per_src.get(rel, [])
+        key = _sha([src] + deps, " ".join(sflags))
         if force or not os.path.exists(obj) or old.get(rel) != key:
             guarded = NO_SPILL.get(rel, [])
-            cmd = [HIPCC] + flags + (["-Rpass-analysis=kernel-resource-usage"] if guarded else []) + ["-c", src, "-o", obj]
+            cmd = [HIPCC] + sflags + (["-Rpass-analysis=kernel-resource-usage"] if guarded else []) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             r = subprocess.run(cmd, capture_output=True, text=True)
@@ -148,7 +155,7 @@ def build(force: bool = False, verbose: bool = False, diag: bool = False, varian
                 raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-8000:]))
             if guarded:
                 _check_no_spill(src, obj, r.stderr, guarded)
-                _check_inflight(src, obj, flags, guarded)
+                _check_inflight(src, obj, sflags, guarded)
         keys[rel] = key
         return obj
 
@@ -249,7 +256,8 @@ def build_io(force: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    # python build.py [--force] [--diag] [--variant NAME -DFLAG ...]
+    # python build.py [--force] [--diag] [--variant NAME -DFLAG ... -mllvm=-llvm-option=value ... srwn_x.hip:-mllvm=-option=value ...]
     _variant = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else ""
     print(build(force="--force" in sys.argv, verbose=True, diag="--diag" in sys.argv, variant=_variant,
-                extra_flags=[a for a in sys.argv[1:] if a.startswith("-D")]))
+                extra_flags=[a for a in sys.argv[1:] if a.startswith("-D") or a.startswith("-mllvm=") or ".hip:" in a
+                             for a in (a.split("=", 1) if a.startswith("-mllvm=") else [a])]))      # -mllvm=-opt=val -> -mllvm -opt=val
